@@ -1,0 +1,94 @@
+"""ctypes binding of libgeot_hip.so (the C ABI declared in include/geot_hip.h).
+
+This is the reference-side stub a maintainer would write to bind the library
+(see INTEGRATION.md): plain pointers and sizes, no torch types cross the
+boundary.  The library is the ONLY compute path of this package: if it is
+missing or fails to load, every op raises -- there is no CPU or PyTorch
+fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgeot_hip.so")
+
+_c_int, _c_float, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
+_P = ctypes.c_void_p  # device pointers are passed as raw addresses
+
+# name -> argtypes (all return int = hipError_t), in include/geot_hip.h order.
+PROTOTYPES = {
+    "geot_furthest_point_sampling": [_c_int, _c_int, _c_int, _P, _P, _P, _c_int, _c_int, _c_void_p],
+    "geot_furthestsampling_offset": [_c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_gather_points": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
+    "geot_gather_points_grad": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
+    "geot_ball_query": [_c_int, _c_int, _c_int, _c_float, _c_int, _P, _P, _P, _c_void_p],
+    "geot_ballquery_offset": [_c_int, _c_int, _c_float, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_group_points": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
+    "geot_group_points_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
+    "geot_three_nn": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_three_interpolate_grad": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_knnquery_heap": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_knn_sorted": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_grouping_cl": [_c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
+    "geot_grouping_cl_grad": [_c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
+    "geot_interpolation_cl": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_interpolation_cl_grad": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_subtraction_cl": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_subtraction_cl_grad": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_aggregation_cl": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_aggregation_cl_grad": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
+}
+
+_lib = None
+
+
+class GeotLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libgeot_hip.so once.  Raises GeotLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GeotLibraryError(
+            "geot_amd: %s is missing -- build it with `python -m geot_amd.build` "
+            "(there is no CPU/PyTorch fallback)" % LIB_PATH)
+    # Make sure the HIP runtime torch already uses is the one the library binds
+    # to (same SONAME libamdhip64.so.7 => the loader reuses the loaded copy), so
+    # torch's stream handles are valid in our launches.
+    try:
+        import torch  # noqa: F401
+        tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(tl):
+            ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
+    except ImportError:
+        pass
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise GeotLibraryError("geot_amd: cannot load %s: %s" % (LIB_PATH, e))
+    lib.geot_abi_version.restype = _c_int
+    lib.geot_abi_version.argtypes = []
+    lib.geot_error_string.restype = ctypes.c_char_p
+    lib.geot_error_string.argtypes = [_c_int]
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = _c_int
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(err, what):
+    if err != 0:
+        msg = load().geot_error_string(err)
+        raise RuntimeError("geot_amd: %s failed: %s (hipError %d)" %
+                           (what, msg.decode() if msg else "?", err))
+
+
+def exported_symbols():
+    """All C-ABI symbol names the Python side binds."""
+    return ["geot_abi_version", "geot_error_string"] + list(PROTOTYPES)

@@ -1,0 +1,433 @@
+// gather_group.hip -- index gathers / scatter-adds for gfx950 (MI355X).
+//
+// Replaces (behaviour, not code):
+//   gather            : pointnet2/_ext_src/src/sampling_gpu.cu:11-60,
+//                       openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:15-92
+//   group             : pointnet2/_ext_src/src/group_points_gpu.cu:11-78,
+//                       openpoints/cpp/pointnet2_batch/src/group_points_gpu.cu:14-93
+//   three_interpolate : pointnet2/_ext_src/src/interpolate_gpu.cu:75-157,
+//                       openpoints/cpp/pointnet2_batch/src/interpolate_gpu.cu:84-170
+//   channels-last ops : openpoints/cpp/pointops/src/{grouping,interpolation,
+//                       subtraction,aggregation}/*_cuda_kernel.cu
+//
+// These are HBM-bound copies. Layout rule used throughout: consecutive lanes
+// walk the contiguous output dimension so stores coalesce, each lane loads its
+// index (and weights) once and reuses them across a chunk of channels, and the
+// random reads hit rows that are L2-resident (one channel row of a 24k-point
+// cloud is 96 KB).
+#include "geot_common.h"
+#include "geot_hip.h"
+
+namespace geot {
+
+constexpr int GG_THREADS = 256;
+constexpr int GG_CCHUNK = 8; // channels handled per lane (index reuse)
+
+// out[b,c,j] = points[b,c,idx[b,j]]
+__global__ __launch_bounds__(GG_THREADS) void gather_points_kernel(
+    int c, int n, int m, const float *__restrict__ points, const int *__restrict__ idx,
+    float *__restrict__ out)
+{
+    const int bi = blockIdx.z, c0 = blockIdx.y * GG_CCHUNK;
+    const int j = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (j >= m) return;
+    const int a = idx[(size_t)bi * m + j];
+    const int cend = min(c0 + GG_CCHUNK, c);
+    for (int l = c0; l < cend; ++l)
+        out[((size_t)bi * c + l) * m + j] = points[((size_t)bi * c + l) * n + a];
+}
+
+__global__ __launch_bounds__(GG_THREADS) void gather_points_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points)
+{
+    const int bi = blockIdx.z, c0 = blockIdx.y * GG_CCHUNK;
+    const int j = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (j >= m) return;
+    const int a = idx[(size_t)bi * m + j];
+    const int cend = min(c0 + GG_CCHUNK, c);
+    for (int l = c0; l < cend; ++l)
+        atomicAdd(grad_points + ((size_t)bi * c + l) * n + a, grad_out[((size_t)bi * c + l) * m + j]);
+}
+
+// out[b,c,j,k] = points[b,c,idx[b,j,k]]; (j,k) flattened = the contiguous dim.
+__global__ __launch_bounds__(GG_THREADS) void group_points_kernel(
+    int c, int n, int npns, const float *__restrict__ points, const int *__restrict__ idx,
+    float *__restrict__ out)
+{
+    const int bi = blockIdx.z, c0 = blockIdx.y * GG_CCHUNK;
+    const int e = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (e >= npns) return;
+    const int a = idx[(size_t)bi * npns + e];
+    const int cend = min(c0 + GG_CCHUNK, c);
+    for (int l = c0; l < cend; ++l)
+        out[((size_t)bi * c + l) * npns + e] = points[((size_t)bi * c + l) * n + a];
+}
+
+__global__ __launch_bounds__(GG_THREADS) void group_points_grad_kernel(
+    int c, int n, int npns, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_points)
+{
+    const int bi = blockIdx.z, c0 = blockIdx.y * GG_CCHUNK;
+    const int e = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (e >= npns) return;
+    const int a = idx[(size_t)bi * npns + e];
+    const int cend = min(c0 + GG_CCHUNK, c);
+    for (int l = c0; l < cend; ++l)
+        atomicAdd(grad_points + ((size_t)bi * c + l) * n + a, grad_out[((size_t)bi * c + l) * npns + e]);
+}
+
+// out[b,c,j] = sum_t points[b,c,idx[b,j,t]] * weight[b,j,t]
+// Evaluation order follows the reference expression p0*w0 + p1*w1 + p2*w2.
+__global__ __launch_bounds__(GG_THREADS) void three_interpolate_kernel(
+    int c, int m, int n, const float *__restrict__ points, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ out)
+{
+    const int bi = blockIdx.z, c0 = blockIdx.y * GG_CCHUNK;
+    const int j = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (j >= n) return;
+    const size_t o = ((size_t)bi * n + j) * 3;
+    const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
+    const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
+    const int cend = min(c0 + GG_CCHUNK, c);
+    for (int l = c0; l < cend; ++l) {
+        const float *P = points + ((size_t)bi * c + l) * m;
+        out[((size_t)bi * c + l) * n + j] = P[i0] * w0 + P[i1] * w1 + P[i2] * w2;
+    }
+}
+
+__global__ __launch_bounds__(GG_THREADS) void three_interpolate_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_points)
+{
+    const int bi = blockIdx.z, c0 = blockIdx.y * GG_CCHUNK;
+    const int j = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (j >= n) return;
+    const size_t o = ((size_t)bi * n + j) * 3;
+    const int i0 = idx[o], i1 = idx[o + 1], i2 = idx[o + 2];
+    const float w0 = weight[o], w1 = weight[o + 1], w2 = weight[o + 2];
+    const int cend = min(c0 + GG_CCHUNK, c);
+    for (int l = c0; l < cend; ++l) {
+        const float g = grad_out[((size_t)bi * c + l) * n + j];
+        float *G = grad_points + ((size_t)bi * c + l) * m;
+        atomicAdd(G + i0, g * w0);
+        atomicAdd(G + i1, g * w1);
+        atomicAdd(G + i2, g * w2);
+    }
+}
+
+// ---- channels-last (openpoints pointops) -----------------------------------
+// One lane per output element with the channel index fastest, so both the
+// gathered row reads and the stores are contiguous across the wave.
+__global__ __launch_bounds__(GG_THREADS) void grouping_cl_kernel(
+    long long total, int ns, int c, const float *__restrict__ input, const int *__restrict__ idx,
+    float *__restrict__ out)
+{
+    for (long long e = (long long)blockIdx.x * GG_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * GG_THREADS) {
+        int ch = (int)(e % c);
+        long long ms = e / c; // m_idx*ns + s
+        out[e] = input[(size_t)idx[ms] * c + ch];
+    }
+}
+
+__global__ __launch_bounds__(GG_THREADS) void grouping_cl_grad_kernel(
+    long long total, int ns, int c, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    float *__restrict__ grad_in)
+{
+    for (long long e = (long long)blockIdx.x * GG_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * GG_THREADS) {
+        int ch = (int)(e % c);
+        long long ms = e / c;
+        atomicAdd(grad_in + (size_t)idx[ms] * c + ch, grad_out[e]);
+    }
+}
+
+// The reference accumulates into a pre-zeroed output (output[index] += ...).
+__global__ __launch_bounds__(GG_THREADS) void interpolation_cl_kernel(
+    long long total, int c, int k, const float *__restrict__ input, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ out)
+{
+    for (long long e = (long long)blockIdx.x * GG_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * GG_THREADS) {
+        int ch = (int)(e % c);
+        long long ni = e / c;
+        float acc = out[e];
+        for (int t = 0; t < k; ++t)
+            acc += input[(size_t)idx[ni * k + t] * c + ch] * weight[ni * k + t];
+        out[e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(GG_THREADS) void interpolation_cl_grad_kernel(
+    long long total, int c, int k, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_in)
+{
+    for (long long e = (long long)blockIdx.x * GG_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * GG_THREADS) {
+        int ch = (int)(e % c);
+        long long ni = e / c;
+        float g = grad_out[e];
+        for (int t = 0; t < k; ++t)
+            atomicAdd(grad_in + (size_t)idx[ni * k + t] * c + ch, g * weight[ni * k + t]);
+    }
+}
+
+__global__ __launch_bounds__(GG_THREADS) void subtraction_cl_kernel(
+    long long total, int ns, int c, const float *__restrict__ in1, const float *__restrict__ in2,
+    const int *__restrict__ idx, float *__restrict__ out)
+{
+    for (long long e = (long long)blockIdx.x * GG_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * GG_THREADS) {
+        int ch = (int)(e % c);
+        long long ms = e / c;
+        long long ni = ms / ns;
+        out[e] = in1[ni * c + ch] - in2[(size_t)idx[ms] * c + ch];
+    }
+}
+
+__global__ __launch_bounds__(GG_THREADS) void subtraction_cl_grad_kernel(
+    long long total, int ns, int c, const int *__restrict__ idx, const float *__restrict__ grad_out,
+    float *__restrict__ g1, float *__restrict__ g2)
+{
+    for (long long e = (long long)blockIdx.x * GG_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * GG_THREADS) {
+        int ch = (int)(e % c);
+        long long ms = e / c;
+        long long ni = ms / ns;
+        float g = grad_out[e];
+        atomicAdd(g1 + ni * c + ch, g);
+        atomicAdd(g2 + (size_t)idx[ms] * c + ch, -g);
+    }
+}
+
+__global__ __launch_bounds__(GG_THREADS) void aggregation_cl_kernel(
+    long long total, int ns, int c, int w_c, const float *__restrict__ input,
+    const float *__restrict__ position, const float *__restrict__ weight,
+    const int *__restrict__ idx, float *__restrict__ out)
+{
+    for (long long e = (long long)blockIdx.x * GG_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * GG_THREADS) {
+        int ch = (int)(e % c);
+        long long ni = e / c;
+        int wch = ch % w_c;
+        float acc = out[e];
+        for (int s = 0; s < ns; ++s) {
+            long long ms = ni * ns + s;
+            acc += (input[(size_t)idx[ms] * c + ch] + position[ms * c + ch]) * weight[ms * w_c + wch];
+        }
+        out[e] = acc;
+    }
+}
+
+__global__ __launch_bounds__(GG_THREADS) void aggregation_cl_grad_kernel(
+    long long total, int ns, int c, int w_c, const float *__restrict__ input,
+    const float *__restrict__ position, const float *__restrict__ weight,
+    const int *__restrict__ idx, const float *__restrict__ grad_out, float *__restrict__ g_in,
+    float *__restrict__ g_pos, float *__restrict__ g_w)
+{
+    for (long long e = (long long)blockIdx.x * GG_THREADS + threadIdx.x; e < total;
+         e += (long long)gridDim.x * GG_THREADS) {
+        int ch = (int)(e % c);
+        long long ni = e / c;
+        int wch = ch % w_c;
+        float g = grad_out[e];
+        for (int s = 0; s < ns; ++s) {
+            long long ms = ni * ns + s;
+            size_t ii = (size_t)idx[ms] * c + ch;
+            float w = weight[ms * w_c + wch];
+            atomicAdd(g_in + ii, g * w);
+            g_pos[ms * c + ch] = g * w;
+            atomicAdd(g_w + ms * w_c + wch, g * (input[ii] + position[ms * c + ch]));
+        }
+    }
+}
+
+static inline dim3 grid3(long long inner, int c, int b)
+{
+    return dim3((unsigned)((inner + GG_THREADS - 1) / GG_THREADS), (unsigned)((c + GG_CCHUNK - 1) / GG_CCHUNK),
+                (unsigned)b);
+}
+static inline dim3 grid1(long long total)
+{
+    long long blocks = (total + GG_THREADS - 1) / GG_THREADS;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    return dim3((unsigned)blocks);
+}
+
+} // namespace geot
+
+using namespace geot;
+
+#define GEOT_CHECK_DIMS3(b, c) \
+    if ((b) > 65535 || ((c) + GG_CCHUNK - 1) / GG_CCHUNK > 65535) return hipErrorInvalidValue
+
+GEOT_EXPORT int geot_gather_points(int b, int c, int n, int m, const float *points, const int *idx,
+                                   float *out, void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || m == 0) return hipSuccess;
+    GEOT_CHECK_DIMS3(b, c);
+    hipLaunchKernelGGL(gather_points_kernel, grid3(m, c, b), dim3(GG_THREADS), 0, (hipStream_t)stream, c,
+                       n, m, points, idx, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_gather_points_grad(int b, int c, int n, int m, const float *grad_out,
+                                        const int *idx, float *grad_points, void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || m == 0) return hipSuccess;
+    GEOT_CHECK_DIMS3(b, c);
+    hipLaunchKernelGGL(gather_points_grad_kernel, grid3(m, c, b), dim3(GG_THREADS), 0,
+                       (hipStream_t)stream, c, n, m, grad_out, idx, grad_points);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                                  const int *idx, float *out, void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return hipErrorInvalidValue;
+    long long npns = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || npns == 0) return hipSuccess;
+    if (npns > 0x7fffffffLL) return hipErrorInvalidValue;
+    GEOT_CHECK_DIMS3(b, c);
+    hipLaunchKernelGGL(group_points_kernel, grid3(npns, c, b), dim3(GG_THREADS), 0, (hipStream_t)stream,
+                       c, n, (int)npns, points, idx, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_group_points_grad(int b, int c, int n, int npoints, int nsample,
+                                       const float *grad_out, const int *idx, float *grad_points,
+                                       void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0) return hipErrorInvalidValue;
+    long long npns = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || npns == 0) return hipSuccess;
+    if (npns > 0x7fffffffLL) return hipErrorInvalidValue;
+    GEOT_CHECK_DIMS3(b, c);
+    hipLaunchKernelGGL(group_points_grad_kernel, grid3(npns, c, b), dim3(GG_THREADS), 0,
+                       (hipStream_t)stream, c, n, (int)npns, grad_out, idx, grad_points);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                                       const float *weight, float *out, void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || n == 0) return hipSuccess;
+    GEOT_CHECK_DIMS3(b, c);
+    hipLaunchKernelGGL(three_interpolate_kernel, grid3(n, c, b), dim3(GG_THREADS), 0,
+                       (hipStream_t)stream, c, m, n, points, idx, weight, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out,
+                                            const int *idx, const float *weight, float *grad_points,
+                                            void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || n == 0) return hipSuccess;
+    GEOT_CHECK_DIMS3(b, c);
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, grid3(n, c, b), dim3(GG_THREADS), 0,
+                       (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_grouping_cl(int m, int nsample, int c, const float *input, const int *idx,
+                                 float *out, void *stream)
+{
+    long long total = (long long)m * nsample * c;
+    if (m < 0 || nsample < 0 || c < 0) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(grouping_cl_kernel, grid1(total), dim3(GG_THREADS), 0, (hipStream_t)stream, total,
+                       nsample, c, input, idx, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_grouping_cl_grad(int m, int nsample, int c, const float *grad_out, const int *idx,
+                                      float *grad_in, void *stream)
+{
+    long long total = (long long)m * nsample * c;
+    if (m < 0 || nsample < 0 || c < 0) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(grouping_cl_grad_kernel, grid1(total), dim3(GG_THREADS), 0, (hipStream_t)stream,
+                       total, nsample, c, grad_out, idx, grad_in);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_interpolation_cl(int n, int c, int k, const float *input, const int *idx,
+                                      const float *weight, float *out, void *stream)
+{
+    long long total = (long long)n * c;
+    if (n < 0 || c < 0 || k < 0) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(interpolation_cl_kernel, grid1(total), dim3(GG_THREADS), 0, (hipStream_t)stream,
+                       total, c, k, input, idx, weight, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_interpolation_cl_grad(int n, int c, int k, const float *grad_out, const int *idx,
+                                           const float *weight, float *grad_in, void *stream)
+{
+    long long total = (long long)n * c;
+    if (n < 0 || c < 0 || k < 0) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(interpolation_cl_grad_kernel, grid1(total), dim3(GG_THREADS), 0,
+                       (hipStream_t)stream, total, c, k, grad_out, idx, weight, grad_in);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_subtraction_cl(int n, int nsample, int c, const float *in1, const float *in2,
+                                    const int *idx, float *out, void *stream)
+{
+    long long total = (long long)n * nsample * c;
+    if (n < 0 || nsample < 0 || c < 0) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(subtraction_cl_kernel, grid1(total), dim3(GG_THREADS), 0, (hipStream_t)stream,
+                       total, nsample, c, in1, in2, idx, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_subtraction_cl_grad(int n, int nsample, int c, const int *idx,
+                                         const float *grad_out, float *grad_in1, float *grad_in2,
+                                         void *stream)
+{
+    long long total = (long long)n * nsample * c;
+    if (n < 0 || nsample < 0 || c < 0) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(subtraction_cl_grad_kernel, grid1(total), dim3(GG_THREADS), 0,
+                       (hipStream_t)stream, total, nsample, c, idx, grad_out, grad_in1, grad_in2);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_aggregation_cl(int n, int nsample, int c, int w_c, const float *input,
+                                    const float *position, const float *weight, const int *idx,
+                                    float *out, void *stream)
+{
+    long long total = (long long)n * c;
+    if (n < 0 || nsample < 0 || c < 0 || w_c <= 0) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(aggregation_cl_kernel, grid1(total), dim3(GG_THREADS), 0, (hipStream_t)stream,
+                       total, nsample, c, w_c, input, position, weight, idx, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_aggregation_cl_grad(int n, int nsample, int c, int w_c, const float *input,
+                                         const float *position, const float *weight, const int *idx,
+                                         const float *grad_out, float *grad_in, float *grad_position,
+                                         float *grad_weight, void *stream)
+{
+    long long total = (long long)n * c;
+    if (n < 0 || nsample < 0 || c < 0 || w_c <= 0) return hipErrorInvalidValue;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(aggregation_cl_grad_kernel, grid1(total), dim3(GG_THREADS), 0,
+                       (hipStream_t)stream, total, nsample, c, w_c, input, position, weight, idx,
+                       grad_out, grad_in, grad_position, grad_weight);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_abi_version(void) { return GEOT_ABI_VERSION; }
+
+GEOT_EXPORT const char *geot_error_string(int e) { return hipGetErrorString((hipError_t)e); }

@@ -1,0 +1,90 @@
+// geot_common.h -- shared device helpers for the gfx950 kernels.
+// All translation units are built with -ffp-contract=off: squared distances
+// must be un-contracted IEEE fp32 so integer results match the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GEOT_EXPORT extern "C" __attribute__((visibility("default")))
+#define GEOT_WAVE 64
+
+namespace geot {
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return s;
+}
+
+// fminf without the canonicalising v_max_f32 the compiler puts in front of
+// llvm.minnum under IEEE mode. v_min_f32 returns the non-NaN operand, which is
+// the fminf/CUDA min semantics the reference relies on.
+__device__ __forceinline__ float fmin_raw(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// ---- DPP cross-lane moves (no LDS traffic) --------------------------------
+// dpp_ctrl encodings (GFX9): quad_perm 0x00-0xFF, row_mirror 0x140,
+// row_half_mirror 0x141.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+
+constexpr int DPP_QUAD_XOR1 = 0xB1;       // quad_perm [1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;       // quad_perm [2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// After these four steps every lane of a 16-lane row holds the row's result.
+__device__ __forceinline__ uint32_t row16_max_u32(uint32_t v)
+{
+    v = max(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = max(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = max(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = max(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t row16_min_u32(uint32_t v)
+{
+    v = min(v, dpp_mov<DPP_QUAD_XOR1>(v));
+    v = min(v, dpp_mov<DPP_QUAD_XOR2>(v));
+    v = min(v, dpp_mov<DPP_ROW_HALF_MIRROR>(v));
+    v = min(v, dpp_mov<DPP_ROW_MIRROR>(v));
+    return v;
+}
+__device__ __forceinline__ float row16_min_f32(float v)
+{
+    v = fminf(v, __uint_as_float(dpp_mov<DPP_QUAD_XOR1>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(dpp_mov<DPP_QUAD_XOR2>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(dpp_mov<DPP_ROW_HALF_MIRROR>(__float_as_uint(v))));
+    v = fminf(v, __uint_as_float(dpp_mov<DPP_ROW_MIRROR>(__float_as_uint(v))));
+    return v;
+}
+
+// Wave-uniform results (returned in SGPRs via readlane).
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    v = row16_max_u32(v);
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    v = row16_min_u32(v);
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+} // namespace geot

@@ -1,0 +1,312 @@
+// neighbors.hip -- radius / nearest-neighbour searches for gfx950 (MI355X).
+//
+// Replaces (behaviour, not code):
+//   ball query : pointnet2/_ext_src/src/ball_query_gpu.cu:12-57,
+//                openpoints/cpp/pointnet2_batch/src/ball_query_gpu.cu:15-74,
+//                openpoints/cpp/pointops/src/ballquery/ballquery_cuda_kernel.cu:13-88
+//   three_nn   : pointnet2/_ext_src/src/interpolate_gpu.cu:12-71,
+//                openpoints/cpp/pointnet2_batch/src/interpolate_gpu.cu:16-72
+//   kNN (heap) : pointops/src/knnquery/knnquery_cuda_kernel.cu:21-116
+//   kNN (sorted): contract of knn_cuda.KNN / knn_point
+//
+// All of these are O(queries x support) scans of fp32 coordinates that fit in
+// L2; they are VALU-bound, not HBM-bound. Support points are staged through
+// LDS in tiles so that every lane of a wave reads the same address
+// (broadcast, conflict-free) while each lane owns one query.
+#include "geot_common.h"
+#include "geot_hip.h"
+
+namespace geot {
+
+// ---------------------------------------------------------------------------
+// Ball query: one wave per query, the 64 lanes test 64 consecutive support
+// points per step, so "the first nsample hits in ascending index order" falls
+// out of a ballot + prefix popcount, and the wave stops as soon as nsample
+// hits are found (same early exit as the reference's serial scan).
+// ---------------------------------------------------------------------------
+constexpr int BQ_WAVES = 4;
+
+__device__ __forceinline__ void ball_query_one(const float *__restrict__ P, int n_pts, int idx_base,
+                                               float qx, float qy, float qz, float r2, int nsample,
+                                               int *__restrict__ hits, int *__restrict__ out)
+{
+    const int lane = lane_id();
+    int cnt = 0;
+    for (int k0 = 0; k0 < n_pts && cnt < nsample; k0 += 64) {
+        int k = k0 + lane;
+        bool hit = false;
+        if (k < n_pts) {
+            float d2 = sqdist3(qx, qy, qz, P[k * 3 + 0], P[k * 3 + 1], P[k * 3 + 2]);
+            hit = d2 < r2;
+        }
+        unsigned long long mask = __ballot(hit);
+        if (mask) {
+            int rank = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (hit && rank < nsample) hits[rank] = idx_base + k;
+            cnt += __popcll(mask);
+        }
+    }
+    if (cnt > nsample) cnt = nsample;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    int first = cnt ? hits[0] : 0;
+    for (int l = lane; l < nsample; l += 64) out[l] = l < cnt ? hits[l] : first;
+}
+
+__global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
+    int b, int n, int m, float radius, int nsample, const float *__restrict__ new_xyz,
+    const float *__restrict__ xyz, int *__restrict__ idx)
+{
+    extern __shared__ int bq_hits[];
+    const int wave = threadIdx.x >> 6;
+    int *hits = bq_hits + wave * nsample;
+    const float r2 = radius * radius;
+    const long long total = (long long)b * m;
+    for (long long q = (long long)blockIdx.x * BQ_WAVES + wave; q < total;
+         q += (long long)gridDim.x * BQ_WAVES) {
+        int bi = (int)(q / m);
+        const float *Q = new_xyz + q * 3;
+        ball_query_one(xyz + (size_t)bi * n * 3, n, 0, Q[0], Q[1], Q[2], r2, nsample, hits,
+                       idx + q * nsample);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__device__ __forceinline__ int segment_of(int pt, const int *__restrict__ off, int b)
+{
+    int i = 0;
+    while (i < b - 1 && !(pt < off[i])) ++i;
+    return i;
+}
+
+__global__ __launch_bounds__(BQ_WAVES * 64) void ballquery_offset_kernel(
+    int b, int m, float radius, int nsample, const float *__restrict__ xyz,
+    const float *__restrict__ new_xyz, const int *__restrict__ offset,
+    const int *__restrict__ new_offset, int *__restrict__ idx)
+{
+    extern __shared__ int bq_hits[];
+    const int wave = threadIdx.x >> 6;
+    int *hits = bq_hits + wave * nsample;
+    const float r2 = radius * radius;
+    for (int q = blockIdx.x * BQ_WAVES + wave; q < m; q += gridDim.x * BQ_WAVES) {
+        int bt = segment_of(q, new_offset, b);
+        int start = bt ? offset[bt - 1] : 0, end = offset[bt];
+        const float *Q = new_xyz + (size_t)q * 3;
+        ball_query_one(xyz + (size_t)start * 3, end - start, start, Q[0], Q[1], Q[2], r2, nsample,
+                       hits, idx + (size_t)q * nsample);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// three_nn: one lane per unknown point, known points streamed through LDS.
+// Result = 3 smallest by (d2, index): strict '<' while scanning k ascending.
+// The reference keeps the running bests as doubles initialised to 1e40; with
+// fp32 candidates that is the same as fp32 bests initialised to +inf.
+// ---------------------------------------------------------------------------
+constexpr int NN_THREADS = 256;
+constexpr int NN_TILE = 1024;
+
+__global__ __launch_bounds__(NN_THREADS) void three_nn_kernel(
+    int n, int m, const float *__restrict__ unknown, const float *__restrict__ known,
+    float *__restrict__ dist2, int *__restrict__ idx)
+{
+    __shared__ float tile[NN_TILE * 3];
+    const int bi = blockIdx.y;
+    const float *U = unknown + (size_t)bi * n * 3;
+    const float *K = known + (size_t)bi * m * 3;
+    const int j = blockIdx.x * NN_THREADS + threadIdx.x;
+    const bool live = j < n;
+    float ux = 0, uy = 0, uz = 0;
+    if (live) { ux = U[j * 3]; uy = U[j * 3 + 1]; uz = U[j * 3 + 2]; }
+    float b1 = INFINITY, b2 = INFINITY, b3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    for (int k0 = 0; k0 < m; k0 += NN_TILE) {
+        int cnt = min(NN_TILE, m - k0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * 3; t += NN_THREADS) tile[t] = K[(size_t)k0 * 3 + t];
+        __syncthreads();
+        for (int t = 0; t < cnt; ++t) {
+            float d = sqdist3(ux, uy, uz, tile[t * 3], tile[t * 3 + 1], tile[t * 3 + 2]);
+            if (d < b3) {
+                int k = k0 + t;
+                if (d < b1) { b3 = b2; i3 = i2; b2 = b1; i2 = i1; b1 = d; i1 = k; }
+                else if (d < b2) { b3 = b2; i3 = i2; b2 = d; i2 = k; }
+                else { b3 = d; i3 = k; }
+            }
+        }
+    }
+    if (live) {
+        size_t o = ((size_t)bi * n + j) * 3;
+        dist2[o] = b1; dist2[o + 1] = b2; dist2[o + 2] = b3;
+        idx[o] = i1; idx[o + 1] = i2; idx[o + 2] = i3;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// kNN, both flavours: one lane per query, its candidate list in LDS laid out
+// [slot][lane] (bank = lane, so the common "all lanes touch slot s" access is
+// conflict-free), support points read through the L1/L2 (same address across
+// the wave except at segment boundaries).
+// ---------------------------------------------------------------------------
+constexpr int KNN_THREADS = 64;
+
+struct LdsList {
+    float *d;
+    int *i;
+    __device__ __forceinline__ float &D(int s) { return d[s * KNN_THREADS]; }
+    __device__ __forceinline__ int &I(int s) { return i[s * KNN_THREADS]; }
+};
+
+// Max-heap sift-down with the reference's exact comparison structure
+// (knnquery_cuda_kernel.cu:21-36): take the right child only if strictly
+// larger; stop only if root strictly larger than that child.
+__device__ __forceinline__ void heap_sift(LdsList h, int k)
+{
+    int root = 0, child = 1;
+    while (child < k) {
+        if (child + 1 < k && h.D(child + 1) > h.D(child)) ++child;
+        float dr = h.D(root), dc = h.D(child);
+        if (dr > dc) return;
+        h.D(root) = dc; h.D(child) = dr;
+        int ir = h.I(root); h.I(root) = h.I(child); h.I(child) = ir;
+        root = child;
+        child = 2 * root + 1;
+    }
+}
+
+__global__ __launch_bounds__(KNN_THREADS) void knnquery_heap_kernel(
+    int b, int m, int nsample, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+    const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ idx,
+    float *__restrict__ dist2)
+{
+    extern __shared__ float knn_lds[];
+    LdsList h{knn_lds + threadIdx.x, (int *)(knn_lds + nsample * KNN_THREADS) + threadIdx.x};
+    const int p = blockIdx.x * KNN_THREADS + threadIdx.x;
+    if (p >= m) return;
+    int bt = segment_of(p, new_offset, b);
+    int start = bt ? offset[bt - 1] : 0, end = offset[bt];
+    float qx = new_xyz[p * 3], qy = new_xyz[p * 3 + 1], qz = new_xyz[p * 3 + 2];
+    for (int s = 0; s < nsample; ++s) { h.D(s) = 1e10f; h.I(s) = start; }
+    float root = 1e10f;
+    for (int i = start; i < end; ++i) {
+        float d2 = sqdist3(qx, qy, qz, xyz[i * 3], xyz[i * 3 + 1], xyz[i * 3 + 2]);
+        if (d2 < root) {
+            h.D(0) = d2; h.I(0) = i;
+            heap_sift(h, nsample);
+            root = h.D(0);
+        }
+    }
+    for (int i = nsample - 1; i > 0; --i) {
+        float t = h.D(0); h.D(0) = h.D(i); h.D(i) = t;
+        int u = h.I(0); h.I(0) = h.I(i); h.I(i) = u;
+        heap_sift(h, i);
+    }
+    for (int s = 0; s < nsample; ++s) {
+        idx[(size_t)p * nsample + s] = h.I(s);
+        dist2[(size_t)p * nsample + s] = h.D(s);
+    }
+}
+
+// Sorted list, ascending by (d2, index): a candidate enters only if strictly
+// smaller than the current k-th, and is inserted after all entries <= it.
+__global__ __launch_bounds__(KNN_THREADS) void knn_sorted_kernel(
+    int nq, int nr, int k, const float *__restrict__ query, const float *__restrict__ ref,
+    int *__restrict__ idx, float *__restrict__ dist2)
+{
+    extern __shared__ float knn_lds[];
+    LdsList h{knn_lds + threadIdx.x, (int *)(knn_lds + k * KNN_THREADS) + threadIdx.x};
+    const int bi = blockIdx.y;
+    const int j = blockIdx.x * KNN_THREADS + threadIdx.x;
+    if (j >= nq) return;
+    const float *Q = query + ((size_t)bi * nq + j) * 3;
+    const float *R = ref + (size_t)bi * nr * 3;
+    float qx = Q[0], qy = Q[1], qz = Q[2];
+    for (int s = 0; s < k; ++s) { h.D(s) = INFINITY; h.I(s) = 0; }
+    float kth = INFINITY;
+    int filled = 0;
+    for (int r = 0; r < nr; ++r) {
+        float d = sqdist3(qx, qy, qz, R[r * 3], R[r * 3 + 1], R[r * 3 + 2]);
+        if (filled == k && !(d < kth)) continue;
+        int pos = filled < k ? filled : k - 1;
+        while (pos > 0 && d < h.D(pos - 1)) {
+            h.D(pos) = h.D(pos - 1); h.I(pos) = h.I(pos - 1);
+            --pos;
+        }
+        h.D(pos) = d; h.I(pos) = r;
+        if (filled < k) ++filled;
+        kth = h.D(k - 1);
+    }
+    size_t o = ((size_t)bi * nq + j) * k;
+    for (int s = 0; s < k; ++s) { idx[o + s] = h.I(s); dist2[o + s] = h.D(s); }
+}
+
+static inline int grid_cap(long long want, int cap) { return (int)(want < cap ? (want < 1 ? 1 : want) : cap); }
+
+} // namespace geot
+
+using namespace geot;
+
+GEOT_EXPORT int geot_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                const float *xyz, int *idx, void *stream)
+{
+    if (b < 0 || n < 0 || m < 0 || nsample < 0) return hipErrorInvalidValue;
+    if (b == 0 || m == 0 || nsample == 0) return hipSuccess;
+    size_t lds = (size_t)BQ_WAVES * nsample * sizeof(int);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    long long blocks = ((long long)b * m + BQ_WAVES - 1) / BQ_WAVES;
+    hipLaunchKernelGGL(ball_query_kernel, dim3(grid_cap(blocks, 1 << 16)), dim3(BQ_WAVES * 64), lds,
+                       (hipStream_t)stream, b, n, m, radius, nsample, new_xyz, xyz, idx);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ballquery_offset(int b, int m, float radius, int nsample, const float *xyz,
+                                      const float *new_xyz, const int *offset, const int *new_offset,
+                                      int *idx, void *stream)
+{
+    if (b < 0 || m < 0 || nsample < 0) return hipErrorInvalidValue;
+    if (b == 0 || m == 0 || nsample == 0) return hipSuccess;
+    size_t lds = (size_t)BQ_WAVES * nsample * sizeof(int);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    long long blocks = ((long long)m + BQ_WAVES - 1) / BQ_WAVES;
+    hipLaunchKernelGGL(ballquery_offset_kernel, dim3(grid_cap(blocks, 1 << 16)), dim3(BQ_WAVES * 64),
+                       lds, (hipStream_t)stream, b, m, radius, nsample, xyz, new_xyz, offset,
+                       new_offset, idx);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_three_nn(int b, int n, int m, const float *unknown, const float *known,
+                              float *dist2, int *idx, void *stream)
+{
+    if (b < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
+    if (b == 0 || n == 0) return hipSuccess;
+    if (b > 65535) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(three_nn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS, b), dim3(NN_THREADS), 0,
+                       (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_knnquery_heap(int b, int m, int nsample, const float *xyz, const float *new_xyz,
+                                   const int *offset, const int *new_offset, int *idx, float *dist2,
+                                   void *stream)
+{
+    if (b < 0 || m < 0 || nsample < 0 || nsample > 256) return hipErrorInvalidValue;
+    if (b == 0 || m == 0 || nsample == 0) return hipSuccess;
+    size_t lds = (size_t)nsample * KNN_THREADS * 8;
+    hipLaunchKernelGGL(knnquery_heap_kernel, dim3((m + KNN_THREADS - 1) / KNN_THREADS),
+                       dim3(KNN_THREADS), lds, (hipStream_t)stream, b, m, nsample, xyz, new_xyz, offset,
+                       new_offset, idx, dist2);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_knn_sorted(int b, int nq, int nr, int k, const float *query, const float *ref,
+                                int *idx, float *dist2, void *stream)
+{
+    if (b < 0 || nq < 0 || nr < 0 || k < 0 || k > 256) return hipErrorInvalidValue;
+    if (b == 0 || nq == 0 || k == 0) return hipSuccess;
+    if (b > 65535) return hipErrorInvalidValue;
+    size_t lds = (size_t)k * KNN_THREADS * 8;
+    hipLaunchKernelGGL(knn_sorted_kernel, dim3((nq + KNN_THREADS - 1) / KNN_THREADS, b),
+                       dim3(KNN_THREADS), lds, (hipStream_t)stream, nq, nr, k, query, ref, idx, dist2);
+    return hipGetLastError();
+}

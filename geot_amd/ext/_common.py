@@ -1,0 +1,61 @@
+"""Tensor validation + stream plumbing shared by the extension-shaped modules.
+
+Error behaviour: every violated precondition raises RuntimeError (the reference
+mixes AT_ASSERT -> RuntimeError, exit(-1) and no checks at all; we never exit and
+never silently read a bad tensor).  CPU tensors are rejected like the
+reference's AT_ASSERT(false, "CPU not supported") -- there is no CPU path.
+"""
+import torch
+
+from .. import _lib
+
+
+def req(t, name, dtype, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s: CPU not supported (tensor must live on the GPU)" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be a %s tensor, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be a contiguous tensor" % name)
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError("%s must have %d dimensions, got %d" % (name, ndim, t.dim()))
+    return t
+
+
+def f32(t, name, ndim=None):
+    return req(t, name, torch.float32, ndim)
+
+
+def i32(t, name, ndim=None):
+    return req(t, name, torch.int32, ndim)
+
+
+def same_device(*ts):
+    dev = ts[0].device
+    for t in ts[1:]:
+        if t.device != dev:
+            raise RuntimeError("all tensors must be on the same device (%s vs %s)" % (dev, t.device))
+    return dev
+
+
+def need(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def stream_of(dev):
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+def call(name, dev, *args):
+    """Launch C-ABI entry `name` on torch's current stream of `dev`."""
+    lib = _lib.load()
+    with torch.cuda.device(dev):
+        err = getattr(lib, name)(*args, stream_of(dev))
+    _lib.check(err, name)
+
+
+def ptr(t):
+    return t.data_ptr() if t is not None else None

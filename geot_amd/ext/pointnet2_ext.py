@@ -1,0 +1,109 @@
+"""Drop-in for the reference's ``pointnet2._ext`` module.
+
+Same nine callables, argument order and ownership as
+pointnet2/_ext_src/src/bindings.cpp:10-21: outputs are allocated here, zero /
+1e10-initialised exactly as the reference does (sampling.cpp:27-29,53-55,71-77;
+ball_query.cpp:22-24; group_points.cpp:25-27,50-52; interpolate.cpp:26-31,58-60,
+87-89), and returned.
+"""
+import torch
+
+from ._common import f32, i32, same_device, need, call, ptr
+
+
+def gather_points(points, idx):
+    f32(points, "points", 3); i32(idx, "idx", 2)
+    dev = same_device(points, idx)
+    b, c, n = points.shape
+    need(idx.shape[0] == b, "idx batch mismatch")
+    m = idx.shape[1]
+    out = torch.zeros((b, c, m), dtype=torch.float32, device=dev)
+    call("geot_gather_points", dev, b, c, n, m, ptr(points), ptr(idx), ptr(out))
+    return out
+
+
+def gather_points_grad(grad_out, idx, n):
+    f32(grad_out, "grad_out", 3); i32(idx, "idx", 2)
+    dev = same_device(grad_out, idx)
+    b, c, m = grad_out.shape
+    need(tuple(idx.shape) == (b, m), "idx shape mismatch")
+    out = torch.zeros((b, c, int(n)), dtype=torch.float32, device=dev)
+    call("geot_gather_points_grad", dev, b, c, int(n), m, ptr(grad_out), ptr(idx), ptr(out))
+    return out
+
+
+def furthest_point_sampling(points, nsamples):
+    f32(points, "points", 3)
+    need(points.shape[2] == 3, "points must be (B, N, 3)")
+    dev = points.device
+    b, n, _ = points.shape
+    nsamples = int(nsamples)
+    out = torch.zeros((b, nsamples), dtype=torch.int32, device=dev)
+    tmp = torch.full((b, n), 1e10, dtype=torch.float32, device=dev)
+    call("geot_furthest_point_sampling", dev, b, n, nsamples, ptr(points), ptr(tmp), ptr(out), 512, 1)
+    return out
+
+
+def three_nn(unknowns, knows):
+    f32(unknowns, "unknowns", 3); f32(knows, "knows", 3)
+    dev = same_device(unknowns, knows)
+    b, n, _ = unknowns.shape
+    need(knows.shape[0] == b and unknowns.shape[2] == 3 and knows.shape[2] == 3, "three_nn shape mismatch")
+    m = knows.shape[1]
+    idx = torch.zeros((b, n, 3), dtype=torch.int32, device=dev)
+    dist2 = torch.zeros((b, n, 3), dtype=torch.float32, device=dev)
+    call("geot_three_nn", dev, b, n, m, ptr(unknowns), ptr(knows), ptr(dist2), ptr(idx))
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    f32(points, "points", 3); i32(idx, "idx", 3); f32(weight, "weight", 3)
+    dev = same_device(points, idx, weight)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    need(tuple(idx.shape) == (b, n, 3) and tuple(weight.shape) == (b, n, 3), "idx/weight must be (B, n, 3)")
+    out = torch.zeros((b, c, n), dtype=torch.float32, device=dev)
+    call("geot_three_interpolate", dev, b, c, m, n, ptr(points), ptr(idx), ptr(weight), ptr(out))
+    return out
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    f32(grad_out, "grad_out", 3); i32(idx, "idx", 3); f32(weight, "weight", 3)
+    dev = same_device(grad_out, idx, weight)
+    b, c, n = grad_out.shape
+    need(tuple(idx.shape) == (b, n, 3) and tuple(weight.shape) == (b, n, 3), "idx/weight must be (B, n, 3)")
+    out = torch.zeros((b, c, int(m)), dtype=torch.float32, device=dev)
+    call("geot_three_interpolate_grad", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out))
+    return out
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    f32(new_xyz, "new_xyz", 3); f32(xyz, "xyz", 3)
+    dev = same_device(new_xyz, xyz)
+    b, m, _ = new_xyz.shape
+    need(xyz.shape[0] == b and xyz.shape[2] == 3 and new_xyz.shape[2] == 3, "ball_query shape mismatch")
+    n = xyz.shape[1]
+    idx = torch.zeros((b, m, int(nsample)), dtype=torch.int32, device=dev)
+    call("geot_ball_query", dev, b, n, m, float(radius), int(nsample), ptr(new_xyz), ptr(xyz), ptr(idx))
+    return idx
+
+
+def group_points(points, idx):
+    f32(points, "points", 3); i32(idx, "idx", 3)
+    dev = same_device(points, idx)
+    b, c, n = points.shape
+    need(idx.shape[0] == b, "idx batch mismatch")
+    npoints, nsample = idx.shape[1], idx.shape[2]
+    out = torch.zeros((b, c, npoints, nsample), dtype=torch.float32, device=dev)
+    call("geot_group_points", dev, b, c, n, npoints, nsample, ptr(points), ptr(idx), ptr(out))
+    return out
+
+
+def group_points_grad(grad_out, idx, n):
+    f32(grad_out, "grad_out", 4); i32(idx, "idx", 3)
+    dev = same_device(grad_out, idx)
+    b, c, npoints, nsample = grad_out.shape
+    need(tuple(idx.shape) == (b, npoints, nsample), "idx shape mismatch")
+    out = torch.zeros((b, c, int(n)), dtype=torch.float32, device=dev)
+    call("geot_group_points_grad", dev, b, c, int(n), npoints, nsample, ptr(grad_out), ptr(idx), ptr(out))
+    return out

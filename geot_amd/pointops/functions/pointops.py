@@ -1,0 +1,129 @@
+"""Mirror of pointops/functions/pointops.py (knn :7-21, fps :24-32, fps_weight :34-44,
+index_points :47-58, FurthestSampling :61-78, FurthestSamplingWeight :81-98,
+KNNQuery :101-116) over ``pointops_cuda``.
+
+One deliberate host-side difference: the reference derives ``n_max`` and the output
+length with per-element device reads (``offset[i]``, ``.item()``: pointops.py:69-72),
+one host sync per batch entry; here a single ``.tolist()`` of the (b,) offsets does
+both.  Results are identical.
+"""
+import torch
+from torch.autograd import Function
+
+from ...ext import pointops_cuda
+
+
+def _uniform_offsets(b, n, device):
+    return torch.arange(1, b + 1, device=device, dtype=torch.int32) * n
+
+
+def knn(x, src, k, transpose=False):
+    """x (B,n,3) queries, src (B,m,3) support -> (idx (B,n,k) int64 local, dist (B,n,k))."""
+    if transpose:
+        x = x.transpose(1, 2).contiguous()
+        src = src.transpose(1, 2).contiguous()
+    b, n, _ = x.shape
+    m = src.shape[1]
+    x = x.reshape(-1, 3)
+    src = src.reshape(-1, 3)
+    x_offset = _uniform_offsets(b, n, x.device)
+    src_offset = _uniform_offsets(b, m, x.device)
+    idx, dists = knnquery(k, src, x, src_offset, x_offset)
+    idx = idx.view(b, n, k) - (src_offset - m)[:, None, None]
+    return idx.long(), dists.view(b, n, k)
+
+
+def fps(x, k):
+    """x (B,n,3) -> sampled points (B,k,3); first pick = point 0 of each cloud."""
+    b, n, _ = x.shape
+    x = x.reshape(-1, 3)
+    idx = furthestsampling(x, _uniform_offsets(b, n, x.device), _uniform_offsets(b, k, x.device)).long()
+    return x[idx].view(b, k, 3)
+
+
+def fps_weight(x, k, weight=None):
+    assert weight is not None, "the weight should be defined if using weighted fps"
+    b, n, _ = x.shape
+    x = x.reshape(-1, 3)
+    weight = weight.reshape(-1)
+    idx = furthestsampling_weight(x, _uniform_offsets(b, n, x.device), _uniform_offsets(b, k, x.device),
+                                  weight).long()
+    return x[idx].view(b, k, 3)
+
+
+def index_points(points, idx):
+    """points (B,N,C), idx (B,S,[K]) -> (B,S,[K],C)."""
+    raw = idx.size()
+    idx = idx.reshape(raw[0], -1)
+    res = torch.gather(points, 1, idx[..., None].expand(-1, -1, points.size(-1)))
+    return res.reshape(*raw, -1)
+
+
+def _segments(offset, new_offset):
+    off = offset.tolist()
+    n_max = max(e - s for s, e in zip([0] + off[:-1], off)) if off else 0
+    return n_max, int(new_offset[-1].item()) if new_offset.numel() else 0
+
+
+class FurthestSampling(Function):
+    @staticmethod
+    def forward(ctx, xyz, offset, new_offset):
+        """xyz (n,3), offset (b), new_offset (b) -> idx (m) int32 global indices."""
+        assert xyz.is_contiguous()
+        n, b = xyz.shape[0], offset.shape[0]
+        n_max, m_total = _segments(offset, new_offset)
+        idx = torch.zeros(m_total, dtype=torch.int32, device=xyz.device)
+        tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
+        pointops_cuda.furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None
+
+
+furthestsampling = FurthestSampling.apply
+
+
+class FurthestSamplingWeight(Function):
+    @staticmethod
+    def forward(ctx, xyz, offset, new_offset, weights):
+        assert xyz.is_contiguous()
+        n, b = xyz.shape[0], offset.shape[0]
+        n_max, m_total = _segments(offset, new_offset)
+        idx = torch.zeros(m_total, dtype=torch.int32, device=xyz.device)
+        tmp = torch.full((n,), 1e10, dtype=torch.float32, device=xyz.device)
+        pointops_cuda.furthestsampling_weights_cuda(b, n_max, xyz, offset, new_offset,
+                                                    weights.contiguous(), tmp, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+furthestsampling_weight = FurthestSamplingWeight.apply
+
+
+class KNNQuery(Function):
+    @staticmethod
+    def forward(ctx, nsample, xyz, new_xyz, offset, new_offset):
+        """xyz (n,3) support, new_xyz (m,3) queries -> (idx (m,nsample) i32 global, dist (m,nsample))."""
+        if new_xyz is None:
+            new_xyz = xyz
+        assert xyz.is_contiguous() and new_xyz.is_contiguous()
+        m = new_xyz.shape[0]
+        idx = torch.zeros((m, nsample), dtype=torch.int32, device=xyz.device)
+        dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=xyz.device)
+        pointops_cuda.knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2)
+        ctx.mark_non_differentiable(idx)
+        return idx, torch.sqrt(dist2)
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None
+
+
+knnquery = KNNQuery.apply

@@ -1,0 +1,136 @@
+/*
+ * geot_hip.h -- C ABI of libgeot_hip.so, the MI355X (gfx950) implementation of
+ * GeoT's point-cloud sampling / grouping / interpolation hot path.
+ *
+ * Every entry point is a plain launcher: device pointers, sizes and a HIP
+ * stream handle in, hipError_t (as int, 0 == hipSuccess) out.  No torch types,
+ * no allocation, no host synchronisation, never exit(): safe to call from any
+ * thread and to capture into a hipGraph.  `stream` is a hipStream_t passed as
+ * void* (NULL = the legacy default stream).
+ *
+ * Each declaration cites the reference launcher / binding it replaces
+ * (paths relative to the GeoT checkout).  Layouts: fp32 and int32 only, all
+ * tensors contiguous, exactly as the reference's extensions require
+ * (SURVEY.md section 8b).  Accumulating outputs (`*_grad`, FPS `temp`) must
+ * arrive pre-filled (0 / 1e10) as in the reference; all other outputs are
+ * written in full, so they may arrive uninitialised.
+ *
+ * Distances are un-contracted IEEE fp32, ((dx*dx)+(dy*dy))+(dz*dz), so integer
+ * results are bit-identical to the CPU oracle (oracle/geot_oracle.c).
+ */
+#ifndef GEOT_HIP_H
+#define GEOT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GEOT_ABI_VERSION 1
+
+/* ABI version / diagnostics. */
+int geot_abi_version(void);
+const char *geot_error_string(int hip_error);
+
+/* ---- furthest point sampling -------------------------------------------
+ * Dense batch.  Replaces
+ *   pointnet2/_ext_src/src/sampling_gpu.cu:178-232 furthest_point_sampling_kernel_wrapper
+ *     (bound as furthest_point_sampling, sampling.cpp:67-88): block_cap=512, skip_origin=1
+ *   openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:218-260 (bound as
+ *     furthest_point_sampling_wrapper, sampling.cpp:39-48):          block_cap=1024, skip_origin=0
+ * xyz (b,n,3); temp (b,n) in/out, pre-filled 1e10; idxs (b,m) out.
+ * block_cap selects the reference thread-block size whose reduction order
+ * defines the tie rule; it is not our launch geometry. */
+int geot_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp, int *idxs,
+                                 int block_cap, int skip_origin, void *stream);
+
+/* Offset-batched, optionally weighted.  Replaces
+ *   pointops/src/sampling/sampling_cuda_kernel.cu:131-171 furthestsampling_cuda_launcher
+ *   pointops/src/sampling/sampling_cuda_kernel.cu:309-349 furthestsampling_weights_cuda_launcher
+ *   (declared extern "C" in pointops/src/sampling/sampling_cuda_kernel.h:9-29).
+ * xyz (n_total,3); offset/new_offset (b) int32 inclusive prefix sums (device);
+ * weights (n_total) or NULL; tmp (n_total) in/out, pre-filled 1e10;
+ * idx (new_offset[b-1]) out, global indices.  n_max = largest segment. */
+int geot_furthestsampling_offset(int b, int n_max, const float *xyz, const int *offset,
+                                 const int *new_offset, const float *weights, float *tmp,
+                                 int *idx, void *stream);
+
+/* ---- gather ---------------------------------------------------------------
+ * pointnet2/_ext_src/src/sampling_gpu.cu:25-33, 52-60
+ * openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu (gather_points_kernel_launcher_fast, _grad_) */
+int geot_gather_points(int b, int c, int n, int m, const float *points, const int *idx, float *out,
+                       void *stream);
+int geot_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                            float *grad_points, void *stream);
+
+/* ---- ball query -------------------------------------------------------------
+ * pointnet2/_ext_src/src/ball_query_gpu.cu:49-57 query_ball_point_kernel_wrapper
+ * openpoints/cpp/pointnet2_batch/src/ball_query_gpu.cu (ball_query_kernel_launcher_fast)
+ * new_xyz (b,m,3), xyz (b,n,3) -> idx (b,m,nsample); written in full. */
+int geot_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                    const float *xyz, int *idx, void *stream);
+/* openpoints/cpp/pointops/src/ballquery/ballquery_cuda_kernel.cu:80-88 ballquery_launcher.
+ * b = number of batch segments in offset/new_offset (the reference scans for it). */
+int geot_ballquery_offset(int b, int m, float radius, int nsample, const float *xyz,
+                          const float *new_xyz, const int *offset, const int *new_offset, int *idx,
+                          void *stream);
+
+/* ---- group (channels-first) -------------------------------------------------
+ * pointnet2/_ext_src/src/group_points_gpu.cu:33-42, 69-78
+ * openpoints/cpp/pointnet2_batch/src/group_points_gpu.cu (…_launcher_fast) */
+int geot_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                      const int *idx, float *out, void *stream);
+int geot_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                           const int *idx, float *grad_points, void *stream);
+
+/* ---- three_nn / three_interpolate ------------------------------------------
+ * pointnet2/_ext_src/src/interpolate_gpu.cu:64-71, 106-115, 148-157
+ * openpoints/cpp/pointnet2_batch/src/interpolate_gpu.cu (…_launcher_fast)
+ * dist2 holds SQUARED distances (callers take sqrt). */
+int geot_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                  int *idx, void *stream);
+int geot_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                           const float *weight, float *out, void *stream);
+int geot_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                const float *weight, float *grad_points, void *stream);
+
+/* ---- kNN --------------------------------------------------------------------
+ * Heap-ordered, offset-batched: pointops/src/knnquery/knnquery_cuda_kernel.cu:111-116
+ * knnquery_cuda_launcher (extern "C" in knnquery_cuda_kernel.h:9-17).
+ * idx (m,nsample) global indices, dist2 (m,nsample) squared.  nsample <= 256. */
+int geot_knnquery_heap(int b, int m, int nsample, const float *xyz, const float *new_xyz,
+                       const int *offset, const int *new_offset, int *idx, float *dist2,
+                       void *stream);
+/* Sorted brute-force kNN: the contract of the un-vendored knn_cuda.KNN
+ * (openpoints/models/backbone/transformer.py:280,293,313,353) and of
+ * knn_point = cdist + topk (openpoints/models/layers/knn.py:7-20).
+ * query (b,nq,3), ref (b,nr,3) -> idx (b,nq,k) int32, dist2 (b,nq,k) squared,
+ * ascending by (dist2, index); missing neighbours are (inf, 0).  k <= 256. */
+int geot_knn_sorted(int b, int nq, int nr, int k, const float *query, const float *ref, int *idx,
+                    float *dist2, void *stream);
+
+/* ---- openpoints pointops, channels-last -----
+ * openpoints/cpp/pointops/src/{grouping,interpolation,subtraction,aggregation}/…_cuda_kernel.cu */
+int geot_grouping_cl(int m, int nsample, int c, const float *input, const int *idx, float *out,
+                     void *stream);
+int geot_grouping_cl_grad(int m, int nsample, int c, const float *grad_out, const int *idx,
+                          float *grad_in, void *stream);
+int geot_interpolation_cl(int n, int c, int k, const float *input, const int *idx,
+                          const float *weight, float *out, void *stream);
+int geot_interpolation_cl_grad(int n, int c, int k, const float *grad_out, const int *idx,
+                               const float *weight, float *grad_in, void *stream);
+int geot_subtraction_cl(int n, int nsample, int c, const float *in1, const float *in2,
+                        const int *idx, float *out, void *stream);
+int geot_subtraction_cl_grad(int n, int nsample, int c, const int *idx, const float *grad_out,
+                             float *grad_in1, float *grad_in2, void *stream);
+int geot_aggregation_cl(int n, int nsample, int c, int w_c, const float *input,
+                        const float *position, const float *weight, const int *idx, float *out,
+                        void *stream);
+int geot_aggregation_cl_grad(int n, int nsample, int c, int w_c, const float *input,
+                             const float *position, const float *weight, const int *idx,
+                             const float *grad_out, float *grad_in, float *grad_position,
+                             float *grad_weight, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOT_HIP_H */

@@ -1,0 +1,79 @@
+"""CPU suite, part 2: the drop-in boundary.  The C-ABI library must load and
+export every symbol include/geot_hip.h declares (no compute without a GPU), and the
+product must refuse to run without it rather than fall back."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "geot_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(geot_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    from geot_amd import build
+    return build.build()
+
+
+def test_library_exports_every_declared_symbol(built):
+    out = subprocess.run(["nm", "-D", "--defined-only", built], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (geot_[a-z0-9_]+)", out))
+    declared = _declared()
+    assert len(declared) >= 23
+    missing = [s for s in declared if s not in exported]
+    assert not missing, "declared in geot_hip.h but not exported: %s" % missing
+    extra = [s for s in exported if s not in declared]
+    assert not extra, "exported but undeclared: %s" % extra
+
+
+def test_ctypes_binding_covers_the_header(built):
+    from geot_amd import _lib
+    lib = _lib.load()
+    assert lib.geot_abi_version() == 1
+    assert sorted(_lib.exported_symbols()) == _declared()
+    assert b"invalid" in lib.geot_error_string(1).lower()
+
+
+def test_code_object_is_gfx950_only(built):
+    blob = open(built, "rb").read()
+    targets = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-f]+)", blob))
+    assert targets == {b"gfx950"}, targets
+
+
+def test_cpu_tensors_are_rejected_not_emulated(built):
+    import torch
+    from geot_amd.ext import pointnet2_ext, pointnet2_batch_cuda
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        pointnet2_ext.furthest_point_sampling(torch.zeros(1, 8, 3), 4)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        pointnet2_batch_cuda.three_nn_wrapper(1, 4, 4, torch.zeros(1, 4, 3), torch.zeros(1, 4, 3),
+                                              torch.zeros(1, 4, 3), torch.zeros(1, 4, 3, dtype=torch.int32))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from geot_amd import _lib\n"
+            "_lib.LIB_PATH = %r\n"
+            "try:\n    _lib.load()\nexcept _lib.GeotLibraryError as e:\n    print('LOUD', e)\n"
+            % (ROOT, str(tmp_path / "nope.so")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "LOUD" in out.stdout and "no CPU/PyTorch fallback" in out.stdout
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "geot_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h")):
+                t = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", t, flags=re.M) or "libgeot_oracle" in t:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,423 @@
+"""GPU suite: the HIP path (through the C ABI) against the CPU oracle.
+
+Bit-exact for every integer output (FPS order, ball-query / kNN / three_nn ids) and
+for the fp32 squared distances (same un-contracted arithmetic); 1e-5 relative for
+interpolation / grouping values and atomically-accumulated gradients.
+"""
+import numpy as np
+import pytest
+import torch
+
+from geot_amd.synth import make_batch, make_cloud
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+RTOL = 1e-5  # north-star tolerance for float interpolation / grouping
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ext():
+    from geot_amd import _lib
+    from geot_amd.ext import pointnet2_ext, pointnet2_batch_cuda, pointops_cuda
+    _lib.load()  # must be the HIP library; raises if missing
+
+    class E:
+        p2 = pointnet2_ext
+        p2b = pointnet2_batch_cuda
+        pops = pointops_cuda
+    return E
+
+
+def fps_k1(ext, xyz, m):
+    return host(ext.p2.furthest_point_sampling(dev(xyz), m))
+
+
+def fps_k1p(ext, xyz, m, return_temp=False):
+    b, n, _ = xyz.shape
+    out = torch.full((b, m), -7, dtype=torch.int32, device=DEV)  # garbage: must be overwritten
+    temp = torch.full((b, n), 1e10, dtype=torch.float32, device=DEV)
+    ext.p2b.furthest_point_sampling_wrapper(b, n, m, dev(xyz), temp, out)
+    return (host(out), host(temp)) if return_temp else host(out)
+
+
+def fps_k2(ext, flat, off, noff, w=None):
+    off_t, noff_t = dev(off, torch.int32), dev(noff, torch.int32)
+    sizes = np.diff(np.concatenate([[0], off]))
+    idx = torch.full((int(noff[-1]),), -7, dtype=torch.int32, device=DEV)
+    tmp = torch.full((flat.shape[0],), 1e10, dtype=torch.float32, device=DEV)
+    if w is None:
+        ext.pops.furthestsampling_cuda(len(off), int(sizes.max()), dev(flat), off_t, noff_t, tmp, idx)
+    else:
+        ext.pops.furthestsampling_weights_cuda(len(off), int(sizes.max()), dev(flat), off_t, noff_t, dev(w), tmp, idx)
+    return host(idx)
+
+
+# ---- FPS ------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["plain", "dup1pct"])
+def test_config1_golden_on_gpu(ext, golden, tag):
+    g = golden("config1_%s.npz" % tag)
+    xyz = g["xyz"]
+    k1 = fps_k1(ext, xyz, 1024)
+    assert np.array_equal(k1, g["fps_k1"])
+    assert np.array_equal(fps_k1p(ext, xyz, 1024), g["fps_k1p"])
+    assert np.array_equal(fps_k2(ext, xyz.reshape(-1, 3), np.array([4096]), np.array([1024])), g["fps_k2"])
+    centres = np.take_along_axis(xyz, k1[..., None].astype(np.int64).repeat(3, -1), 1)
+    bq = host(ext.p2.ball_query(dev(centres), dev(xyz), float(g["radius"]), int(g["nsample"])))
+    assert np.array_equal(bq, g["ball_query"])
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (3, 3), (5, 4), (63, 17), (64, 64), (65, 33), (100, 100),
+                                 (513, 200), (777, 300), (1025, 128), (1500, 256), (2049, 300), (4097, 200),
+                                 (8193, 150), (16385, 100)])
+def test_fps_small_and_ragged(ext, oracle, n, m):
+    xyz, _ = make_batch(2, n, start_index=n, dup_frac=0.05 if n > 20 else 0.0, origin_pts=2)
+    assert np.array_equal(fps_k1(ext, xyz, m), oracle.fps_dense(xyz, m, 512, True))
+    got, temp = fps_k1p(ext, xyz, m, return_temp=True)
+    want, wtemp = oracle.fps_dense(xyz, m, 1024, False, return_temp=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(temp, wtemp)  # the running min-distance buffer is part of the contract
+
+
+def test_fps_edge_cases(ext, oracle):
+    xyz, _ = make_batch(1, 40, origin_pts=0)
+    assert np.array_equal(fps_k1p(ext, xyz, 60), oracle.fps_dense(xyz, 60, 1024, False))  # m > n
+    tiny = (np.random.default_rng(0).standard_normal((1, 50, 3)) * 0.001).astype(np.float32)
+    assert (fps_k1(ext, tiny, 10) == 0).all()  # every point origin-skipped
+    tie = np.zeros((1, 16, 3), dtype=np.float32)
+    tie[0, 1:, 0] = 1.0
+    got = fps_k1p(ext, tie, 3)
+    assert got[0, 1] == 8 and np.array_equal(got, oracle.fps_dense(tie, 3, 1024, False))
+    # heavy ties at full register occupancy: 24k points drawn from 300 distinct positions
+    rng = np.random.default_rng(1)
+    base, _ = make_cloud(300, 99, origin_pts=0)
+    heavy = base[rng.integers(0, 300, 24000)][None]
+    assert np.array_equal(fps_k1p(ext, heavy, 400), oracle.fps_dense(heavy, 400, 1024, False))
+    assert np.array_equal(fps_k1(ext, heavy, 400), oracle.fps_dense(heavy, 400, 512, True))
+
+
+def test_fps_offset_ragged_weighted(ext, oracle):
+    sizes = [700, 1300, 64, 2048, 5000]
+    ms = [100, 333, 64, 512, 1000]
+    flat = np.concatenate([make_cloud(n, 50 + i, dup_frac=0.02)[0] for i, n in enumerate(sizes)])
+    off, noff = np.cumsum(sizes), np.cumsum(ms)
+    assert np.array_equal(fps_k2(ext, flat, off, noff), oracle.fps_offset(flat, off, noff))
+    w = np.random.default_rng(3).random(flat.shape[0]).astype(np.float32)
+    w[::17] = 0.0
+    assert np.array_equal(fps_k2(ext, flat, off, noff, w), oracle.fps_offset(flat, off, noff, w))
+
+
+def test_fps_full_size_vs_oracle_and_properties(ext, oracle):
+    """BASELINE shapes: 24k-point clouds, the 512 / 8192 targets of the backbone."""
+    xyz, _ = make_batch(2, 24000, dup_frac=0.01)
+    got512 = fps_k1(ext, xyz, 512)
+    assert np.array_equal(got512, oracle.fps_dense(xyz, 512, 512, True))
+    flat = xyz.reshape(-1, 3)
+    off = np.array([24000, 48000])
+    got = fps_k2(ext, flat, off, np.array([8192, 16384]))
+    assert np.array_equal(got, oracle.fps_offset(flat, off, np.array([8192, 16384])))
+    # size-independent properties: starts at the segment base, stays in segment, prefix property
+    for i in range(2):
+        seg = got[i * 8192:(i + 1) * 8192]
+        assert seg[0] == i * 24000 and (seg >= i * 24000).all() and (seg < (i + 1) * 24000).all()
+    half = fps_k2(ext, flat, off, np.array([4096, 8192]))
+    assert np.array_equal(half[:4096], got[:4096]) and np.array_equal(half[4096:], got[8192:8192 + 4096])
+    # greedy max-min property: each pick maximises the distance to the set picked so far
+    p = xyz[0].astype(np.float64)
+    sel = got[:64]
+    mind = np.full(24000, np.inf)
+    for j in range(63):
+        mind = np.minimum(mind, ((p - p[sel[j]]) ** 2).sum(1))
+        assert mind[sel[j + 1]] >= mind.max() * (1 - 1e-6)
+
+
+def test_fps_streaming_path_large_cloud(ext, oracle):
+    xyz, _ = make_batch(1, 30000, start_index=4)  # > 24576 points: not register-resident
+    assert np.array_equal(fps_k1p(ext, xyz, 300), oracle.fps_dense(xyz, 300, 1024, False))
+    assert np.array_equal(fps_k1(ext, xyz, 300), oracle.fps_dense(xyz, 300, 512, True))
+
+
+# ---- ball query -------------------------------------------------------------
+def test_ball_query_edges(ext, oracle):
+    xyz, _ = make_batch(2, 600, start_index=7, dup_frac=0.05)
+    q = xyz[:, ::7].copy()
+    q[:, 0] = 5.0
+    for r, ns in [(0.05, 8), (0.2, 16), (0.5, 64), (3.0, 700), (0.2, 1)]:
+        got = host(ext.p2.ball_query(dev(q), dev(xyz), r, ns))
+        assert np.array_equal(got, oracle.ball_query(q, xyz, r, ns))
+    b, m, n = 2, q.shape[1], 600
+    idx = torch.full((b, m, 16), -7, dtype=torch.int32, device=DEV)  # uninitialised output
+    ext.p2b.ball_query_wrapper(b, n, m, 0.2, 16, dev(q), dev(xyz), idx)
+    assert np.array_equal(host(idx), oracle.ball_query(q, xyz, 0.2, 16))
+    off, noff = np.array([600, 1200]), np.array([m, 2 * m])
+    idx = torch.full((2 * m, 16), -7, dtype=torch.int32, device=DEV)
+    ext.pops.ballquery_cuda(2 * m, 0.2, 16, dev(xyz.reshape(-1, 3)), dev(q.reshape(-1, 3)),
+                            dev(off, torch.int32), dev(noff, torch.int32), idx)
+    assert np.array_equal(host(idx), oracle.ballquery_offset(0.2, 16, xyz.reshape(-1, 3), q.reshape(-1, 3), off, noff))
+
+
+def test_ball_query_config2_size(ext, oracle):
+    """BASELINE configs[1]: 24k points, 6000 FPS centres, r=0.1, nsample=32."""
+    xyz, _ = make_batch(1, 24000)
+    centres_idx = fps_k1p(ext, xyz, 6000)
+    centres = np.take_along_axis(xyz, centres_idx[..., None].astype(np.int64).repeat(3, -1), 1)
+    got = host(ext.p2.ball_query(dev(centres), dev(xyz), 0.1, 32))
+    assert np.array_equal(got, oracle.ball_query(centres, xyz, 0.1, 32))
+    # properties: ascending unique prefix, then repeats of the first hit; all inside the radius
+    d2 = ((xyz[0][got[0]] - centres[0][:, None, :]) ** 2).sum(-1)
+    assert (d2 < 0.1 * 0.1 + 1e-6).all()
+    assert (got[0][:, 0] <= got[0].min(1)).all()
+
+
+# ---- three_nn / interpolate ---------------------------------------------------
+def test_three_nn(ext, oracle):
+    xyz, _ = make_batch(2, 900, start_index=3, dup_frac=0.05)
+    known = xyz[:, ::5].copy()
+    d2, idx = ext.p2.three_nn(dev(xyz), dev(known))
+    wd2, widx = oracle.three_nn(xyz, known)
+    assert np.array_equal(host(idx), widx) and np.array_equal(host(d2), wd2)
+    for m in (1, 2, 3):
+        d2, idx = ext.p2.three_nn(dev(xyz[:, :10]), dev(known[:, :m]))
+        wd2, widx = oracle.three_nn(xyz[:, :10], known[:, :m])
+        assert np.array_equal(host(idx), widx) and np.array_equal(host(d2), wd2)
+    b, n, m = 2, 900, known.shape[1]
+    d2 = torch.full((b, n, 3), -1.0, device=DEV)
+    idx = torch.full((b, n, 3), -7, dtype=torch.int32, device=DEV)
+    ext.p2b.three_nn_wrapper(b, n, m, dev(xyz), dev(known), d2, idx)
+    wd2, widx = oracle.three_nn(xyz, known)
+    assert np.array_equal(host(idx), widx) and np.array_equal(host(d2), wd2)
+
+
+def test_three_nn_propagation0_size(ext, oracle):
+    """propogation_0 of the backbone: 24000 unknown x 8192 known."""
+    xyz, _ = make_batch(1, 24000, start_index=2, dup_frac=0.01)
+    sel = fps_k2(ext, xyz.reshape(-1, 3), np.array([24000]), np.array([8192]))
+    known = xyz[:, sel]
+    d2, idx = ext.p2.three_nn(dev(xyz), dev(known))
+    wd2, widx = oracle.three_nn(xyz, known)
+    assert np.array_equal(host(idx), widx) and np.array_equal(host(d2), wd2)
+    assert (host(d2)[0, sel, 0] == 0).all()  # a known point's nearest neighbour is itself
+
+
+def test_three_interpolate_fwd_bwd(ext, oracle):
+    rng = np.random.default_rng(11)
+    b, c, m, n = 2, 37, 256, 1000
+    feats = rng.standard_normal((b, c, m)).astype(np.float32)
+    idx = rng.integers(0, m, (b, n, 3)).astype(np.int32)
+    w = rng.random((b, n, 3)).astype(np.float32)
+    w /= w.sum(-1, keepdims=True)
+    out = ext.p2.three_interpolate(dev(feats), dev(idx), dev(w))
+    np.testing.assert_allclose(host(out), oracle.three_interpolate(feats, idx, w), rtol=RTOL, atol=1e-6)
+    go = rng.standard_normal((b, c, n)).astype(np.float32)
+    g = ext.p2.three_interpolate_grad(dev(go), dev(idx), dev(w), m)
+    np.testing.assert_allclose(host(g), oracle.three_interpolate_grad(go, idx, w, m), rtol=1e-4, atol=1e-5)
+    out2 = torch.full((b, c, n), float("nan"), device=DEV)
+    ext.p2b.three_interpolate_wrapper(b, c, m, n, dev(feats), dev(idx), dev(w), out2)
+    assert torch.equal(out, out2)
+    g2 = torch.zeros((b, c, m), device=DEV)
+    ext.p2b.three_interpolate_grad_wrapper(b, c, n, m, dev(go), dev(idx), dev(w), g2)
+    np.testing.assert_allclose(host(g2), host(g), rtol=1e-4, atol=1e-5)
+
+
+def test_reference_gradcheck_vector_on_gpu(ext):
+    """pointnet2/pointnet2_test.py:15-27 through the autograd wrapper."""
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    torch.manual_seed(0)
+    feats = torch.randn(1, 2, 4, device=DEV, requires_grad=True)
+    idx = torch.tensor([[[0, 1, 2], [1, 2, 3]]], dtype=torch.int32, device=DEV)
+    w = torch.tensor([[[1., 1, 1], [2, 2, 2]]], device=DEV)
+    assert torch.autograd.gradcheck(lambda f: pu.three_interpolate(f, idx, w), (feats,), eps=1e-2,
+                                    atol=1e-1, rtol=1e-1, nondet_tol=1e-3)
+    pu.three_interpolate(feats, idx, w).sum().backward()
+    assert torch.equal(feats.grad[0, 0].cpu(), torch.tensor([1., 3, 3, 2]))
+
+
+# ---- gather / group -----------------------------------------------------------
+def test_gather_group_fwd_bwd(ext, oracle):
+    rng = np.random.default_rng(5)
+    b, c, n, m = 2, 19, 3000, 700
+    feats = rng.standard_normal((b, c, n)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m)).astype(np.int32)
+    out = ext.p2.gather_points(dev(feats), dev(idx))
+    assert np.array_equal(host(out), oracle.gather_points(feats, idx))
+    # reference smoke check (openpoints/models/layers/subsample.py:159-185): == torch.gather
+    tg = torch.gather(dev(feats), 2, dev(idx).long().unsqueeze(1).expand(-1, c, -1))
+    assert torch.equal(out, tg)
+    go = rng.standard_normal((b, c, m)).astype(np.float32)
+    np.testing.assert_allclose(host(ext.p2.gather_points_grad(dev(go), dev(idx), n)),
+                               oracle.gather_points_grad(go, idx, n), rtol=1e-4, atol=1e-5)
+    gidx = rng.integers(0, n, (b, 250, 16)).astype(np.int32)
+    gout = ext.p2.group_points(dev(feats), dev(gidx))
+    assert np.array_equal(host(gout), oracle.group_points(feats, gidx))
+    go = rng.standard_normal((b, c, 250, 16)).astype(np.float32)
+    np.testing.assert_allclose(host(ext.p2.group_points_grad(dev(go), dev(gidx), n)),
+                               oracle.group_points_grad(go, gidx, n), rtol=1e-4, atol=1e-4)
+    o2 = torch.full((b, c, 250, 16), float("nan"), device=DEV)
+    ext.p2b.group_points_wrapper(b, c, n, 250, 16, dev(feats), dev(gidx), o2)
+    assert torch.equal(o2, gout)
+    o3 = torch.full((b, c, m), float("nan"), device=DEV)
+    ext.p2b.gather_points_wrapper(b, c, n, m, dev(feats), dev(idx), o3)
+    assert torch.equal(o3, out)
+
+
+# ---- kNN ----------------------------------------------------------------------
+def test_knn_heap(ext, oracle):
+    xyz, _ = make_batch(3, 500, start_index=21, dup_frac=0.1)
+    flat = xyz.reshape(-1, 3)
+    off = np.array([500, 1000, 1500])
+    q = flat[::3].copy()
+    noff = np.array([167, 334, 500])
+    for k in (1, 3, 5, 16, 64):
+        idx = torch.full((q.shape[0], k), -7, dtype=torch.int32, device=DEV)
+        d2 = torch.full((q.shape[0], k), -1.0, device=DEV)
+        ext.pops.knnquery_cuda(q.shape[0], k, dev(flat), dev(q), dev(off, torch.int32), dev(noff, torch.int32), idx, d2)
+        wi, wd = oracle.knnquery_heap(k, flat, q, off, noff)
+        assert np.array_equal(host(idx), wi) and np.array_equal(host(d2), wd)
+    # fewer candidates than nsample
+    idx = torch.zeros((2, 6), dtype=torch.int32, device=DEV)
+    d2 = torch.zeros((2, 6), device=DEV)
+    ext.pops.knnquery_cuda(2, 6, dev(flat[:4]), dev(flat[:2]), dev(np.array([4]), torch.int32),
+                           dev(np.array([2]), torch.int32), idx, d2)
+    wi, wd = oracle.knnquery_heap(6, flat[:4], flat[:2], np.array([4]), np.array([2]))
+    assert np.array_equal(host(idx), wi) and np.array_equal(host(d2), wd)
+
+
+def test_pointops_python_api(ext, oracle):
+    from geot_amd.pointops.functions import pointops
+    xyz, _ = make_batch(2, 1200, start_index=8, dup_frac=0.02)
+    x = dev(xyz)
+    pts = pointops.fps(x, 300)
+    want = oracle.fps_offset(xyz.reshape(-1, 3), np.array([1200, 2400]), np.array([300, 600]))
+    assert np.array_equal(host(pts), xyz.reshape(-1, 3)[want].reshape(2, 300, 3))
+    idx, dist = pointops.knn(x[:, :100].contiguous(), x, 5)
+    wi, wd = oracle.knnquery_heap(5, xyz.reshape(-1, 3), xyz[:, :100].reshape(-1, 3), np.array([1200, 2400]),
+                                  np.array([100, 200]))
+    assert idx.dtype == torch.int64
+    assert np.array_equal(host(idx).reshape(-1, 5), wi - np.repeat([0, 1200], 100)[:, None])
+    np.testing.assert_allclose(host(dist).reshape(-1, 5), np.sqrt(wd), rtol=1e-6)
+
+
+def test_knn_sorted_and_knn_cuda_module(ext, oracle, golden):
+    from geot_amd.knn_cuda import KNN, knn_sorted
+    xyz, _ = make_batch(2, 900, start_index=3, dup_frac=0.05)
+    q = xyz[:, ::5].copy()
+    for k in (1, 4, 32, 33):
+        d2, idx = knn_sorted(dev(q), dev(xyz), k)
+        wi, wd = oracle.knn_sorted(q, xyz, k)
+        assert np.array_equal(host(idx), wi) and np.array_equal(host(d2), wd)
+    d2, idx = knn_sorted(dev(q), dev(xyz[:, :2]), 4)  # fewer refs than k -> (inf, 0)
+    wi, wd = oracle.knn_sorted(q, xyz[:, :2], 4)
+    assert np.array_equal(host(idx), wi) and np.array_equal(host(d2), wd)
+    dist, idx = KNN(4, transpose_mode=True)(dev(xyz), dev(q))
+    assert idx.dtype == torch.int64 and tuple(idx.shape) == (2, q.shape[1], 4)
+    wi, wd = oracle.knn_sorted(q, xyz, 4)
+    assert np.array_equal(host(idx), wi)
+    dist_t, idx_t = KNN(4, transpose_mode=False)(dev(xyz).transpose(1, 2).contiguous(), dev(q).transpose(1, 2).contiguous())
+    assert tuple(idx_t.shape) == (2, 4, q.shape[1]) and torch.equal(idx_t.transpose(1, 2), idx)
+    # the reference's own knn_point outputs (fixture from /root/reference, see make_golden.py)
+    g = golden("knn_point_ref.npz")
+    d2, idx = knn_sorted(dev(g["xyz"]), dev(g["xyz"]), int(g["k"]))
+    assert np.array_equal(host(idx), g["idx"])
+    assert np.abs(np.sqrt(host(d2)) - g["dist"]).max() < 2e-3
+
+
+# ---- channels-last pointops ------------------------------------------------------
+def test_channels_last_ops(ext, oracle):
+    rng = np.random.default_rng(9)
+    n, ns, c, w_c = 300, 8, 32, 8
+    x = rng.standard_normal((n, c)).astype(np.float32)
+    y = rng.standard_normal((n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (n, ns)).astype(np.int32)
+    w = rng.random((n, ns)).astype(np.float32)
+    pos = rng.standard_normal((n, ns, c)).astype(np.float32)
+    ww = rng.random((n, ns, w_c)).astype(np.float32)
+    go_nc = rng.standard_normal((n, c)).astype(np.float32)
+    go_nsc = rng.standard_normal((n, ns, c)).astype(np.float32)
+    P = ext.pops
+    out = torch.full((n, ns, c), float("nan"), device=DEV)
+    P.grouping_forward_cuda(n, ns, c, dev(x), dev(idx), out)
+    assert np.array_equal(host(out), oracle.grouping_cl(x, idx))
+    g = torch.zeros((n, c), device=DEV)
+    P.grouping_backward_cuda(n, ns, c, dev(go_nsc), dev(idx), g)
+    np.testing.assert_allclose(host(g), oracle.grouping_cl_grad(go_nsc, idx, n), rtol=1e-4, atol=1e-4)
+    out = torch.zeros((n, c), device=DEV)
+    P.interpolation_forward_cuda(n, c, ns, dev(x), dev(idx), dev(w), out)
+    np.testing.assert_allclose(host(out), oracle.interpolation_cl(x, idx, w), rtol=RTOL, atol=1e-6)
+    g = torch.zeros((n, c), device=DEV)
+    P.interpolation_backward_cuda(n, c, ns, dev(go_nc), dev(idx), dev(w), g)
+    np.testing.assert_allclose(host(g), oracle.interpolation_cl_grad(go_nc, idx, w, n), rtol=1e-4, atol=1e-4)
+    out = torch.full((n, ns, c), float("nan"), device=DEV)
+    P.subtraction_forward_cuda(n, ns, c, dev(x), dev(y), dev(idx), out)
+    assert np.array_equal(host(out), oracle.subtraction_cl(x, y, idx))
+    g1, g2 = torch.zeros((n, c), device=DEV), torch.zeros((n, c), device=DEV)
+    P.subtraction_backward_cuda(n, ns, c, dev(idx), dev(go_nsc), g1, g2)
+    w1, w2 = oracle.subtraction_cl_grad(idx, go_nsc)
+    np.testing.assert_allclose(host(g1), w1, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(g2), w2, rtol=1e-4, atol=1e-4)
+    out = torch.zeros((n, c), device=DEV)
+    P.aggregation_forward_cuda(n, ns, c, w_c, dev(x), dev(pos), dev(ww), dev(idx), out)
+    np.testing.assert_allclose(host(out), oracle.aggregation_cl(x, pos, ww, idx), rtol=RTOL, atol=1e-5)
+    gi, gp, gw = torch.zeros((n, c), device=DEV), torch.zeros((n, ns, c), device=DEV), torch.zeros((n, ns, w_c), device=DEV)
+    P.aggregation_backward_cuda(n, ns, c, w_c, dev(x), dev(pos), dev(ww), dev(idx), dev(go_nc), gi, gp, gw)
+    wi, wp, wwg = oracle.aggregation_cl_grad(x, pos, ww, idx, go_nc)
+    np.testing.assert_allclose(host(gi), wi, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(gp), wp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(gw), wwg, rtol=1e-4, atol=1e-4)
+
+
+# ---- wrappers: autograd + stream semantics ------------------------------------------
+def test_query_and_group_matches_composition(ext, oracle):
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    xyz, _ = make_batch(2, 2000, start_index=12)
+    x = dev(xyz)
+    feats = torch.randn(2, 5, 2000, device=DEV, requires_grad=True)
+    inds = pu.furthest_point_sample(x, 128)
+    assert inds.dtype == torch.int32 and not inds.requires_grad
+    new_xyz = pu.gather_operation(x.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    grouper = pu.QueryAndGroup(0.25, 16, use_xyz=True)
+    out = grouper(x, new_xyz, feats)
+    assert tuple(out.shape) == (2, 8, 128, 16)
+    bq = oracle.ball_query(host(new_xyz), xyz, 0.25, 16)
+    gx = oracle.group_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), bq) - host(new_xyz).transpose(0, 2, 1)[..., None]
+    gf = oracle.group_points(host(feats), bq)
+    np.testing.assert_allclose(host(out), np.concatenate([gx, gf], 1), rtol=RTOL, atol=1e-6)
+    out.sum().backward()
+    cnt = np.zeros((2, 2000), dtype=np.float32)
+    for b in range(2):
+        np.add.at(cnt[b], bq[b].reshape(-1), 1.0)
+    np.testing.assert_allclose(host(feats.grad), np.repeat(cnt[:, None, :], 5, 1), rtol=1e-5)
+
+
+def test_ops_run_on_the_current_stream(ext, oracle):
+    xyz, _ = make_batch(1, 3000, start_index=31)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        x = dev(xyz)
+        got = ext.p2.furthest_point_sampling(x, 200)
+        d2, idx = ext.p2.three_nn(x, x[:, :500].contiguous())
+    s.synchronize()
+    assert np.array_equal(host(got), oracle.fps_dense(xyz, 200, 512, True))
+    assert np.array_equal(host(idx), oracle.three_nn(xyz, xyz[:, :500])[1])
+
+
+def test_bad_arguments_raise(ext):
+    x = torch.zeros(1, 8, 3, device=DEV)
+    with pytest.raises(RuntimeError):
+        ext.p2.furthest_point_sampling(x.double(), 4)
+    with pytest.raises(RuntimeError):
+        ext.p2.furthest_point_sampling(x.transpose(1, 2), 4)
+    with pytest.raises(RuntimeError):
+        ext.p2.gather_points(torch.zeros(1, 2, 8, device=DEV), torch.zeros(1, 4, dtype=torch.int64, device=DEV))
+    with pytest.raises(RuntimeError):
+        ext.p2.ball_query(x, x, 0.1, 10 ** 6)  # nsample beyond the LDS budget -> hipErrorInvalidValue
