@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py -- throughput of the GeoT sampling/grouping hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--clouds B] [--workload sa|backbone_ops]
+
+Workload (default, BASELINE.json configs[1]): one 24 000-point synthetic tooth cloud per
+GPU through a PointNet++ SetAbstraction forward (PointnetSAModuleVotes npoint=6000,
+radius=0.1, nsample=32, mlp=[3,64,64,128], use_xyz) = furthest_point_sample ->
+gather_operation -> ball_query -> fused {group xyz, group features, centre subtraction,
+SharedMLP on fp32 MFMA, max over nsample}, eval mode, inputs resident in HBM.
+One "step" = one such forward over the rank's clouds.  N > 1: one process per GPU
+(torchrun), every rank works on its own clouds (weak scaling, no data-path collective);
+the timed region is bracketed by barrier + synchronize and the max over ranks is used.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+N_POINTS = 24000
+NPOINT, RADIUS, NSAMPLE, MLP = 6000, 0.1, 32, [3, 64, 64, 128]
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (= fp32 MFMA) rate
+HBM_PEAK_GBS = 8000.0
+FPS_FLOP_PER_UPDATE = 10          # 3 sub, 3 mul, 2 add, min, compare
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--clouds", type=int, default=1, help="clouds per GPU per step (configs[1] uses 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def build_module(device):
+    from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(1609)
+    sa = PointnetSAModuleVotes(mlp=list(MLP), npoint=NPOINT, radius=RADIUS, nsample=NSAMPLE, use_xyz=True)
+    return sa.to(device).eval()
+
+
+class FpsTimer:
+    """HIP events around the dominant kernel (FPS) on the stream it is launched on
+    (torch's current stream, which is where the C ABI launcher puts it)."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def wrap(self, fn):
+        def timed(xyz, npoint):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(xyz, npoint)
+            e1.record()
+            self.pairs.append((e0, e1))
+            return out
+        return timed
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
+
+
+def cpu_baseline(xyz_np, feats_np, sa_cpu, steps):
+    """The CPU port of the same step: oracle (C restatement, OpenMP over all host cores) for
+    FPS / ball query / grouping + the same SharedMLP on torch-CPU.  Checker code, used here
+    only as the reported baseline, never as the thing shipped."""
+    from oracle import capi
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one():
+        inds = capi.fps_dense(xyz_np, NPOINT, 512, True)
+        new_xyz = np.take_along_axis(xyz_np, inds[..., None].astype(np.int64).repeat(3, -1), 1)
+        idx = capi.ball_query(new_xyz, xyz_np, RADIUS, NSAMPLE)
+        gx = capi.group_points(np.ascontiguousarray(xyz_np.transpose(0, 2, 1)), idx)
+        gx -= new_xyz.transpose(0, 2, 1)[..., None]
+        gf = capi.group_points(feats_np, idx)
+        with torch.no_grad():
+            y = sa_cpu.mlp_module(torch.from_numpy(np.concatenate([gx, gf], 1)))
+            return torch.nn.functional.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1)
+
+    one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": xyz_np.shape[0] * steps / dt, "unit": "clouds/s", "cores": cores, "kind": "port",
+            "sample": "%d SetAbstraction forwards of %d cloud(s) x %d pts (oracle C/OpenMP FPS+ball_query+group, "
+                      "torch-CPU SharedMLP+max), %.1f s" % (steps, xyz_np.shape[0], N_POINTS, dt)}
+
+
+def main():
+    args = parse()
+    from geot_amd import dist_utils
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    world, rank, local = dist_utils.env_world()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist_utils.init("nccl")
+
+    from geot_amd import _lib
+    from geot_amd.synth import make_batch
+    from geot_amd.pointnet2 import pointnet2_utils
+    _lib.load()
+
+    B = args.clouds
+    xyz_np, _ = make_batch(B, N_POINTS, start_index=dist_utils.cloud_range(rank, B)[0])
+    feats_np = np.random.default_rng(1609 + rank).standard_normal((B, MLP[0], N_POINTS)).astype(np.float32)
+    xyz = torch.from_numpy(xyz_np).to(dev)
+    feats = torch.from_numpy(feats_np).to(dev)
+    sa = build_module(dev)
+
+    timer = FpsTimer()
+    orig_fps = pointnet2_utils.furthest_point_sample
+    import geot_amd.pointnet2.pointnet2_modules as mods
+
+    def step():
+        with torch.no_grad():
+            return sa(xyz, feats)
+
+    for _ in range(args.warmup):
+        step()
+    mods.pointnet2_utils.furthest_point_sample = timer.wrap(orig_fps)
+    torch.cuda.synchronize()
+    dist_utils.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dist_utils.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mods.pointnet2_utils.furthest_point_sample = orig_fps
+    elapsed = dist_utils.max_over_ranks(elapsed, dev)
+    assert torch.isfinite(out[1]).all()
+
+    fps_ms = timer.mean_ms()
+    fps_flop = B * N_POINTS * (NPOINT - 1) * FPS_FLOP_PER_UPDATE
+    achieved = fps_flop / (fps_ms * 1e-3) / 1e12
+    result = {
+        "metric": "point-clouds/sec (24k pts, 17 classes)",
+        "value": world * B * args.steps / elapsed,
+        "unit": "clouds/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: PointNet++ SetAbstraction fwd (FPS 24000->6000, ball_query r=0.1 "
+                               "ns=32, group, SharedMLP [6,64,64,128], max), eval",
+                   "clouds_per_gpu": B, "points": N_POINTS, "npoint": NPOINT, "nsample": NSAMPLE,
+                   "parallelism": "independent clouds per rank, no collective"},
+        "roofline": {"kernel": "fps_kernel", "bound": "valu",
+                     "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                     "avg_launch_ms": fps_ms,
+                     "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic "
+                             "flop = N*(m-1) updates * 10; one workgroup (one CU of 256) per cloud"},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sa_cpu = build_module("cpu")
+        sa_cpu.load_state_dict(sa.state_dict())
+        result["cpu_baseline"] = cpu_baseline(xyz_np, feats_np, sa_cpu, args.cpu_steps)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,12 @@ PROTOTYPES = {
     "geot_subtraction_cl_grad": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_aggregation_cl": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_aggregation_cl_grad": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_sa_group_mlp_max": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_float, _c_int,
+                              ctypes.POINTER(_c_int), _c_int, _P, _P, _c_void_p],
+}
+# entry points that do not follow the "(..., stream) -> hipError_t" shape
+PLAIN = {
+    "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),
 }
 
 _lib = None
@@ -78,6 +84,10 @@ def load():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = _c_int
         fn.argtypes = argtypes
+    for name, (argtypes, restype) in PLAIN.items():
+        fn = getattr(lib, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
     _lib = lib
     return lib
 
@@ -91,4 +101,4 @@ def check(err, what):
 
 def exported_symbols():
     """All C-ABI symbol names the Python side binds."""
-    return ["geot_abi_version", "geot_error_string"] + list(PROTOTYPES)
+    return ["geot_abi_version", "geot_error_string"] + list(PROTOTYPES) + list(PLAIN)

@@ -130,6 +130,26 @@ int geot_aggregation_cl_grad(int n, int nsample, int c, int w_c, const float *in
                              const float *grad_out, float *grad_in, float *grad_position,
                              float *grad_weight, void *stream);
 
+/* ---- fused SetAbstraction body ---------------
+ * Replaces the chain QueryAndGroup (pointnet2/pointnet2_utils.py:343-358: two
+ * grouping_operation + centre subtraction + cat) -> SharedMLP
+ * (pointnet2/pytorch_utils.py:8-33: 1x1 Conv2d + BatchNorm + ReLU stack) ->
+ * max_pool2d over nsample (pointnet2/pointnet2_modules.py:360-363), for inference
+ * (BatchNorm folded into the conv by the caller).  fp32 MFMA.
+ * xyz (b,n,3), new_xyz (b,npoint,3), features (b,c_feat,n) or NULL when c_feat==0,
+ * idx (b,npoint,nsample) from ball_query, out (b, widths[nlayers-1], npoint).
+ * widths = host array of the nlayers output widths (each <= 256, nlayers <= 4);
+ * relu_mask bit l = ReLU after layer l.  params = device block, per layer
+ * W^T zero-padded to [kp][cp] then bias [cp], with kp_0 = 3+c_feat rounded up to even,
+ * kp_l = cp_{l-1}, cp = width rounded up to 32/64/128/256;
+ * geot_sa_param_floats returns its length (or -1 for unsupported shapes).
+ * nsample must be 8, 16 or a multiple of 32. */
+int geot_sa_param_floats(int c_feat, int nlayers, const int *widths);
+int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int c_feat, const float *xyz,
+                          const float *new_xyz, const float *features, const int *idx,
+                          float xyz_scale, int nlayers, const int *widths, int relu_mask,
+                          const float *params, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

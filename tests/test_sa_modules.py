@@ -1,0 +1,100 @@
+"""SetAbstraction body: the SharedMLP mirror against the reference's own SharedMLP outputs
+(fixture tests/golden/shared_mlp_ref.npz, generated from /root/reference by make_golden.py),
+and the fused HIP kernel (grouping + MLP on fp32 MFMA + max) against both that fixture and
+the unfused composition of the individual ops."""
+import numpy as np
+import pytest
+import torch
+
+from geot_amd.synth import make_batch
+
+
+def _load_ref_mlp(golden, device="cpu"):
+    from geot_amd.pointnet2.pytorch_utils import SharedMLP
+    g = golden("shared_mlp_ref.npz")
+    mlp = SharedMLP([6, 16, 16, 32], bn=True)
+    sd = {str(k): torch.from_numpy(g[str(k).replace(".", "__")]) for k in g["keys"]}
+    assert list(mlp.state_dict().keys()) == [str(k) for k in g["keys"]]  # checkpoint-compatible names
+    mlp.load_state_dict(sd)
+    return mlp.eval().to(device), g
+
+
+def test_shared_mlp_mirror_matches_reference_fixture(golden):
+    mlp, g = _load_ref_mlp(golden)
+    with torch.no_grad():
+        y = mlp(torch.from_numpy(g["x"]))
+    np.testing.assert_allclose(y.numpy(), g["y"], rtol=1e-5, atol=1e-6)
+    pooled = torch.nn.functional.max_pool2d(y, kernel_size=[1, y.size(3)]).squeeze(-1)
+    np.testing.assert_allclose(pooled.numpy(), g["pooled"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_fused_sa_kernel_matches_reference_shared_mlp(golden):
+    from geot_amd.sa_fused import fused_group_mlp_max, fused_sa_available
+    mlp, g = _load_ref_mlp(golden, "cuda:0")
+    assert fused_sa_available(mlp)
+    x = torch.from_numpy(g["x"]).cuda()  # (2, 6, 24, 8): already-grouped tensor
+    b, c, npoint, ns = x.shape
+    flat = x.reshape(b, c, npoint * ns)
+    xyz = flat[:, :3].transpose(1, 2).contiguous()
+    feats = flat[:, 3:].contiguous()
+    new_xyz = torch.zeros(b, npoint, 3, device="cuda:0")
+    idx = torch.arange(npoint * ns, dtype=torch.int32, device="cuda:0").reshape(1, npoint, ns).repeat(b, 1, 1)
+    out = fused_group_mlp_max(xyz, new_xyz, feats, idx.contiguous(), mlp)
+    np.testing.assert_allclose(out.cpu().numpy(), g["pooled"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsample,mlp_spec,c_feat,normalize", [(32, [3, 64, 64, 128], 3, False),
+                                                              (16, [5, 32, 48], 5, True),
+                                                              (8, [0, 16], 0, False),
+                                                              (64, [3, 64, 64, 128], 3, False),
+                                                              (32, [13, 100, 40, 70, 200], 13, False)])
+def test_sa_module_fused_equals_unfused(nsample, mlp_spec, c_feat, normalize):
+    from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(3)
+    xyz_np, _ = make_batch(2, 3000, start_index=5)
+    xyz = torch.from_numpy(xyz_np).cuda()
+    feats = torch.randn(2, c_feat, 3000, device="cuda:0") if c_feat else None
+    sa = PointnetSAModuleVotes(mlp=list(mlp_spec), npoint=500, radius=0.15, nsample=nsample,
+                               normalize_xyz=normalize).cuda()
+    with torch.no_grad():
+        for m in sa.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.3, 0.3)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    sa.eval()
+    if feats is None:
+        # the reference asserts features for the votes module's MLP when c_feat==0 is xyz-only
+        with torch.no_grad():
+            sa.fused_eval = False
+            nx0, nf0, i0 = sa(xyz, None)
+        assert nf0.shape == (2, mlp_spec[-1], 500)
+        return
+    with torch.no_grad():
+        nx1, nf1, i1 = sa(xyz, feats)          # fused HIP path
+        sa.fused_eval = False
+        nx0, nf0, i0 = sa(xyz, feats)          # reference composition (HIP ops + torch MLP)
+    assert torch.equal(i0, i1) and torch.equal(nx0, nx1)
+    np.testing.assert_allclose(nf1.cpu().numpy(), nf0.cpu().numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_sa_and_fp_modules_train_mode_backward():
+    from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes, PointnetFPModule, PointnetSAModuleMSG
+    torch.manual_seed(1)  # mirrors the reference smoke test pointnet2_modules.py:725-744
+    xyz_np, _ = make_batch(2, 1024, start_index=9)
+    xyz = torch.from_numpy(xyz_np).cuda()
+    feats = torch.randn(2, 6, 1024, device="cuda:0", requires_grad=True)
+    sa = PointnetSAModuleVotes(mlp=[6, 32, 64], npoint=128, radius=0.2, nsample=16).cuda().train()
+    fp = PointnetFPModule(mlp=[64 + 6, 32]).cuda().train()
+    new_xyz, nf, inds = sa(xyz, feats)
+    up = fp(xyz, new_xyz, feats, nf)
+    assert up.shape == (2, 32, 1024)
+    up.sum().backward()
+    assert torch.isfinite(feats.grad).all() and feats.grad.abs().sum() > 0
+    msg = PointnetSAModuleMSG(npoint=64, radii=[0.1, 0.3], nsamples=[8, 16], mlps=[[6, 16], [6, 24]]).cuda()
+    nx, nf2 = msg(xyz, feats)
+    assert nf2.shape == (2, 40, 64)
