@@ -1,0 +1,44 @@
+"""Register the HIP-backed modules under the names the reference imports.
+
+After ``geot_amd.aliases.install()`` these reference import lines resolve to this package
+(SURVEY.md section 8b "Import-time names"):
+
+    import pointnet2._ext                                  (pointnet2/pointnet2_utils.py:23)
+    import pointops_cuda                                   (pointops/functions/pointops.py:4)
+    import pointnet2_batch_cuda                            (openpoints/cpp/pointnet2_batch/__init__.py:1)
+    from knn_cuda import KNN                               (openpoints/models/backbone/transformer.py:11)
+    from pointnet2_ops import pointnet2_utils              (examples/segmentation/train.py:39)
+
+so the reference's own wrapper files (pointnet2_utils.py, pointops.py, subsample.py, ...) run on
+MI355X unchanged.  Nothing is registered implicitly: call install() before importing the
+reference packages.
+"""
+import sys
+import types
+
+
+def install(force=False):
+    from .ext import pointnet2_ext, pointops_cuda, pointnet2_batch_cuda
+    from . import knn_cuda
+    from .pointnet2 import pointnet2_utils
+
+    def put(name, mod):
+        if force or name not in sys.modules:
+            sys.modules[name] = mod
+
+    put("pointops_cuda", pointops_cuda)
+    put("pointnet2_batch_cuda", pointnet2_batch_cuda)
+    put("knn_cuda", knn_cuda)
+    # `import pointnet2._ext` needs a parent package; reuse a real one if the reference's is importable
+    parent = sys.modules.get("pointnet2")
+    if parent is None:
+        parent = types.ModuleType("pointnet2")
+        parent.__path__ = []
+        sys.modules["pointnet2"] = parent
+    put("pointnet2._ext", pointnet2_ext)
+    parent._ext = sys.modules["pointnet2._ext"]
+    ops = types.ModuleType("pointnet2_ops")
+    ops.pointnet2_utils = pointnet2_utils
+    put("pointnet2_ops", ops)
+    put("pointnet2_ops.pointnet2_utils", pointnet2_utils)
+    return ["pointnet2._ext", "pointops_cuda", "pointnet2_batch_cuda", "knn_cuda", "pointnet2_ops"]
