@@ -85,6 +85,34 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
     return min(min(a, b), min(c, d));
 }
 
+__device__ __forceinline__ int row16_max_i32(int v)
+{
+    v = max(v, (int)dpp_mov<DPP_QUAD_XOR1>((uint32_t)v));
+    v = max(v, (int)dpp_mov<DPP_QUAD_XOR2>((uint32_t)v));
+    v = max(v, (int)dpp_mov<DPP_ROW_HALF_MIRROR>((uint32_t)v));
+    v = max(v, (int)dpp_mov<DPP_ROW_MIRROR>((uint32_t)v));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    v = row16_max_i32(v);
+    int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+// float min / max over the wave (used in one-time prologues; the fminf/fmaxf
+// canonicalisation cost does not matter there).
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+    v = row16_min_f32(v);
+    float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 0));
+    float b = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 16));
+    float c = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 32));
+    float d = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 48));
+    return fminf(fminf(a, b), fminf(c, d));
+}
+__device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 } // namespace geot

@@ -40,6 +40,13 @@ def ext():
     return E
 
 
+@pytest.fixture(params=["pruned", "basic"])
+def fps_impl(request, monkeypatch):
+    """Both FPS kernels (bucket-pruned default, unpruned GEOT_FPS_IMPL=basic) must be bit-exact."""
+    monkeypatch.setenv("GEOT_FPS_IMPL", request.param)
+    return request.param
+
+
 def fps_k1(ext, xyz, m):
     return host(ext.p2.furthest_point_sampling(dev(xyz), m))
 
@@ -66,7 +73,7 @@ def fps_k2(ext, flat, off, noff, w=None):
 
 # ---- FPS ------------------------------------------------------------------
 @pytest.mark.parametrize("tag", ["plain", "dup1pct"])
-def test_config1_golden_on_gpu(ext, golden, tag):
+def test_config1_golden_on_gpu(ext, golden, tag, fps_impl):
     g = golden("config1_%s.npz" % tag)
     xyz = g["xyz"]
     k1 = fps_k1(ext, xyz, 1024)
@@ -81,7 +88,7 @@ def test_config1_golden_on_gpu(ext, golden, tag):
 @pytest.mark.parametrize("n,m", [(1, 1), (2, 2), (3, 3), (5, 4), (63, 17), (64, 64), (65, 33), (100, 100),
                                  (513, 200), (777, 300), (1025, 128), (1500, 256), (2049, 300), (4097, 200),
                                  (8193, 150), (16385, 100)])
-def test_fps_small_and_ragged(ext, oracle, n, m):
+def test_fps_small_and_ragged(ext, oracle, n, m, fps_impl):
     xyz, _ = make_batch(2, n, start_index=n, dup_frac=0.05 if n > 20 else 0.0, origin_pts=2)
     assert np.array_equal(fps_k1(ext, xyz, m), oracle.fps_dense(xyz, m, 512, True))
     got, temp = fps_k1p(ext, xyz, m, return_temp=True)
@@ -90,7 +97,7 @@ def test_fps_small_and_ragged(ext, oracle, n, m):
     assert np.array_equal(temp, wtemp)  # the running min-distance buffer is part of the contract
 
 
-def test_fps_edge_cases(ext, oracle):
+def test_fps_edge_cases(ext, oracle, fps_impl):
     xyz, _ = make_batch(1, 40, origin_pts=0)
     assert np.array_equal(fps_k1p(ext, xyz, 60), oracle.fps_dense(xyz, 60, 1024, False))  # m > n
     tiny = (np.random.default_rng(0).standard_normal((1, 50, 3)) * 0.001).astype(np.float32)
@@ -107,7 +114,7 @@ def test_fps_edge_cases(ext, oracle):
     assert np.array_equal(fps_k1(ext, heavy, 400), oracle.fps_dense(heavy, 400, 512, True))
 
 
-def test_fps_offset_ragged_weighted(ext, oracle):
+def test_fps_offset_ragged_weighted(ext, oracle, fps_impl):
     sizes = [700, 1300, 64, 2048, 5000]
     ms = [100, 333, 64, 512, 1000]
     flat = np.concatenate([make_cloud(n, 50 + i, dup_frac=0.02)[0] for i, n in enumerate(sizes)])
@@ -118,7 +125,7 @@ def test_fps_offset_ragged_weighted(ext, oracle):
     assert np.array_equal(fps_k2(ext, flat, off, noff, w), oracle.fps_offset(flat, off, noff, w))
 
 
-def test_fps_full_size_vs_oracle_and_properties(ext, oracle):
+def test_fps_full_size_vs_oracle_and_properties(ext, oracle, fps_impl):
     """BASELINE shapes: 24k-point clouds, the 512 / 8192 targets of the backbone."""
     xyz, _ = make_batch(2, 24000, dup_frac=0.01)
     got512 = fps_k1(ext, xyz, 512)
@@ -142,7 +149,7 @@ def test_fps_full_size_vs_oracle_and_properties(ext, oracle):
         assert mind[sel[j + 1]] >= mind.max() * (1 - 1e-6)
 
 
-def test_fps_streaming_path_large_cloud(ext, oracle):
+def test_fps_streaming_path_large_cloud(ext, oracle, fps_impl):
     xyz, _ = make_batch(1, 30000, start_index=4)  # > 24576 points: not register-resident
     assert np.array_equal(fps_k1p(ext, xyz, 300), oracle.fps_dense(xyz, 300, 1024, False))
     assert np.array_equal(fps_k1(ext, xyz, 300), oracle.fps_dense(xyz, 300, 512, True))
