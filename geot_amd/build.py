@@ -22,7 +22,7 @@ HEADERS = ["geot_common.h", os.path.join(ROOT, "include", "geot_hip.h")]
 # -ffp-contract=off: squared distances must be un-contracted IEEE fp32 so that
 # integer outputs match the CPU oracle bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-fvisibility=hidden", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-fvisibility=hidden", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 

@@ -175,63 +175,97 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
 //    min(d, temp) leaves it unchanged -- the bucket is skipped.  Only the surviving slots
 //    (a ballot mask, typically 0-2 per wave) are updated and their smax re-reduced.
 //  * Arg-max: wave max over the per-slot maxima, then the reference tie key among the
-//    lanes of the winning slot(s); the owning lane publishes (max, key, x, y, z) so the next
-//    round needs no memory access at all -- one LDS hop and ONE barrier per round.
+//    lanes of the winning slot(s).  The wave's candidate (max, key, x, y, z) is wave-uniform
+//    (SGPRs), is recomputed only in rounds where the wave updated something, and is
+//    published to LDS so the next round needs no memory access at all -- one LDS hop and
+//    ONE barrier per round.
+//  * The per-lane point arrays are ext_vector registers indexed with a wave-uniform runtime
+//    slot (VGPR-index mode, s_set_gpr_idx_on), so the round loop is a few hundred
+//    instructions.  (A first version dispatched to per-slot straight-line code; at 47 slots
+//    that was 60 KB of loop body and every round missed the instruction cache.)
 //  The temps, the selected indices and the tie-breaking are bit-identical to the unpruned
 //  kernel (and to the reference): skipping is only ever a proven no-op.
 // ===========================================================================
-constexpr int FP_THREADS = 512;
-constexpr int FP_WAVES = FP_THREADS / 64;
+// ---- developer lab hooks (tools/fps_lab.py builds variants with -DGEOT_LAB_*) ----------
+#if defined(GEOT_LAB_STATS) || defined(GEOT_LAB_STAMPS)
+__device__ unsigned long long geot_fps_dbg[8];
+#endif
 constexpr int FP_CELLS = 4096;
-constexpr int FP_MAX_PPT = 47;
+constexpr int FP_MAX_N = 768 * 32;
 
-struct FpsExch {
-    int M;
-    uint32_t key;
-    float x, y, z;
-    float pad[3];
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+// 16 or 32 floats per lane held in VGPRs; get/set take a WAVE-UNIFORM runtime index and are
+// lowered to VGPR-index mode (s_set_gpr_idx_on + v_mov), branch-free.
+template <int CAP> struct RegVec;
+template <> struct RegVec<16> {
+    f32x16 a;
+    __device__ __forceinline__ float get(int i) const { return a[i]; }
+    __device__ __forceinline__ void set(int i, float v) { a[i] = v; }
+};
+template <> struct RegVec<32> {
+    f32x32 a;
+    __device__ __forceinline__ float get(int i) const { return a[i]; }
+    __device__ __forceinline__ void set(int i, float v) { a[i] = v; }
 };
 
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F &&f)
-{
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
+struct FpsEntry { // one wave's published candidate
+    uint32_t key;
+    float x, y, z;
+};
 
-// Run f(slot) for every set bit of the wave-uniform `mask` with the slot as a COMPILE-TIME
-// constant (register arrays cannot be indexed dynamically).  Two-level test: one scalar
-// branch per group of 8 slots, then one per slot inside a non-empty group, so the common
-// case (0-2 active slots out of PPT) costs ~PPT/8 + 8 scalar tests.  Straight-line,
-// structured code: a 47-way switch made the register allocator spill.
-template <int PPT, typename F>
-__device__ __forceinline__ void fp_for_each_slot(unsigned long long mask, F &&f)
+// v[lane `lane`] = value, both wave-uniform.  v_writelane_b32 allows only one SGPR besides
+// M0 on gfx9, so the lane select goes through M0.
+__device__ __forceinline__ void set_lane(int &v, int value, int lane)
 {
-    static_for<0, (PPT + 7) / 8>([&](auto G) {
-        constexpr int g = decltype(G)::value;
-        if ((mask >> (8 * g)) & 0xFFull) {
-            static_for<8 * g, (8 * g + 8 < PPT ? 8 * g + 8 : PPT)>([&](auto S) {
-                constexpr int sl = decltype(S)::value;
-                if ((mask >> sl) & 1ull) f(S);
-            });
-        }
-    });
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(lane) : "m0");
 }
-
-// v[lane LANE] = value (wave-uniform); v_writelane_b32 via asm (no builtin in this toolchain).
-template <int LANE>
-__device__ __forceinline__ void set_lane(int &v, int value)
+__device__ __forceinline__ void set_lane(float &v, float value, int lane)
 {
-    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(value), "n"(LANE));
-}
-template <int LANE>
-__device__ __forceinline__ void set_lane(float &v, float value)
-{
-    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(value), "n"(LANE));
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(value), "s"(lane) : "m0");
 }
 __device__ __forceinline__ float uniform(float v) { return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v))); }
+__device__ __forceinline__ float read_lane(float v, int lane)
+{
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
+
+// Fused DPP reductions (the op reads its first source through the DPP network): half the
+// instructions of a v_mov_dpp + op pair.  2 wait states between a VALU write and a DPP read.
+#define GEOT_DPP_STEP(op, ctrl) op " %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+__device__ __forceinline__ int wave_max_i32_fast(int v)
+{
+    asm volatile("s_nop 1\n\t"
+                 GEOT_DPP_STEP("v_max_i32_dpp", "quad_perm:[1,0,3,2]")
+                 GEOT_DPP_STEP("v_max_i32_dpp", "quad_perm:[2,3,0,1]")
+                 GEOT_DPP_STEP("v_max_i32_dpp", "row_half_mirror")
+                 GEOT_DPP_STEP("v_max_i32_dpp", "row_mirror")
+                 : "+v"(v));
+    int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ uint32_t wave_min_u32_fast(uint32_t v)
+{
+    asm volatile("s_nop 1\n\t"
+                 GEOT_DPP_STEP("v_min_u32_dpp", "quad_perm:[1,0,3,2]")
+                 GEOT_DPP_STEP("v_min_u32_dpp", "quad_perm:[2,3,0,1]")
+                 GEOT_DPP_STEP("v_min_u32_dpp", "row_half_mirror")
+                 GEOT_DPP_STEP("v_min_u32_dpp", "row_mirror")
+                 : "+v"(v));
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
+}
+
+// LDS 64-bit max without return value (the atomic optimizer would wrap atomicMax in
+// wave-election code although we are already down to one lane).
+__device__ __forceinline__ void lds_max_u64(unsigned long long *addr, unsigned long long v)
+{
+    uint32_t a = (uint32_t)(uintptr_t)addr; // LDS pointers: low 32 bits are the LDS offset
+    asm volatile("ds_max_u64 %0, %1" : : "v"(a), "v"(v) : "memory");
+}
 
 __device__ __forceinline__ uint32_t morton12(uint32_t cx, uint32_t cy, uint32_t cz)
 {
@@ -242,18 +276,23 @@ __device__ __forceinline__ uint32_t morton12(uint32_t cx, uint32_t cy, uint32_t 
     return m;
 }
 
-template <int PPT, bool SKIP>
-__global__ __launch_bounds__(FP_THREADS) void fps_pruned_kernel(
+// NT threads (NW = NT/64 waves), PPT points per lane (<= CAP register slots; one slot per lane
+// for the box test, so PPT <= 32 < 64).
+template <int NT, int PPT, bool SKIP>
+__global__ __launch_bounds__(NT) void fps_pruned_kernel(
     const float *__restrict__ xyz, const int *__restrict__ offset,
     const int *__restrict__ new_offset, int n_dense, int m_dense, float *__restrict__ temp,
     int *__restrict__ idxs, int L)
 {
-    static_assert(PPT <= FP_MAX_PPT, "one slot per lane for the box test");
-    __shared__ uint16_t perm[PPT * FP_THREADS];
+    constexpr int NW = NT / 64;
+    constexpr int CAP = PPT <= 16 ? 16 : 32;
+    static_assert(PPT <= CAP && NW <= 16, "geometry");
+    __shared__ uint16_t perm[PPT * NT];
     __shared__ uint32_t cellcnt[FP_CELLS];
-    __shared__ FpsExch exch[2][FP_WAVES];
-    __shared__ float red[FP_WAVES][6];
-    __shared__ uint32_t wsum[FP_WAVES];
+    __shared__ FpsEntry exch[2][16];
+    __shared__ unsigned long long best[3];
+    __shared__ float red[NW][6];
+    __shared__ uint32_t wsum[8];
 
     const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int start_n, n, start_m, m, base;
@@ -275,7 +314,7 @@ __global__ __launch_bounds__(FP_THREADS) void fps_pruned_kernel(
 
     // ---- 1. bounding box of the cloud --------------------------------------------------
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int k = tid; k < n; k += FP_THREADS) {
+    for (int k = tid; k < n; k += NT) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             float v = P[k * 3 + a];
@@ -288,24 +327,25 @@ __global__ __launch_bounds__(FP_THREADS) void fps_pruned_kernel(
         float l = wave_min_f32(lo[a]), h = wave_max_f32(hi[a]);
         if (lane == 0) { red[wave][a] = l; red[wave][3 + a] = h; }
     }
-    for (int c = tid; c < FP_CELLS; c += FP_THREADS) cellcnt[c] = 0;
+    for (int c = tid; c < FP_CELLS; c += NT) cellcnt[c] = 0;
+    if (tid < 3) best[tid] = 0ull;
     __syncthreads();
     float inv[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float l = red[0][a], h = red[0][3 + a];
-        for (int w = 1; w < FP_WAVES; ++w) { l = fminf(l, red[w][a]); h = fmaxf(h, red[w][3 + a]); }
+        for (int w = 1; w < NW; ++w) { l = fminf(l, red[w][a]); h = fmaxf(h, red[w][3 + a]); }
         lo[a] = l;
         float ext = h - l;
         inv[a] = (ext > 0.f && ext < INFINITY) ? 16.f / ext : 0.f;
     }
 
     // ---- 2. Morton cell histogram; remember (cell, rank-in-cell) per point -----------------
-    uint32_t cr[PPT];
-#pragma unroll
+    RegVec<CAP> X, Y, Z, D; // D doubles as the (cell,rank) scratch of the sort, then holds temp
+#pragma unroll 1
     for (int i = 0; i < PPT; ++i) {
-        int k = i * FP_THREADS + tid;
-        cr[i] = 0;
+        int k = i * NT + tid;
+        uint32_t cr = 0;
         if (k < n) {
             uint32_t c[3];
 #pragma unroll
@@ -316,158 +356,182 @@ __global__ __launch_bounds__(FP_THREADS) void fps_pruned_kernel(
             }
             uint32_t cell = morton12(c[0], c[1], c[2]);
             uint32_t r = atomicAdd(&cellcnt[cell], 1u);
-            cr[i] = (cell << 16) | r;
+            cr = (cell << 16) | r;
         }
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); // bound look-ahead: VGPR pressure
+        D.set(i, __uint_as_float(cr));
     }
     __syncthreads();
-    // ---- 3. exclusive prefix over the 4096 cells (8 per thread) ------------------------------
+    // ---- 3. exclusive prefix over the 4096 cells (8 per thread, first 512 threads) -------------
     {
-        uint32_t v[8], s = 0;
+        uint32_t v[8], s = 0, inc = 0;
+        if (tid < 512) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = cellcnt[tid * 8 + e]; s += v[e]; }
-        uint32_t inc = s;
+            for (int e = 0; e < 8; ++e) { v[e] = cellcnt[tid * 8 + e]; s += v[e]; }
+            inc = s;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t o = __shfl_up(inc, d);
+                if (lane >= d) inc += o;
+            }
+            if (lane == 63) wsum[wave] = inc;
         }
-        if (lane == 63) wsum[wave] = inc;
         __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        uint32_t run = woff + inc - s;
+        if (tid < 512) {
+            uint32_t woff = 0;
+            for (int w = 0; w < wave; ++w) woff += wsum[w];
+            uint32_t run = woff + inc - s;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { cellcnt[tid * 8 + e] = run; run += v[e]; }
+            for (int e = 0; e < 8; ++e) { cellcnt[tid * 8 + e] = run; run += v[e]; }
+        }
     }
     __syncthreads();
     // ---- 4. scatter: sorted position -> original (local) index ---------------------------------
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < PPT; ++i) {
-        int k = i * FP_THREADS + tid;
-        if (k < n) perm[cellcnt[cr[i] >> 16] + (cr[i] & 0xFFFFu)] = (uint16_t)k;
+        int k = i * NT + tid;
+        uint32_t cr = __float_as_uint(D.get(i));
+        if (k < n) perm[cellcnt[cr >> 16] + (cr & 0xFFFFu)] = (uint16_t)k;
     }
     __syncthreads();
 
-    // ---- 5. gather the sorted points into registers ----------------------------------------------
-    float px[PPT], py[PPT], pz[PPT], t[PPT];
-#pragma unroll
+    // ---- 5. gather the sorted points; 6. per-slot boxes and maxima (lane i owns slot i) ---------
+    // smax holds the fp32 BITS of the slot's max min-distance; slots without a valid point (and
+    // lanes >= PPT) hold the bits of -1.0f: negative as an int, and never 'active' as a float.
+    float bx0 = 0.f, by0 = 0.f, bz0 = 0.f, bx1 = 0.f, by1 = 0.f, bz1 = 0.f;
+    int smax = __float_as_int(-1.f);
+#pragma unroll 1
     for (int i = 0; i < PPT; ++i) {
-        int pos = i * FP_THREADS + tid;
+        int pos = i * NT + tid;
         bool in = pos < n;
         int k = in ? (int)perm[pos] : 0;
-        px[i] = in ? P[k * 3 + 0] : 0.f;
-        py[i] = in ? P[k * 3 + 1] : 0.f;
-        pz[i] = in ? P[k * 3 + 2] : 0.f;
-        t[i] = in ? T[k] : -1.f;
-        if (SKIP && in && origin_skipped(px[i], py[i], pz[i])) t[i] = -1.f;
-        if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); // bound the scheduler's look-ahead (VGPR pressure)
+        float x = in ? P[k * 3 + 0] : 0.f, y = in ? P[k * 3 + 1] : 0.f, z = in ? P[k * 3 + 2] : 0.f;
+        float t = in ? T[k] : -1.f;
+        if (SKIP && in && origin_skipped(x, y, z)) t = -1.f;
+        X.set(i, x); Y.set(i, y); Z.set(i, z); D.set(i, t);
+        bool valid = t >= 0.f;
+        set_lane(bx0, uniform(wave_min_f32(valid ? x : INFINITY)), i);
+        set_lane(bx1, uniform(wave_max_f32(valid ? x : -INFINITY)), i);
+        set_lane(by0, uniform(wave_min_f32(valid ? y : INFINITY)), i);
+        set_lane(by1, uniform(wave_max_f32(valid ? y : -INFINITY)), i);
+        set_lane(bz0, uniform(wave_min_f32(valid ? z : INFINITY)), i);
+        set_lane(bz1, uniform(wave_max_f32(valid ? z : -INFINITY)), i);
+        set_lane(smax, __builtin_amdgcn_readfirstlane(wave_max_i32(__float_as_int(t))), i);
     }
-    // ---- 6. per-slot boxes and maxima: lane i owns slot i of its wave ------------------------------
-    float bx0 = 0.f, by0 = 0.f, bz0 = 0.f, bx1 = 0.f, by1 = 0.f, bz1 = 0.f;
-    int smax = -1;
-    static_for<0, PPT>([&](auto I) {
-        constexpr int i = decltype(I)::value;
-        bool valid = t[i] >= 0.f;
-        set_lane<i>(bx0, uniform(wave_min_f32(valid ? px[i] : INFINITY)));
-        set_lane<i>(bx1, uniform(wave_max_f32(valid ? px[i] : -INFINITY)));
-        set_lane<i>(by0, uniform(wave_min_f32(valid ? py[i] : INFINITY)));
-        set_lane<i>(by1, uniform(wave_max_f32(valid ? py[i] : -INFINITY)));
-        set_lane<i>(bz0, uniform(wave_min_f32(valid ? pz[i] : INFINITY)));
-        set_lane<i>(bz1, uniform(wave_max_f32(valid ? pz[i] : -INFINITY)));
-        set_lane<i>(smax, __builtin_amdgcn_readfirstlane(wave_max_i32(__float_as_int(t[i]))));
-        __builtin_amdgcn_sched_barrier(0);
-    });
 
+    // This wave's candidate, wave-uniform, carried across rounds.  Min-distances only ever
+    // decrease, so it stays the wave's arg-max until its own slot (cslot) is updated.
+    int cM = -1, cslot = -1;
+    uint32_t ckey = KEY_NONE;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    bool cand_ok = false;
+
+#ifdef GEOT_LAB_STAMPS
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, t0, t1;
+#define GEOT_STAMP(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
+#else
+#define GEOT_STAMP(acc) do {} while (0)
+#endif
     float qx = P[0], qy = P[1], qz = P[2];
+    int r3 = 1; // j % 3
     for (int j = 1; j < m; ++j) {
+#ifdef GEOT_LAB_STAMPS
+        t0 = __builtin_readcyclecounter();
+#endif
         // -- which of my wave's slots can the new sample change?
         float dx = fmaxf(fmaxf(bx0 - qx, qx - bx1), 0.f);
         float dy = fmaxf(fmaxf(by0 - qy, qy - by1), 0.f);
         float dz = fmaxf(fmaxf(bz0 - qz, qz - bz1), 0.f);
         float lb2 = dx * dx + dy * dy + dz * dz;
-        bool act = lane < PPT && smax >= 0 && !(lb2 > __int_as_float(smax) * 1.00001f);
+        bool act = !(lb2 > __int_as_float(smax) * 1.00001f);
         unsigned long long mask = __ballot(act);
-        {
-            fp_for_each_slot<PPT>(mask, [&](auto I) {
-                constexpr int s = decltype(I)::value;
-                // opaque copies: without them LICM hoists all PPT distance evaluations out of
-                // the mask loop (they only depend on q), which is exactly the work we prune
-                float ax = qx, ay = qy, az = qz;
-                asm volatile("" : "+s"(ax), "+s"(ay), "+s"(az));
-                float d = sqdist3(px[s], py[s], pz[s], ax, ay, az);
-                float d2 = fmin_raw(d, t[s]);
-                t[s] = d2;
-                int sm = __builtin_amdgcn_readfirstlane(wave_max_i32(__float_as_int(d2)));
-                // lane s of every wave owns slot s: one v_writelane instead of a compare + select
-                set_lane<s>(smax, sm);
-            });
+#ifdef GEOT_LAB_STATS
+        if (lane == 0) {
+            atomicAdd(&geot_fps_dbg[0], (unsigned long long)__popcll(mask));
+            atomicAdd(&geot_fps_dbg[1], 1ull);
+            if (mask) atomicAdd(&geot_fps_dbg[2], 1ull);
+            if (!cand_ok || (cslot >= 0 && ((mask >> cslot) & 1ull))) atomicAdd(&geot_fps_dbg[3], 1ull);
         }
-        // -- this wave's candidate
-        int wM = __builtin_amdgcn_readfirstlane(wave_max_i32(lane < PPT ? smax : -1));
-        uint32_t wkey = KEY_NONE;
-        // volatile: keeps each slot's publish store inside its own branch (merging the PPT
-        // conditional stores into one costs ~3 VGPRs per slot in phi copies)
-        volatile FpsExch *mine = &exch[j & 1][wave];
-        if (wM >= 0) {
-            unsigned long long cm = __ballot(lane < PPT && smax == wM);
-            {
-                fp_for_each_slot<PPT>(cm, [&](auto I) {
-                    constexpr int s = decltype(I)::value;
-                    int wMo = wM;
-                    asm volatile("" : "+s"(wMo)); // keep the per-slot work inside the mask loop (see above)
-                    bool hit = __float_as_int(t[s]) == wMo;
-                    // `zero` is opaque so the (round-invariant) perm read + key computation is not
-                    // hoisted out of the round loop for all PPT slots (+1 live VGPR per point)
-                    int zero = 0;
-                    asm volatile("" : "+s"(zero));
-                    uint32_t key = KEY_NONE;
-                    if (hit) key = fps_key(perm[s * FP_THREADS + tid + zero], L);
-                    uint32_t kmin = wave_min_u32(key);
-                    if (kmin < wkey) {
-                        wkey = kmin;
-                        if (key == kmin) {
-                            mine->M = wM; mine->key = kmin;
-                            mine->x = px[s]; mine->y = py[s]; mine->z = pz[s];
-                        }
+#endif
+        const bool redo = !cand_ok || (cslot >= 0 && ((mask >> cslot) & 1ull));
+        GEOT_STAMP(tA);
+        while (mask) {
+            int s = __builtin_ctzll(mask);
+            mask &= mask - 1;
+            float d = sqdist3(X.get(s), Y.get(s), Z.get(s), qx, qy, qz);
+            float d2 = fmin_raw(d, D.get(s));
+            D.set(s, d2);
+            set_lane(smax, __builtin_amdgcn_readfirstlane(wave_max_i32_fast(__float_as_int(d2))), s);
+        }
+        GEOT_STAMP(tB);
+        // -- this wave's candidate: recomputed only when its slot was touched
+        if (redo) {
+            cand_ok = true;
+            cM = __builtin_amdgcn_readfirstlane(wave_max_i32_fast(smax));
+            ckey = KEY_NONE;
+            cslot = -1;
+            if (cM >= 0) {
+                unsigned long long cm = __ballot(smax == cM);
+                while (cm) {
+                    int s = __builtin_ctzll(cm);
+                    cm &= cm - 1;
+                    bool hit = __float_as_int(D.get(s)) == cM;
+                    uint32_t key = hit ? fps_key(perm[s * NT + tid], L) : KEY_NONE;
+                    uint32_t kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_fast(key));
+                    if (kmin < ckey) {
+                        ckey = kmin;
+                        cslot = s;
+                        int owner = __builtin_ctzll(__ballot(key == kmin));
+                        cx = read_lane(X.get(s), owner);
+                        cy = read_lane(Y.get(s), owner);
+                        cz = read_lane(Z.get(s), owner);
                     }
-                });
+                }
             }
+            if (ckey == KEY_NONE) cM = -1;
         }
-        if (wkey == KEY_NONE && lane == 0) { mine->M = -1; mine->key = KEY_NONE; }
+        GEOT_STAMP(tC);
+        // -- publish: one LDS atomic max on (M+1 : ~key) does the block arg-max with the
+        //    reference tie rule; the entry carries the coordinates for the next round
+        if (lane == 0) {
+            FpsEntry *mine = &exch[j & 1][wave];
+            mine->key = ckey; mine->x = cx; mine->y = cy; mine->z = cz;
+            unsigned long long packed = ((unsigned long long)(uint32_t)(cM + 1) << 32) | (uint32_t)~ckey;
+            lds_max_u64(&best[r3], packed);
+        }
         __syncthreads();
-        // -- block winner: max M, then min key; its coordinates become the next q
-        const FpsExch e = exch[j & 1][lane & (FP_WAVES - 1)];
-        int Mg = e.M;
-        Mg = max(Mg, (int)dpp_mov<DPP_QUAD_XOR1>((uint32_t)Mg));
-        Mg = max(Mg, (int)dpp_mov<DPP_QUAD_XOR2>((uint32_t)Mg));
-        Mg = max(Mg, (int)dpp_mov<DPP_ROW_HALF_MIRROR>((uint32_t)Mg));
-        uint32_t kg = e.M == Mg ? e.key : KEY_NONE;
-        kg = min(kg, dpp_mov<DPP_QUAD_XOR1>(kg));
-        kg = min(kg, dpp_mov<DPP_QUAD_XOR2>(kg));
-        kg = min(kg, dpp_mov<DPP_ROW_HALF_MIRROR>(kg));
-        kg = __builtin_amdgcn_readfirstlane(kg);
+        GEOT_STAMP(tD);
+        const unsigned long long bw = best[r3];
+        const FpsEntry e = exch[j & 1][lane & 15];
+        int rz = r3 + 2; rz = rz >= 3 ? rz - 3 : rz;
+        if (tid == 0) best[rz] = 0ull; // slot of round j+2: nobody can touch it before barrier j+1
+        r3 = r3 == 2 ? 0 : r3 + 1;
+        const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(bw >> 32));
+        const uint32_t kg = ~__builtin_amdgcn_readfirstlane((uint32_t)bw);
         uint32_t old;
-        if (kg == KEY_NONE) {
+        if (bhi == 0u) { // no wave has a candidate (e.g. every point origin-skipped)
             old = 0;
             qx = P[0]; qy = P[1]; qz = P[2];
         } else {
             old = fps_key_decode(kg, L);
-            unsigned long long wm = __ballot(e.M == Mg && e.key == kg);
-            int wl = __builtin_ctzll(wm);
-            qx = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e.x), wl));
-            qy = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e.y), wl));
-            qz = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(e.z), wl));
+            int wl = __builtin_ctzll(__ballot(e.key == kg) & ((1ull << NW) - 1ull));
+            qx = read_lane(e.x, wl);
+            qy = read_lane(e.y, wl);
+            qz = read_lane(e.z, wl);
         }
         if (tid == 0) out[j] = base + (int)old;
+        GEOT_STAMP(tE);
     }
-    // Re-read perm behind a compiler barrier: otherwise the gather's index and 64-bit address
-    // per slot stay live across the whole round loop (+3 VGPRs per point).
-    asm volatile("" ::: "memory");
-#pragma unroll
+#ifdef GEOT_LAB_STAMPS
+    if (lane == 0) {
+        atomicAdd(&geot_fps_dbg[0], tA); atomicAdd(&geot_fps_dbg[1], tB); atomicAdd(&geot_fps_dbg[2], tC);
+        atomicAdd(&geot_fps_dbg[3], tD); atomicAdd(&geot_fps_dbg[4], tE); atomicAdd(&geot_fps_dbg[5], (unsigned long long)(m - 1));
+    }
+#endif
+#pragma unroll 1
     for (int i = 0; i < PPT; ++i) {
-        int pos = i * FP_THREADS + tid;
-        if (pos < n && t[i] >= 0.f) T[perm[pos]] = t[i]; // skipped / padded slots hold -1
+        int pos = i * NT + tid;
+        float t = D.get(i);
+        if (pos < n && t >= 0.f) T[perm[pos]] = t; // skipped / padded slots hold -1
     }
 }
 
@@ -476,15 +540,13 @@ static hipError_t fps_pruned_launch(int b, int n_max, const float *xyz, const in
                                     const int *new_offset, int n_dense, int m_dense, float *temp,
                                     int *idxs, int L, hipStream_t s)
 {
-#define GEOT_FPP_CASE(P)                                                                            \
-    hipLaunchKernelGGL((fps_pruned_kernel<P, SKIP>), dim3(b), dim3(FP_THREADS), 0, s, xyz, offset,  \
+#define GEOT_FPP_CASE(NT, P)                                                                        \
+    hipLaunchKernelGGL((fps_pruned_kernel<NT, P, SKIP>), dim3(b), dim3(NT), 0, s, xyz, offset,      \
                        new_offset, n_dense, m_dense, temp, idxs, L)
-    if (n_max <= 4 * FP_THREADS) GEOT_FPP_CASE(4);
-    else if (n_max <= 8 * FP_THREADS) GEOT_FPP_CASE(8);
-    else if (n_max <= 16 * FP_THREADS) GEOT_FPP_CASE(16);
-    else if (n_max <= 24 * FP_THREADS) GEOT_FPP_CASE(24);
-    else if (n_max <= 32 * FP_THREADS) GEOT_FPP_CASE(32);
-    else GEOT_FPP_CASE(47);
+    if (n_max <= 8 * 512) GEOT_FPP_CASE(512, 8);
+    else if (n_max <= 16 * 512) GEOT_FPP_CASE(512, 16);
+    else if (n_max <= 32 * 512) GEOT_FPP_CASE(512, 32);
+    else GEOT_FPP_CASE(768, 32);
 #undef GEOT_FPP_CASE
     return hipGetLastError();
 }
@@ -494,7 +556,7 @@ static bool fps_use_pruned(int n_max, bool weighted)
 {
     const char *e = getenv("GEOT_FPS_IMPL"); // read per call so tests can A/B both kernels
     bool pruned = !(e && e[0] == 'b');
-    return pruned && !weighted && n_max >= 1024 && n_max <= FP_MAX_PPT * FP_THREADS;
+    return pruned && !weighted && n_max >= 1024 && n_max <= FP_MAX_N;
 }
 
 template <bool SKIP, bool WEIGHTED>
@@ -530,6 +592,18 @@ static int ref_log2_block(int work, int cap)
 }
 
 } // namespace geot
+
+#if defined(GEOT_LAB_STATS) || defined(GEOT_LAB_STAMPS)
+GEOT_EXPORT int geot_lab_read_stats(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(geot::geot_fps_dbg), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(geot::geot_fps_dbg), z, sizeof(z));
+    }
+    return e;
+}
+#endif
 
 GEOT_EXPORT int geot_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
                                              int *idxs, int block_cap, int skip_origin, void *stream)
