@@ -15,6 +15,7 @@
 // (broadcast, conflict-free) while each lane owns one query.
 #include "geot_common.h"
 #include "geot_hip.h"
+#include <cstdlib>
 
 namespace geot {
 
@@ -241,6 +242,84 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_sorted_kernel(
     for (int s = 0; s < k; ++s) { idx[o + s] = h.I(s); dist2[o + s] = h.D(s); }
 }
 
+// ---------------------------------------------------------------------------
+// Wave-cooperative sorted kNN (k <= 64): the 64 lanes each take one reference point per
+// step, the wave serves QW queries whose running best-k lists live one entry per lane
+// (lane i = i-th smallest, lanes >= k hold +inf).  A step costs ~10 VALU per query for all
+// 64 pairs; a candidate beating the current k-th distance tau (wave-uniform) is inserted
+// with one ballot (its rank = #entries <= it, i.e. after equal distances: the (d2, index)
+// order, since lanes are visited in ascending index) and one wave_shr:1 DPP shift.
+// Expected insertions per query are ~k ln(n/k), so the scan dominates.
+// Result identical to knn_sorted_kernel / the reference contract; also serves three_nn
+// (k = 3: "3 smallest by (d2, index)", interpolate_gpu.cu:31-53).
+// ---------------------------------------------------------------------------
+constexpr int KW_QW = 4;     // queries per wave
+constexpr int KW_WAVES = 4;  // waves per block
+constexpr int DPP_WAVE_SHR1 = 0x138;
+
+__device__ __forceinline__ float dpp_wave_shr1(float v, float fill)
+{
+    // lane l receives lane l-1; lane 0 keeps `fill` (bound_ctrl off => old value)
+    return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)__float_as_uint(fill), (int)__float_as_uint(v),
+                                                                 DPP_WAVE_SHR1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ int dpp_wave_shr1(int v, int fill)
+{
+    return __builtin_amdgcn_update_dpp(fill, v, DPP_WAVE_SHR1, 0xF, 0xF, false);
+}
+
+__global__ __launch_bounds__(KW_WAVES * 64) void knn_wave_kernel(
+    int nq, int nr, int k, const float *__restrict__ query, const float *__restrict__ ref,
+    int *__restrict__ idx, float *__restrict__ dist2)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int bi = blockIdx.y;
+    const int q0 = (blockIdx.x * KW_WAVES + wave) * KW_QW;
+    if (q0 >= nq) return;
+    const float *Q = query + (size_t)bi * nq * 3;
+    const float *R = ref + (size_t)bi * nr * 3;
+    float qx[KW_QW], qy[KW_QW], qz[KW_QW], ld[KW_QW], tau[KW_QW];
+    int li[KW_QW];
+#pragma unroll
+    for (int q = 0; q < KW_QW; ++q) {
+        int j = min(q0 + q, nq - 1); // tail waves recompute the last query; stores are guarded
+        qx[q] = Q[j * 3]; qy[q] = Q[j * 3 + 1]; qz[q] = Q[j * 3 + 2];
+        ld[q] = INFINITY; li[q] = 0; tau[q] = INFINITY;
+    }
+    for (int c0 = 0; c0 < nr; c0 += 64) {
+        const int r = c0 + lane;
+        const bool in = r < nr;
+        float rx = 0.f, ry = 0.f, rz = 0.f;
+        if (in) { rx = R[r * 3]; ry = R[r * 3 + 1]; rz = R[r * 3 + 2]; }
+#pragma unroll
+        for (int q = 0; q < KW_QW; ++q) {
+            float d = sqdist3(qx[q], qy[q], qz[q], rx, ry, rz);
+            unsigned long long mask = __ballot(in && d < tau[q]);
+            while (mask) {
+                int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                float dc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(d), l));
+                if (!(dc < tau[q])) continue; // tau may have dropped within this step
+                int pos = __popcll(__ballot(ld[q] <= dc));
+                float sd = dpp_wave_shr1(ld[q], ld[q]);
+                int si = dpp_wave_shr1(li[q], li[q]);
+                ld[q] = lane > pos ? sd : (lane == pos ? dc : ld[q]);
+                li[q] = lane > pos ? si : (lane == pos ? c0 + l : li[q]);
+                tau[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ld[q]), k - 1));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KW_QW; ++q) {
+        int j = q0 + q;
+        if (j < nq && lane < k) {
+            size_t o = ((size_t)bi * nq + j) * k + lane;
+            idx[o] = li[q];
+            dist2[o] = ld[q];
+        }
+    }
+}
+
 static inline int grid_cap(long long want, int cap) { return (int)(want < cap ? (want < 1 ? 1 : want) : cap); }
 
 } // namespace geot
@@ -281,8 +360,15 @@ GEOT_EXPORT int geot_three_nn(int b, int n, int m, const float *unknown, const f
     if (b < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
     if (b == 0 || n == 0) return hipSuccess;
     if (b > 65535) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(three_nn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS, b), dim3(NN_THREADS), 0,
-                       (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+    const char *e = getenv("GEOT_NN_IMPL"); // "basic" = one-lane-per-query kernels (A/B testing)
+    if (e && e[0] == 'b') {
+        hipLaunchKernelGGL(three_nn_kernel, dim3((n + NN_THREADS - 1) / NN_THREADS, b), dim3(NN_THREADS), 0,
+                           (hipStream_t)stream, n, m, unknown, known, dist2, idx);
+    } else {
+        int per_block = KW_WAVES * KW_QW;
+        hipLaunchKernelGGL(knn_wave_kernel, dim3((n + per_block - 1) / per_block, b), dim3(KW_WAVES * 64), 0,
+                           (hipStream_t)stream, n, m, 3, unknown, known, idx, dist2);
+    }
     return hipGetLastError();
 }
 
@@ -305,6 +391,13 @@ GEOT_EXPORT int geot_knn_sorted(int b, int nq, int nr, int k, const float *query
     if (b < 0 || nq < 0 || nr < 0 || k < 0 || k > 256) return hipErrorInvalidValue;
     if (b == 0 || nq == 0 || k == 0) return hipSuccess;
     if (b > 65535) return hipErrorInvalidValue;
+    const char *e = getenv("GEOT_NN_IMPL");
+    if (k <= 64 && !(e && e[0] == 'b')) {
+        int per_block = KW_WAVES * KW_QW;
+        hipLaunchKernelGGL(knn_wave_kernel, dim3((nq + per_block - 1) / per_block, b), dim3(KW_WAVES * 64), 0,
+                           (hipStream_t)stream, nq, nr, k, query, ref, idx, dist2);
+        return hipGetLastError();
+    }
     size_t lds = (size_t)k * KNN_THREADS * 8;
     hipLaunchKernelGGL(knn_sorted_kernel, dim3((nq + KNN_THREADS - 1) / KNN_THREADS, b),
                        dim3(KNN_THREADS), lds, (hipStream_t)stream, nq, nr, k, query, ref, idx, dist2);
