@@ -41,6 +41,14 @@ PROTOTYPES = {
     "geot_sa_group_mlp_max": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_float, _c_int,
                               ctypes.POINTER(_c_int), _c_int, _P, _P, _c_void_p],
 }
+PROTOTYPES.update({
+    "geot_ntm_sig_t_mean": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_sig_t_mean_grad_raw": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_correct": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_correct_grad": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_threed_loss": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_threed_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _c_void_p],
+})
 # entry points that do not follow the "(..., stream) -> hipError_t" shape
 PLAIN = {
     "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),

@@ -1,0 +1,378 @@
+// ntm.hip -- per-point noise-transition-matrix (NTM) block for gfx950 (MI355X).
+//
+// Replaces the Python/torch chains of the reference (behaviour, not code):
+//   sig_t_mean.forward           openpoints/models/backbone/transformer.py:1120-1131
+//       17 Linear(34->17) calls + cat/repeat temporaries + clamp + L1-normalise
+//   logit correction             examples/segmentation/train.py:549-552
+//       newT = normalize(lam*ema_t_corr + (1-lam)*insT); bmm((BN,1,C),(BN,C,C))
+//   threeD_space_loss.forward    utils/insT_loss.py:68-110
+//       32 index_select/cat rounds building (BN,32,289) twice, then the weighted distance
+//
+// All of these stream the (B*N, C, C) per-point matrices (1156 B per point at C=17): they are
+// HBM / L2-bandwidth bound.  Every kernel moves those rows as whole contiguous tiles
+// (64 points x C*C floats = 74 KB through LDS, or one 1156-B row per wave-instruction group)
+// and fuses everything else, so each matrix is read or written exactly once per kernel.
+// C is a template parameter (the reference fixes num_classes = 17).
+#include "geot_common.h"
+#include "geot_hip.h"
+
+namespace geot {
+
+constexpr int NTM_THREADS = 256;
+constexpr int NTM_TILE = 64; // points per LDS tile
+
+template <int C>
+struct NtmLds {
+    static constexpr int CC = C * C;
+    static constexpr int TILE_FLOATS = NTM_TILE * CC;
+    static constexpr int STRIDE = CC | 1; // odd row stride: conflict-free per-point access
+};
+
+// Cooperative, fully coalesced copy of a [cnt][CC] tile between global (contiguous) and LDS
+// (row stride STRIDE).
+template <int C, bool TO_LDS>
+__device__ __forceinline__ void ntm_tile_copy(float *__restrict__ g, float *__restrict__ lds, int cnt)
+{
+    constexpr int CC = C * C, STRIDE = NtmLds<C>::STRIDE;
+    const int total = cnt * CC;
+    for (int e = threadIdx.x; e < total; e += NTM_THREADS) {
+        int pt = e / CC, w = e - pt * CC;
+        if (TO_LDS) lds[pt * STRIDE + w] = g[e];
+        else g[e] = lds[pt * STRIDE + w];
+    }
+}
+
+// ---- sig_t_mean forward -------------------------------------------------------------------
+// raw[kk][o] = sum_j p_j W[kk][o][j] + sum_j cm[kk][j] W[kk][o][C+j]; clamp; L1-normalise over o.
+template <int C, bool BACKWARD>
+__global__ __launch_bounds__(NTM_THREADS) void sig_t_mean_kernel(
+    int total_pts, int n, const float *__restrict__ p, const float *__restrict__ W,
+    const float *__restrict__ cm, const float *__restrict__ grad_out, float *__restrict__ out)
+{
+    constexpr int CC = C * C, STRIDE = NtmLds<C>::STRIDE;
+    extern __shared__ float ntm_lds[];
+    float *Wa = ntm_lds;            // [kk][o][j]
+    float *bias = Wa + C * CC;      // [kk][o]
+    float *tile = bias + CC;        // [NTM_TILE][STRIDE]
+    for (int e = threadIdx.x; e < C * CC; e += NTM_THREADS) {
+        int kk = e / CC, r = e - kk * CC, o = r / C, j = r - o * C;
+        Wa[e] = W[((size_t)kk * C + o) * 2 * C + j];
+    }
+    for (int e = threadIdx.x; e < CC; e += NTM_THREADS) {
+        int kk = e / C, o = e - kk * C;
+        float acc = 0.f;
+        for (int j = 0; j < C; ++j) acc += cm[kk * C + j] * W[((size_t)kk * C + o) * 2 * C + C + j];
+        bias[e] = acc;
+    }
+    __syncthreads();
+    const int pt = threadIdx.x & (NTM_TILE - 1), grp = threadIdx.x >> 6; // 4 row groups
+    for (int i0 = blockIdx.x * NTM_TILE; i0 < total_pts; i0 += gridDim.x * NTM_TILE) {
+        const int cnt = min(NTM_TILE, total_pts - i0);
+        if (BACKWARD) {
+            ntm_tile_copy<C, true>(const_cast<float *>(grad_out) + (size_t)i0 * CC, tile, cnt);
+            __syncthreads();
+        }
+        if (pt < cnt) {
+            const int i = i0 + pt, b = i / n, ni = i - b * n;
+            float pv[C];
+#pragma unroll
+            for (int j = 0; j < C; ++j) pv[j] = p[((size_t)b * C + j) * n + ni];
+            for (int kk = grp; kk < C; kk += 4) {
+                float raw[C], s = 0.f;
+#pragma unroll
+                for (int o = 0; o < C; ++o) {
+                    float acc = bias[kk * C + o];
+#pragma unroll
+                    for (int j = 0; j < C; ++j) acc = fmaf(pv[j], Wa[(kk * C + o) * C + j], acc);
+                    raw[o] = acc;
+                    s += fminf(fmaxf(acc, 1e-5f), 1.f - 1e-5f); // clamped values are positive
+                }
+                const float den = fmaxf(s, 1e-12f);
+                float *row = tile + pt * STRIDE + kk * C;
+                if (!BACKWARD) {
+#pragma unroll
+                    for (int o = 0; o < C; ++o) row[o] = fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) / den;
+                } else {
+                    // d raw = [raw inside the clamp] * (g - sum_o g*tn) / den
+                    float dot = 0.f;
+#pragma unroll
+                    for (int o = 0; o < C; ++o) dot += row[o] * (fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) / den);
+#pragma unroll
+                    for (int o = 0; o < C; ++o) {
+                        bool inside = raw[o] >= 1e-5f && raw[o] <= 1.f - 1e-5f;
+                        row[o] = inside ? (row[o] - dot) / den : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        ntm_tile_copy<C, false>(out + (size_t)i0 * CC, tile, cnt);
+        __syncthreads();
+    }
+}
+
+// ---- logit correction ----------------------------------------------------------------------
+// v = lam*E + (1-lam)*T_i; tn = v / max(sum_c |v|, eps); out[c] = sum_r logit[r] * tn[r][c].
+template <int C, bool BACKWARD>
+__global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
+    int total_pts, int n, float lam, const float *__restrict__ logits, const float *__restrict__ insT,
+    const float *__restrict__ E, const float *__restrict__ grad_out, float *__restrict__ out,
+    float *__restrict__ grad_logits, float *__restrict__ grad_insT, float *__restrict__ grad_E)
+{
+    constexpr int CC = C * C, STRIDE = NtmLds<C>::STRIDE;
+    extern __shared__ float ntm_lds[];
+    float *El = ntm_lds;                         // [CC]
+    float *accE = El + CC;                       // [CC] block partial of grad_E (backward)
+    float *part = accE + CC;                     // [4][NTM_TILE][C] partial outputs per row group
+    float *tile = part + 4 * NTM_TILE * C;       // [NTM_TILE][STRIDE]
+    for (int e = threadIdx.x; e < CC; e += NTM_THREADS) { El[e] = E[e]; accE[e] = 0.f; }
+    __syncthreads();
+    const int pt = threadIdx.x & (NTM_TILE - 1), grp = threadIdx.x >> 6;
+    for (int i0 = blockIdx.x * NTM_TILE; i0 < total_pts; i0 += gridDim.x * NTM_TILE) {
+        const int cnt = min(NTM_TILE, total_pts - i0);
+        ntm_tile_copy<C, true>(const_cast<float *>(insT) + (size_t)i0 * CC, tile, cnt);
+        __syncthreads();
+        const int i = i0 + pt, b = pt < cnt ? i / n : 0, ni = pt < cnt ? i - b * n : 0;
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        if (pt < cnt) {
+            float go[C];
+            if (BACKWARD) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) go[c] = grad_out[((size_t)b * C + c) * n + ni];
+            }
+            for (int r = grp; r < C; r += 4) {
+                float *row = tile + pt * STRIDE + r * C;
+                const float l = logits[((size_t)b * C + r) * n + ni];
+                float v[C], s = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    v[c] = lam * El[r * C + c] + (1.f - lam) * row[c];
+                    s += fabsf(v[c]);
+                }
+                const float den = fmaxf(s, 1e-12f);
+                if (!BACKWARD) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] = fmaf(l, v[c] / den, acc[c]);
+                } else {
+                    float gl = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) gl += (v[c] / den) * go[c];
+                    grad_logits[((size_t)b * C + r) * n + ni] = gl;
+                    const float dot = l * gl; // sum_c dtn*tn with dtn = l*go
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        float sg = v[c] > 0.f ? 1.f : (v[c] < 0.f ? -1.f : 0.f);
+                        float dv = s > 1e-12f ? (l * go[c] - sg * dot) / den : l * go[c] / den;
+                        row[c] = (1.f - lam) * dv;
+                        atomicAdd(&accE[r * C + c], lam * dv);
+                    }
+                }
+            }
+        }
+        if (!BACKWARD) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) part[(grp * NTM_TILE + pt) * C + c] = acc[c];
+        }
+        __syncthreads();
+        if (!BACKWARD) {
+            for (int e = threadIdx.x; e < cnt * C; e += NTM_THREADS) {
+                int c = e / cnt, q = e - c * cnt; // q fastest: coalesced along the point dimension
+                float v = part[(0 * NTM_TILE + q) * C + c] + part[(1 * NTM_TILE + q) * C + c] +
+                          part[(2 * NTM_TILE + q) * C + c] + part[(3 * NTM_TILE + q) * C + c];
+                int gi = i0 + q, gb = gi / n, gn = gi - gb * n;
+                out[((size_t)gb * C + c) * n + gn] = v;
+            }
+        } else {
+            ntm_tile_copy<C, false>(grad_insT + (size_t)i0 * CC, tile, cnt);
+        }
+        __syncthreads();
+    }
+    if (BACKWARD)
+        for (int e = threadIdx.x; e < CC; e += NTM_THREADS) atomicAdd(grad_E + e, accE[e]);
+}
+
+// ---- threeD_space_loss -----------------------------------------------------------------------
+// One wave per point i: T_i held across lanes (element e = lane + 64*r), neighbour rows T_j read as
+// contiguous 4*CC-byte rows; w_ij = [label_i == label_j] * exp(-|p_i-p_j|^2 / (2 sigma^2)).
+// forward : per_point[i] = sum_j w_ij |T_i - T_j|^2 / (sum_j w_ij + 1e-3)
+// backward: grad_T[i] += coef_i * sum_j w_ij (T_i - T_j);  grad_T[j] -= coef_i * w_ij (T_i - T_j)
+//           with coef_i = 2 * gscale / (sum_j w_ij + 1e-3)     (gscale = upstream grad / (B*N))
+template <int CC, bool BACKWARD>
+__global__ __launch_bounds__(256) void threed_loss_kernel(
+    int total_pts, int n, int k, float inv2s2, float gscale, const float *__restrict__ pos,
+    const int *__restrict__ labels, const float *__restrict__ T, const int *__restrict__ nbr,
+    float *__restrict__ per_point, float *__restrict__ grad_T)
+{
+    constexpr int R = (CC + 63) / 64;
+    const int lane = lane_id();
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total_pts; i += gridDim.x * 4) {
+        const int b = i / n;
+        const float *Ti = T + (size_t)i * CC;
+        float ti[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) ti[r] = (lane + 64 * r < CC) ? Ti[lane + 64 * r] : 0.f;
+        const float px = pos[(size_t)i * 3], py = pos[(size_t)i * 3 + 1], pz = pos[(size_t)i * 3 + 2];
+        const int li = labels[i];
+        // lanes 0..k-1 evaluate the k weights in parallel
+        int j = -1;
+        float w = 0.f;
+        if (lane < k) {
+            j = b * n + nbr[(size_t)i * k + lane];
+            float dx = px - pos[(size_t)j * 3], dy = py - pos[(size_t)j * 3 + 1], dz = pz - pos[(size_t)j * 3 + 2];
+            float d2 = dx * dx + dy * dy + dz * dz;
+            w = labels[j] == li ? __expf(-d2 * inv2s2) : 0.f;
+        }
+        float S = w;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) S += __shfl_xor(S, o);
+        S += 0.001f;
+        unsigned long long live = __ballot(w != 0.f);
+        float acc = 0.f, gi[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) gi[r] = 0.f;
+        const float coef = BACKWARD ? 2.f * gscale / S : 0.f;
+        while (live) {
+            int l = __builtin_ctzll(live);
+            live &= live - 1;
+            const int jj = __builtin_amdgcn_readlane(j, l);
+            const float wj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(w), l));
+            const float *Tj = T + (size_t)jj * CC;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int e = lane + 64 * r;
+                if (e < CC) {
+                    float d = ti[r] - Tj[e];
+                    if (!BACKWARD) acc = fmaf(wj * d, d, acc);
+                    else {
+                        float c = coef * wj * d;
+                        gi[r] += c;
+                        atomicAdd(grad_T + (size_t)jj * CC + e, -c);
+                    }
+                }
+            }
+        }
+        if (!BACKWARD) {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) per_point[i] = acc / S;
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                int e = lane + 64 * r;
+                if (e < CC) atomicAdd(grad_T + (size_t)i * CC + e, gi[r]);
+            }
+        }
+    }
+}
+
+template <typename K>
+static hipError_t set_lds(K kernel, size_t lds)
+{
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+static inline int ntm_blocks(int total_pts)
+{
+    int tiles = (total_pts + NTM_TILE - 1) / NTM_TILE;
+    return tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles);
+}
+
+} // namespace geot
+
+using namespace geot;
+
+#define GEOT_NTM_C 17 /* the reference's num_classes (cfgs/tooth_semi/default.yaml:29) */
+
+GEOT_EXPORT int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const float *W, const float *cm,
+                                    float *ins_T, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int C = GEOT_NTM_C;
+    size_t lds = (size_t)(C * C * C + C * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    hipError_t e = set_lds(sig_t_mean_kernel<C, false>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sig_t_mean_kernel<C, false>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
+                       (hipStream_t)stream, b * n, n, p, W, cm, nullptr, ins_T);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_sig_t_mean_grad_raw(int b, int n, int c, const float *p, const float *W,
+                                             const float *cm, const float *grad_ins_T, float *grad_raw,
+                                             void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int C = GEOT_NTM_C;
+    size_t lds = (size_t)(C * C * C + C * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    hipError_t e = set_lds(sig_t_mean_kernel<C, true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((sig_t_mean_kernel<C, true>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
+                       (hipStream_t)stream, b * n, n, p, W, cm, grad_ins_T, grad_raw);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_correct(int b, int n, int c, float lam, const float *logits, const float *ins_T,
+                                 const float *ema_t, float *out, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int C = GEOT_NTM_C;
+    size_t lds = (size_t)(2 * C * C + 4 * NTM_TILE * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    hipError_t e = set_lds(ntm_correct_kernel<C, false>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ntm_correct_kernel<C, false>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
+                       (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, nullptr, out, nullptr,
+                       nullptr, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_correct_grad(int b, int n, int c, float lam, const float *logits,
+                                      const float *ins_T, const float *ema_t, const float *grad_out,
+                                      float *grad_logits, float *grad_ins_T, float *grad_ema_t,
+                                      void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int C = GEOT_NTM_C;
+    size_t lds = (size_t)(2 * C * C + 4 * NTM_TILE * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    hipError_t e = set_lds(ntm_correct_kernel<C, true>, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((ntm_correct_kernel<C, true>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
+                       (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, grad_out, nullptr,
+                       grad_logits, grad_ins_T, grad_ema_t);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_threed_loss(int b, int n, int c, int k, float sigma, const float *positions,
+                                     const int *labels, const float *ins_T, const int *nbr,
+                                     float *per_point, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
+    int blocks = (b * n + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((threed_loss_kernel<CC, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       b * n, n, k, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr,
+                       per_point, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigma, float grad_scale,
+                                          const float *positions, const int *labels, const float *ins_T,
+                                          const int *nbr, float *grad_ins_T, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
+    int blocks = (b * n + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((threed_loss_kernel<CC, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       b * n, n, k, 1.f / (2.f * sigma * sigma), grad_scale, positions, labels, ins_T, nbr,
+                       nullptr, grad_ins_T);
+    return hipGetLastError();
+}

@@ -1,0 +1,213 @@
+"""Per-point instance-dependent transition-matrix (NTM) estimation on MI355X.
+
+Mirrors the reference pieces that make up the FixMatch+NTM step:
+
+  sig_t_mean, Ins_T_mean     openpoints/models/backbone/transformer.py:1099-1131,
+                             openpoints/models/segmentation/base_seg.py:254-263
+  class_transition()         examples/segmentation/train.py:505-545, 556-557 (+ gaussian :835-836)
+  correct_logits()           examples/segmentation/train.py:549-552
+  threeD_space_loss          utils/insT_loss.py:61-110
+
+Same constructor arguments / call signatures / returned tensors as the reference.  The
+per-point (B*N, C, C) work runs in fused HIP kernels (geot_amd/csrc/ntm.hip); the C x C
+bookkeeping of class_transition() is vectorised torch (no Python loop over classes, no
+host round trips -- the reference does 289 scalar device ops per step there).
+"""
+import math
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from .ext._common import f32, i32, same_device, need, call, ptr
+from .knn_cuda import knn_sorted
+
+LABEL_PROJ = [0, 8, 7, 6, 5, 4, 3, 2, 1, 9, 10, 11, 12, 13, 14, 15, 16]  # train.py:48
+
+
+# ---------------------------------------------------------------------------------------------
+class _SigTMeanFn(Function):
+    @staticmethod
+    def forward(ctx, p, cm, W):
+        p = f32(p.contiguous(), "x", 3)
+        cm = f32(cm.contiguous(), "cm", 2)
+        W = f32(W.contiguous(), "weight", 3)
+        dev = same_device(p, cm, W)
+        b, c, n = p.shape
+        need(tuple(cm.shape) == (c, c) and tuple(W.shape) == (c, c, 2 * c), "sig_t_mean shape mismatch")
+        out = torch.empty((b * n, c, c), dtype=torch.float32, device=dev)
+        call("geot_ntm_sig_t_mean", dev, b, n, c, ptr(p), ptr(W), ptr(cm), ptr(out))
+        ctx.save_for_backward(p, cm, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        p, cm, W = ctx.saved_tensors
+        b, c, n = p.shape
+        g = grad_out.contiguous()
+        raw = torch.empty_like(g)
+        call("geot_ntm_sig_t_mean_grad_raw", p.device, b, n, c, ptr(p), ptr(W), ptr(cm), ptr(g), ptr(raw))
+        # weight gradient = the Linear layers' own backward GEMMs (tiny: 289 x BN x 34)
+        flat = p.permute(0, 2, 1).reshape(b * n, c)                       # (BN, C)
+        gwa = torch.einsum("iko,ij->koj", raw, flat)                       # (C, C, C)
+        gwb = raw.sum(0).unsqueeze(2) * cm.unsqueeze(1)                    # (C, C, C): [kk][o][j] = S[kk][o]*cm[kk][j]
+        return None, None, torch.cat([gwa, gwb], dim=2)
+
+
+class sig_t_mean(nn.Module):
+    """`nclasses` bias-free Linear(2C -> C) heads, one per transition-matrix row
+    (transformer.py:1101-1131).  forward(x (B,C,N) softmax, cm (C,C)) -> ins_T (B*N, C, C)."""
+
+    def __init__(self, nclasses):
+        super().__init__()
+        self.nclasses = nclasses
+        self.fc = nn.ModuleList([nn.Linear(nclasses * 2, nclasses, bias=False) for _ in range(nclasses)])
+
+    def stacked_weight(self):
+        return torch.stack([l.weight for l in self.fc], dim=0)          # (C, C, 2C), differentiable
+
+    def forward(self, x, cm):
+        return _SigTMeanFn.apply(x, cm, self.stacked_weight())
+
+
+class Ins_T_mean(nn.Module):
+    """base_seg.py:254-263 (registry-free: pass the predictor or the class count)."""
+
+    def __init__(self, T_args=None, nclasses=17, **kwargs):
+        super().__init__()
+        if isinstance(T_args, nn.Module):
+            self.T_predictor = T_args
+        else:
+            if isinstance(T_args, dict):
+                nclasses = T_args.get("nclasses", nclasses)
+            self.T_predictor = sig_t_mean(nclasses)
+
+    def forward(self, clean, cm):
+        return self.T_predictor(clean, cm)
+
+
+# ---------------------------------------------------------------------------------------------
+def gaussian(x, mu, s):
+    """train.py:835-836."""
+    return (1 / (s * math.sqrt(2 * math.pi))) * torch.exp(-((x - mu) ** 2) / (2 * s ** 2))
+
+
+def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999):
+    """The class-level transition estimate of train.py:505-545 + EMA update :556-557.
+
+    eta (B_u, C, N): softmax of the weak view (detached), sigma (C,): learnable widths returned by
+    the segmentor, ema_t (C, C).  Returns (ema_t_corr, ema_t_next, class_T, prior_T).
+    `X / X.sum(1)` is kept exactly as written in the reference (it broadcasts the row sums along
+    the last axis, i.e. divides column j by row-sum j)."""
+    B, C, N = eta.shape
+    eta = eta.detach()
+    flat = eta.permute(1, 0, 2).reshape(C, B * N)
+    best = torch.argmax(flat, dim=1)                                      # first maximum per class
+    class_T = eta.permute(0, 2, 1).reshape(B * N, C)[best]                # (C, C): row cc = eta[b*, :, n*]
+    proj = torch.tensor(LABEL_PROJ[:C], dtype=eta.dtype, device=eta.device)
+    prior_T = gaussian(proj.unsqueeze(0), proj.unsqueeze(1), sigma.unsqueeze(1))   # [cc][k]
+    row0 = torch.zeros(C, dtype=eta.dtype, device=eta.device)
+    row0[0] = 1
+    keep = torch.ones(C, dtype=eta.dtype, device=eta.device)
+    keep[0] = 0
+    prior_T = torch.cat([row0.unsqueeze(0), prior_T[1:] * keep.unsqueeze(0)], dim=0)  # [:,0]=0; [0,0]=1
+    prior_T = prior_T / torch.sum(prior_T, 1)
+    new_T = geo_lambda * class_T + (1 - geo_lambda) * prior_T
+    new_T = torch.cat([class_T[:1], new_T[1:]], dim=0)
+    new_T = new_T / torch.sum(new_T, 1)
+    ema_t_corr = ema_t * ema_decay + new_T * (1 - ema_decay)
+    ema_t_corr = ema_t_corr / torch.sum(ema_t_corr, 1)
+    ema_next = ema_t * ema_decay + class_T * (1 - ema_decay)
+    ema_next = ema_next / torch.sum(ema_next, 1)
+    return ema_t_corr, ema_next, class_T, prior_T
+
+
+# ---------------------------------------------------------------------------------------------
+class _CorrectFn(Function):
+    @staticmethod
+    def forward(ctx, logits, ins_T, ema_t, lam):
+        logits = f32(logits.contiguous(), "logits", 3)
+        ins_T = f32(ins_T.contiguous(), "ins_T", 3)
+        ema_t = f32(ema_t.contiguous(), "ema_t", 2)
+        dev = same_device(logits, ins_T, ema_t)
+        b, c, n = logits.shape
+        need(tuple(ins_T.shape) == (b * n, c, c) and tuple(ema_t.shape) == (c, c), "correct_logits shape mismatch")
+        out = torch.empty_like(logits)
+        call("geot_ntm_correct", dev, b, n, c, float(lam), ptr(logits), ptr(ins_T), ptr(ema_t), ptr(out))
+        ctx.save_for_backward(logits, ins_T, ema_t)
+        ctx.lam = float(lam)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        logits, ins_T, ema_t = ctx.saved_tensors
+        b, c, n = logits.shape
+        g = grad_out.contiguous()
+        gl = torch.empty_like(logits)
+        gi = torch.empty_like(ins_T)
+        ge = torch.zeros_like(ema_t)
+        call("geot_ntm_correct_grad", logits.device, b, n, c, ctx.lam, ptr(logits), ptr(ins_T), ptr(ema_t),
+             ptr(g), ptr(gl), ptr(gi), ptr(ge))
+        return gl, gi, ge, None
+
+
+def correct_logits(pred_u_strong, ins_T, ema_t_corr, lam):
+    """train.py:549-552 fused: returns pred_u_strong_corr (B_u, C, N) =
+    bmm(logits_i (1,C), normalize(lam*ema_t_corr + (1-lam)*ins_T_i, p=1, dim=-1)); newT is never
+    materialised.  Differentiable w.r.t. the logits, ins_T and ema_t_corr."""
+    return _CorrectFn.apply(pred_u_strong, ins_T, ema_t_corr, lam)
+
+
+# ---------------------------------------------------------------------------------------------
+class _ThreeDLossFn(Function):
+    @staticmethod
+    def forward(ctx, positions, labels, ins_T, nbr, sigma):
+        positions = f32(positions.contiguous(), "positions", 3)
+        ins_T = f32(ins_T.contiguous(), "ins_T", 3)
+        labels = i32(labels.contiguous(), "labels", 2)
+        nbr = i32(nbr.contiguous(), "nbr", 3)
+        dev = same_device(positions, labels, ins_T, nbr)
+        b, n, _ = positions.shape
+        c = ins_T.shape[1]
+        k = nbr.shape[2]
+        need(tuple(ins_T.shape) == (b * n, c, c) and tuple(labels.shape) == (b, n) and tuple(nbr.shape) == (b, n, k),
+             "threeD_space_loss shape mismatch")
+        per_point = torch.empty(b * n, dtype=torch.float32, device=dev)
+        call("geot_ntm_threed_loss", dev, b, n, c, k, float(sigma), ptr(positions), ptr(labels), ptr(ins_T),
+             ptr(nbr), ptr(per_point))
+        ctx.save_for_backward(positions, labels, ins_T, nbr)
+        ctx.sigma = float(sigma)
+        return per_point.mean()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        positions, labels, ins_T, nbr = ctx.saved_tensors
+        b, n, _ = positions.shape
+        c, k = ins_T.shape[1], nbr.shape[2]
+        g = torch.zeros_like(ins_T)
+        scale = float(grad_out.item()) / (b * n) if grad_out.numel() == 1 else 1.0 / (b * n)
+        call("geot_ntm_threed_loss_grad", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
+             ptr(labels), ptr(ins_T), ptr(nbr), ptr(g))
+        return None, None, g, None, None
+
+
+class threeD_space_loss(nn.Module):
+    """utils/insT_loss.py:61-110.  forward(positions (B,N,3), labels (B,N), ins_T (B*N,C,C)) -> scalar.
+    Neighbours = the k nearest other points (reference: knn_point(k+1)[..., 1:], i.e. the nearest hit
+    is dropped as "self"); the N x N distance matrix and the (BN, k, C*C) gathers are never built."""
+
+    def __init__(self, k=7, sigma=1.0, num_classes=17):
+        super().__init__()
+        self.k = k
+        self.sigma = sigma
+        self.num_classes = num_classes
+
+    @torch.no_grad()
+    def neighbours(self, positions):
+        _, idx = knn_sorted(positions.contiguous().float(), positions.contiguous().float(), self.k + 1)
+        return idx[:, :, 1:].contiguous()
+
+    def forward(self, positions, labels, ins_T, nbr=None):
+        if nbr is None:
+            nbr = self.neighbours(positions)
+        return _ThreeDLossFn.apply(positions, labels.to(torch.int32), ins_T, nbr, self.sigma)

@@ -150,6 +150,41 @@ int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int c_feat, con
                           float xyz_scale, int nlayers, const int *widths, int relu_mask,
                           const float *params, float *out, void *stream);
 
+/* ---- NTM: per-point instance-dependent transition matrix ------
+ * c must be 17 (the reference's num_classes, cfgs/tooth_semi/default.yaml:29).
+ *
+ * sig_t_mean.forward (openpoints/models/backbone/transformer.py:1120-1131), fused:
+ *   p (b,c,n) softmax probs, W (c,c,2c) = the c Linear(2c->c, bias=False) weights stacked
+ *   [kk][out][in], cm (c,c) class means -> ins_T (b*n,c,c): row kk = clamp([p_i, cm[kk]] @ W[kk]^T,
+ *   1e-5, 1-1e-5), L1-normalised.
+ * _grad_raw: d loss / d (pre-clamp row) for a given d loss / d ins_T (the caller finishes the tiny
+ *   weight-gradient GEMM, as nn.Linear's backward does in the reference). */
+int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const float *W, const float *cm,
+                        float *ins_T, void *stream);
+int geot_ntm_sig_t_mean_grad_raw(int b, int n, int c, const float *p, const float *W, const float *cm,
+                                 const float *grad_ins_T, float *grad_raw, void *stream);
+/* Logit correction (examples/segmentation/train.py:549-552), fused:
+ *   newT_i = L1-normalise(lam * ema_t + (1-lam) * ins_T_i); out[:, i] = logits[:, i]^T @ newT_i.
+ *   logits/out (b,c,n), ins_T (b*n,c,c), ema_t (c,c).  _grad: grad_logits (b,c,n) and grad_ins_T are
+ *   written in full, grad_ema_t (c,c) is accumulated into (pre-zero it). */
+int geot_ntm_correct(int b, int n, int c, float lam, const float *logits, const float *ins_T,
+                     const float *ema_t, float *out, void *stream);
+int geot_ntm_correct_grad(int b, int n, int c, float lam, const float *logits, const float *ins_T,
+                          const float *ema_t, const float *grad_out, float *grad_logits,
+                          float *grad_ins_T, float *grad_ema_t, void *stream);
+/* threeD_space_loss (utils/insT_loss.py:68-110) over a given kNN graph:
+ *   positions (b,n,3), labels (b,n) int32, ins_T (b*n,c,c), nbr (b,n,k) int32 local neighbour ids
+ *   (the reference uses knn_point(k+1)[..., 1:]); per_point (b*n) = sum_j w_ij |T_i-T_j|^2 /
+ *   (sum_j w_ij + 1e-3), w_ij = [label_i==label_j] exp(-|p_i-p_j|^2/(2 sigma^2)); loss = mean.
+ *   _grad accumulates grad_scale * d(sum per_point)/d ins_T into grad_ins_T (pre-zero it);
+ *   pass grad_scale = upstream_grad / (b*n).  k <= 64. */
+int geot_ntm_threed_loss(int b, int n, int c, int k, float sigma, const float *positions,
+                         const int *labels, const float *ins_T, const int *nbr, float *per_point,
+                         void *stream);
+int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigma, float grad_scale,
+                              const float *positions, const int *labels, const float *ins_T,
+                              const int *nbr, float *grad_ins_T, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,131 @@
+"""GPU suite: the fused NTM kernels against the fp64 restatement (oracle/np_ntm.py), fp32
+tolerance 1e-5 relative (sums of <= 289 products; atomically accumulated gradients 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from geot_amd.synth import make_batch
+from oracle import np_ntm
+
+pytestmark = pytest.mark.gpu
+C = 17
+DEV = "cuda:0"
+
+
+def _softmax(x, axis):
+    e = np.exp(x - x.max(axis=axis, keepdims=True))
+    return e / e.sum(axis=axis, keepdims=True)
+
+
+def T(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(DEV)
+
+
+@pytest.mark.parametrize("B,N", [(1, 64), (2, 500), (2, 24000)])
+def test_sig_t_mean_forward_backward(B, N):
+    from geot_amd.ntm import sig_t_mean, Ins_T_mean
+    rng = np.random.default_rng(0)
+    p = _softmax(rng.standard_normal((B, C, N)) * 2, 1).astype(np.float32)
+    cm = _softmax(rng.standard_normal((C, C)), 1).astype(np.float32)
+    mod = Ins_T_mean(nclasses=C).to(DEV)
+    W = torch.stack([l.weight for l in mod.T_predictor.fc]).detach().cpu().numpy()
+    out = mod(T(p), T(cm))
+    want = np_ntm.sig_t_mean(p, cm, W)
+    assert out.shape == (B * N, C, C)
+    # rows are L1-normalised (entries <= 1): 1e-5 relative to the row scale.  Entries sitting on the
+    # 1e-5 clamp come from a 34-term fp32 dot product of O(1) magnitude (abs error ~1e-7).
+    # A row whose entries are nearly all clamped has a tiny L1 norm, which amplifies that error;
+    # the fp32 reference has the same conditioning, so the bound is absolute on the normalised scale.
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=5e-6)
+    if N > 5000:
+        return
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    (out * T(g)).sum().backward()
+    got = torch.stack([l.weight.grad for l in mod.T_predictor.fc]).cpu().numpy()
+    ref = np_ntm.sig_t_mean_grad_W(p, cm, W, g)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
+
+
+def test_class_transition_matches_oracle():
+    from geot_amd.ntm import class_transition
+    rng = np.random.default_rng(1)
+    B, N = 2, 3000
+    eta = _softmax(rng.standard_normal((B, C, N)) * 3, 1)
+    sigma = 0.5 + rng.random(C)
+    ema = _softmax(rng.standard_normal((C, C)), 1)
+    r = np_ntm.class_transition(eta, sigma, ema)
+    sg = T(sigma, torch.float64).requires_grad_(True)
+    corr, nxt, cT, pT = class_transition(T(eta, torch.float64), sg, T(ema, torch.float64))
+    np.testing.assert_allclose(cT.cpu().numpy(), r["class_T"], rtol=0, atol=0)
+    np.testing.assert_allclose(pT.detach().cpu().numpy(), r["prior_T"], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(corr.detach().cpu().numpy(), r["ema_t_corr"], rtol=1e-12)
+    np.testing.assert_allclose(nxt.cpu().numpy(), r["ema_t_next"], rtol=1e-12)
+    corr.sum().backward()          # sigma is learnable through the prior
+    assert torch.isfinite(sg.grad).all() and sg.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("B,N", [(1, 70), (2, 1000)])
+def test_correct_logits_forward_backward(B, N):
+    from geot_amd.ntm import correct_logits
+    rng = np.random.default_rng(2)
+    logits = (rng.standard_normal((B, C, N)) * 2).astype(np.float32)
+    insT = np_ntm.l1_normalize(rng.random((B * N, C, C)) + 0.01, 2).astype(np.float32)
+    E = np_ntm.l1_normalize(rng.random((C, C)) + 0.01, 1).astype(np.float32)
+    tl, ti, tE = T(logits).requires_grad_(True), T(insT).requires_grad_(True), T(E).requires_grad_(True)
+    out = correct_logits(tl, ti, tE, 0.9)
+    _, want = np_ntm.correct_logits(logits, insT, E, 0.9)
+    # A row whose entries are nearly all clamped has a tiny L1 norm, which amplifies that error;
+    # the fp32 reference has the same conditioning, so the bound is absolute on the normalised scale.
+    np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=5e-6)
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    (out * T(g)).sum().backward()
+    gl, gi, gE = np_ntm.correct_logits_grads(logits, insT, E, 0.9, g)
+    np.testing.assert_allclose(tl.grad.cpu().numpy(), gl, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ti.grad.cpu().numpy(), gi, rtol=1e-4, atol=1e-4 * np.abs(gi).max())
+    np.testing.assert_allclose(tE.grad.cpu().numpy(), gE, rtol=1e-3, atol=1e-3 * np.abs(gE).max())
+
+
+@pytest.mark.parametrize("B,N,k,nlab", [(2, 300, 7, 3), (1, 2000, 32, 17), (2, 1500, 32, 1)])
+def test_threed_space_loss_forward_backward(B, N, k, nlab, oracle):
+    from geot_amd.ntm import threeD_space_loss
+    rng = np.random.default_rng(3)
+    xyz, _ = make_batch(B, N, start_index=40, origin_pts=0)
+    labels = rng.integers(0, nlab, (B, N))
+    insT = np_ntm.l1_normalize(rng.random((B * N, C, C)) + 0.01, 2).astype(np.float32)
+    crit = threeD_space_loss(k=k, sigma=1.0, num_classes=C)
+    pos, tT = T(xyz), T(insT).requires_grad_(True)
+    nbr = crit.neighbours(pos)
+    widx, _ = oracle.knn_sorted(xyz, xyz, k + 1)
+    assert np.array_equal(nbr.cpu().numpy(), widx[:, :, 1:])          # the kNN graph is bit-exact
+    loss = crit(pos, T(labels, torch.int64), tT)
+    want, wgrad, _ = np_ntm.threed_space_loss(xyz, labels, insT, widx[:, :, 1:], 1.0)
+    assert abs(loss.item() - want) <= 2e-5 * abs(want) + 1e-9
+    loss.backward()
+    np.testing.assert_allclose(tT.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
+
+
+def test_ntm_step_composition():
+    """The unlabelled half of one FixMatch+NTM step (train.py:505-571) end to end: shapes, finiteness,
+    gradients reach the T-predictor, sigma and the student logits."""
+    from geot_amd.ntm import Ins_T_mean, class_transition, correct_logits, threeD_space_loss
+    torch.manual_seed(0)
+    B, N = 2, 4000
+    xyz, _ = make_batch(B, N, start_index=3)
+    pos = T(xyz)
+    pred_weak = torch.randn(B, C, N, device=DEV)
+    pred_strong = torch.randn(B, C, N, device=DEV, requires_grad=True)
+    sigma = (0.5 + torch.rand(C, device=DEV)).requires_grad_(True)
+    ema_t = torch.softmax(torch.randn(C, C, device=DEV), 1)
+    cm = torch.softmax(torch.randn(C, C, device=DEV), 1)
+    predictor = Ins_T_mean(nclasses=C).to(DEV)
+    eta = torch.softmax(pred_weak, 1)
+    _, label_u = torch.max(eta, 1)
+    ema_corr, ema_next, _, _ = class_transition(eta, sigma, ema_t)
+    insT = predictor(torch.softmax(pred_strong, 1).detach(), cm)
+    corr = correct_logits(pred_strong, insT, ema_corr, 0.9)
+    loss3d = threeD_space_loss(k=32, sigma=1.0)(pos, label_u, insT) * 0.1
+    (corr.square().mean() + loss3d).backward()
+    assert corr.shape == (B, C, N) and torch.isfinite(corr).all() and torch.isfinite(loss3d)
+    assert all(l.weight.grad is not None and torch.isfinite(l.weight.grad).all() for l in predictor.T_predictor.fc)
+    assert sigma.grad.abs().sum() > 0 and pred_strong.grad.abs().sum() > 0
+    assert ema_next.shape == (C, C)
