@@ -41,4 +41,17 @@ def install(force=False):
     ops.pointnet2_utils = pointnet2_utils
     put("pointnet2_ops", ops)
     put("pointnet2_ops.pointnet2_utils", pointnet2_utils)
+    # `import pytorch_utils as pt_utils` (pointnet2/pointnet2_utils.py:14, via its sys.path append)
+    from .pointnet2 import pytorch_utils
+    put("pytorch_utils", pytorch_utils)
+    # `from openpoints.cpp.pointnet2_batch import pointnet2_cuda` (openpoints/models/layers/*.py:7-8)
+    from .openpoints import cpp as op_cpp
+    from .openpoints.cpp import pointnet2_batch as op_p2b
+    if "openpoints" not in sys.modules:
+        pkg = types.ModuleType("openpoints")
+        pkg.__path__ = []
+        sys.modules["openpoints"] = pkg
+        put("openpoints.cpp", op_cpp)
+        sys.modules["openpoints"].cpp = op_cpp
+    put("openpoints.cpp.pointnet2_batch", op_p2b)
     return ["pointnet2._ext", "pointops_cuda", "pointnet2_batch_cuda", "knn_cuda", "pointnet2_ops"]

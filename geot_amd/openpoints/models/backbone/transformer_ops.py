@@ -1,0 +1,58 @@
+"""The sampling / grouping callers of the configured backbone ``PointTransformer_seg_T``
+(openpoints/models/backbone/transformer.py): fps :266-273, Group :275-303 (FPS + kNN patch
+embedding front end), DGCNN_Propagation.fps_downsample / get_graph_feature :326-364.
+Same signatures and outputs (incl. Group's batch-offset flat index); the dense layers around
+them (Conv2d / GroupNorm / transformer blocks) are stock PyTorch and stay in the caller."""
+import torch
+import torch.nn as nn
+
+from ....pointnet2 import pointnet2_utils as pt_utils
+from ....knn_cuda import KNN
+
+
+def fps(data, number):
+    """data (B,N,3) -> furthest-sampled points (B,number,3) (pointnet2._ext FPS: origin-skip quirk)."""
+    fps_idx = pt_utils.furthest_point_sample(data, number)
+    return pt_utils.gather_operation(data.transpose(1, 2).contiguous(), fps_idx).transpose(1, 2).contiguous()
+
+
+class Group(nn.Module):
+    """FPS + kNN: forward(xyz (B,N,3)) -> (neighborhood (B,G,M,3) centred, center (B,G,3), flat idx (B*G*M,))."""
+
+    def __init__(self, num_group, group_size):
+        super().__init__()
+        self.num_group = num_group
+        self.group_size = group_size
+        self.knn = KNN(k=self.group_size, transpose_mode=True)
+
+    def forward(self, xyz):
+        batch_size, num_points, _ = xyz.shape
+        center = fps(xyz, self.num_group)
+        _, idx = self.knn(xyz, center)
+        assert idx.size(1) == self.num_group and idx.size(2) == self.group_size
+        idx = (idx + torch.arange(0, batch_size, device=xyz.device).view(-1, 1, 1) * num_points).view(-1)
+        neighborhood = xyz.reshape(batch_size * num_points, -1)[idx, :]
+        neighborhood = neighborhood.view(batch_size, self.num_group, self.group_size, 3).contiguous()
+        return neighborhood - center.unsqueeze(2), center, idx
+
+
+def fps_downsample(coor, x, num_group):
+    """coor (B,3,N), x (B,C,N) -> (new_coor (B,3,G), new_x (B,C,G))."""
+    fps_idx = pt_utils.furthest_point_sample(coor.transpose(1, 2).contiguous(), num_group)
+    combined = pt_utils.gather_operation(torch.cat([coor, x], dim=1).contiguous(), fps_idx)
+    return combined[:, :3], combined[:, 3:]
+
+
+def get_graph_feature(knn, coor_q, x_q, coor_k, x_k):
+    """EdgeConv features (B, 2C, Nq, k) = cat(x_k[nbr] - x_q, x_q); knn = KNN(k, transpose_mode=False)."""
+    k = knn.k
+    batch_size, num_dims, num_points_k = x_k.shape
+    num_points_q = x_q.size(2)
+    with torch.no_grad():
+        _, idx = knn(coor_k, coor_q)                          # (B, k, Nq)
+        assert idx.shape[1] == k
+        idx = (idx + torch.arange(0, batch_size, device=x_q.device).view(-1, 1, 1) * num_points_k).view(-1)
+    feature = x_k.transpose(2, 1).contiguous().view(batch_size * num_points_k, -1)[idx, :]
+    feature = feature.view(batch_size, k, num_points_q, num_dims).permute(0, 3, 2, 1).contiguous()
+    x_q = x_q.view(batch_size, num_dims, num_points_q, 1).expand(-1, -1, -1, k)
+    return torch.cat((feature - x_q, x_q), dim=1)

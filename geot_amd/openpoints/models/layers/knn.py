@@ -1,0 +1,65 @@
+"""Mirror of openpoints/models/layers/knn.py:7-112.  The reference materialises the full
+(B,M,N) distance matrix with torch.cdist and runs topk (2.3 GB per 24k-point cloud); here the same
+contract -- (distances, indices), ascending -- comes from the fused HIP kNN, nothing is materialised.
+Ties: smaller index first (topk's tie order is implementation-defined)."""
+import torch
+import torch.nn as nn
+
+from ....knn_cuda import knn_sorted
+
+
+def _knn(query, support, k):
+    d2, idx = knn_sorted(query.contiguous().float(), support.contiguous().float(), k)
+    return torch.sqrt(d2), idx
+
+
+@torch.no_grad()
+def knn_point(k, query, support=None):
+    """query (B,M,3), support (B,N,3) -> (dist (B,M,k), idx (B,M,k) int64)."""
+    if support is None:
+        support = query
+    dist, idx = _knn(query, support, k)
+    return dist, idx.long()
+
+
+class KNN(nn.Module):
+    def __init__(self, neighbors, farthest=False, sorted=True, **kwargs):
+        super().__init__()
+        if farthest:
+            raise NotImplementedError("farthest-neighbour search is not on the GeoT hot path")
+        self.neighbors = neighbors
+        self.farthest = farthest
+        self.sorted = sorted
+
+    @torch.no_grad()
+    def forward(self, query, support=None):
+        """-> (dist (B,M,K), idx (B,M,K) int32)."""
+        if support is None:
+            support = query
+        return _knn(query, support, self.neighbors)
+
+
+class DenseDilated(nn.Module):
+    """Every `dilation`-th neighbour of a (B,npoint,k*dilation) list (optionally a random subset)."""
+
+    def __init__(self, k=9, dilation=1, stochastic=False, epsilon=0.0):
+        super().__init__()
+        self.dilation, self.stochastic, self.epsilon, self.k = dilation, stochastic, epsilon, k
+
+    def forward(self, edge_index):
+        if self.stochastic and torch.rand(1) < self.epsilon and self.training:
+            pick = torch.randperm(self.k * self.dilation)[:self.k]
+            return edge_index[:, :, pick].contiguous()
+        return edge_index[:, :, ::self.dilation].contiguous()
+
+
+class DilatedKNN(nn.Module):
+    def __init__(self, k=9, dilation=1, stochastic=False, epsilon=0.0):
+        super().__init__()
+        self.dilation, self.stochastic, self.epsilon, self.k = dilation, stochastic, epsilon, k
+        self._dilated = DenseDilated(k, dilation, stochastic, epsilon)
+        self.knn = KNN(k * self.dilation)
+
+    def forward(self, query):
+        _, idx = self.knn(query, query)
+        return self._dilated(idx)

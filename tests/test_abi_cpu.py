@@ -77,3 +77,21 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", t, flags=re.M) or "libgeot_oracle" in t:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="reference checkout not present")
+def test_reference_wrapper_files_import_against_our_modules(built):
+    """Drop-in check: after aliases.install() the REFERENCE's own wrapper files import cleanly
+    (their `import pointnet2._ext`, `import pointops_cuda`, `import pytorch_utils` lines resolve to this
+    package).  Import only -- no compute without a GPU; the reference source is read in place, never copied."""
+    code = ("import sys, importlib.util; sys.path.insert(0, %r)\n"
+            "import geot_amd.aliases as a; a.install()\n"
+            "def load(p, n):\n"
+            "    s = importlib.util.spec_from_file_location(n, p); m = importlib.util.module_from_spec(s); s.loader.exec_module(m); return m\n"
+            "u = load('/root/reference/pointnet2/pointnet2_utils.py', 'ref_pointnet2_utils')\n"
+            "p = load('/root/reference/pointops/functions/pointops.py', 'ref_pointops')\n"
+            "s = load('/root/reference/openpoints/models/layers/subsample.py', 'ref_subsample')\n"
+            "assert u._ext.__name__.endswith('pointnet2_ext') and hasattr(p, 'knnquery') and hasattr(s, 'furthest_point_sample')\n"
+            "print('DROPIN_OK')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "DROPIN_OK" in out.stdout, out.stderr[-2000:]

@@ -1,0 +1,173 @@
+"""GPU suite: the openpoints-side wrappers (models/layers, cpp/pointops/functions, transformer hot-path
+callers) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from geot_amd.synth import make_batch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    return (t.to(dtype) if dtype is not None else t).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def test_layers_subsample_group_upsampling(oracle):
+    from geot_amd.openpoints.models import layers as L
+    from geot_amd.openpoints.models.layers.group import QueryAndGroup, KNNGroup, create_grouper
+    xyz_np, _ = make_batch(2, 5000, start_index=2, dup_frac=0.01)
+    xyz = dev(xyz_np)
+    feats = torch.randn(2, 7, 5000, device=DEV, requires_grad=True)
+    idx = L.furthest_point_sample(xyz, 600)
+    assert np.array_equal(host(idx), oracle.fps_dense(xyz_np, 600, 1024, False))   # pointnet2_batch flavour
+    g = L.gather_points(feats, idx)
+    assert torch.equal(g, torch.gather(feats, 2, idx.long().unsqueeze(1).expand(-1, 7, -1)))
+    new_xyz = L.fps(xyz, 600)
+    assert torch.equal(new_xyz, torch.gather(xyz, 1, idx.long().unsqueeze(-1).expand(-1, -1, 3)))
+    gx, gf = QueryAndGroup(0.2, 16, normalize_dp=True)(new_xyz, xyz, feats)
+    bq = oracle.ball_query(host(new_xyz), xyz_np, 0.2, 16)
+    want_x = (oracle.group_points(np.ascontiguousarray(xyz_np.transpose(0, 2, 1)), bq) -
+              host(new_xyz).transpose(0, 2, 1)[..., None]) / 0.2
+    np.testing.assert_allclose(host(gx), want_x, rtol=1e-5, atol=1e-6)
+    assert np.array_equal(host(gf), oracle.group_points(host(feats), bq))
+    assert torch.equal(gf, L.torch_grouping_operation(feats, dev(bq)))
+    gf.sum().backward()
+    cnt = np.zeros((2, 5000), np.float32)
+    for b in range(2):
+        np.add.at(cnt[b], bq[b].reshape(-1), 1.0)
+    np.testing.assert_allclose(host(feats.grad), np.repeat(cnt[:, None], 7, 1), rtol=1e-5)
+    kx, kf = KNNGroup(8)(new_xyz, xyz, feats.detach())
+    ki, _ = oracle.knn_sorted(host(new_xyz), xyz_np, 8)
+    assert np.array_equal(host(kf), oracle.group_points(host(feats), ki))
+    assert isinstance(create_grouper({"NAME": "ballquery", "radius": 0.1, "nsample": 8}), QueryAndGroup)
+    # three_interpolation = three_nn + inverse-distance weights + three_interpolate
+    f2 = torch.randn(2, 11, 600, device=DEV, requires_grad=True)
+    up = L.three_interpolation(xyz, new_xyz, f2)
+    d2, i3 = oracle.three_nn(xyz_np, host(new_xyz))
+    r = 1.0 / (np.sqrt(d2) + 1e-8)
+    w = (r / r.sum(2, keepdims=True)).astype(np.float32)
+    np.testing.assert_allclose(host(up), oracle.three_interpolate(host(f2), i3, w), rtol=1e-4, atol=1e-5)
+    up.sum().backward()
+    np.testing.assert_allclose(host(f2.grad), oracle.three_interpolate_grad(np.ones((2, 11, 5000), np.float32), i3, w, 600),
+                               rtol=1e-3, atol=1e-3)
+
+
+def test_layers_knn_matches_reference_fixture(golden, oracle):
+    from geot_amd.openpoints.models.layers.knn import knn_point, KNN, DilatedKNN
+    g = golden("knn_point_ref.npz")
+    x = dev(g["xyz"])
+    dist, idx = knn_point(int(g["k"]), x, x)
+    assert idx.dtype == torch.int64 and np.array_equal(host(idx), g["idx"])      # the reference's own outputs
+    assert np.abs(host(dist) - g["dist"]).max() < 2e-3
+    d33, i33 = KNN(33)(x[:, :256].contiguous(), x)
+    assert (host(i33) == g["idx_sub33"]).mean() > 0.999
+    dil = DilatedKNN(k=4, dilation=2)(x)
+    wi, _ = oracle.knn_sorted(g["xyz"], g["xyz"], 8)
+    assert np.array_equal(host(dil), wi[:, :, ::2])
+
+
+def test_openpoints_pointops_functions(oracle):
+    from geot_amd.openpoints.cpp.pointops.functions import pointops as P
+    sizes, ms = [900, 1300], [200, 300]
+    clouds = np.concatenate([make_batch(1, n, start_index=60 + i, dup_frac=0.02)[0][0] for i, n in enumerate(sizes)])
+    off, noff = np.cumsum(sizes), np.cumsum(ms)
+    xyz, o, no = dev(clouds), dev(off, torch.int32), dev(noff, torch.int32)
+    idx = P.furthestsampling(xyz, o, no)
+    assert np.array_equal(host(idx), oracle.fps_offset(clouds, off, noff))
+    new_xyz = xyz[idx.long()].contiguous()
+    kidx, kd = P.knnquery(6, xyz, new_xyz, o, no)
+    wi, wd = oracle.knnquery_heap(6, clouds, host(new_xyz), off, noff)
+    assert np.array_equal(host(kidx), wi) and np.allclose(host(kd), np.sqrt(wd), rtol=1e-6)
+    bidx = P.ballquery(0.15, 12, xyz, new_xyz, o, no)
+    assert np.array_equal(host(bidx), oracle.ballquery_offset(0.15, 12, clouds, host(new_xyz), off, noff))
+    feat = torch.randn(clouds.shape[0], 9, device=DEV, requires_grad=True)
+    grp = P.grouping(feat, kidx)
+    assert np.array_equal(host(grp), oracle.grouping_cl(host(feat), wi))
+    go = torch.randn_like(grp)
+    grp.backward(go)
+    np.testing.assert_allclose(host(feat.grad), oracle.grouping_cl_grad(host(go), wi, clouds.shape[0]), rtol=1e-4, atol=1e-5)
+    gx, gfeat = P.querygroup(6, xyz, new_xyz, feat.detach(), o, no)
+    assert np.array_equal(host(gfeat), oracle.grouping_cl(host(feat), wi))
+    np.testing.assert_allclose(host(gx), clouds[wi] - host(new_xyz)[:, None, :], rtol=1e-6, atol=1e-7)
+    cat = P.queryandgroup(6, xyz, new_xyz, feat.detach(), None, o, no)
+    assert cat.shape == (500, 6, 12)
+    # subtraction / aggregation on a self-graph
+    n = clouds.shape[0]
+    sidx, _ = P.knnquery(5, xyz, xyz, o, o)
+    a = torch.randn(n, 8, device=DEV, requires_grad=True)
+    b = torch.randn(n, 8, device=DEV, requires_grad=True)
+    sub = P.subtraction(a, b, sidx)
+    assert np.array_equal(host(sub), oracle.subtraction_cl(host(a), host(b), host(sidx)))
+    go = torch.randn_like(sub)
+    sub.backward(go)
+    w1, w2 = oracle.subtraction_cl_grad(host(sidx), host(go))
+    np.testing.assert_allclose(host(a.grad), w1, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(b.grad), w2, rtol=1e-4, atol=1e-5)
+    pos = torch.randn(n, 5, 8, device=DEV, requires_grad=True)
+    wgt = torch.rand(n, 5, 4, device=DEV, requires_grad=True)
+    x = torch.randn(n, 8, device=DEV, requires_grad=True)
+    agg = P.aggregation(x, pos, wgt, sidx)
+    np.testing.assert_allclose(host(agg), oracle.aggregation_cl(host(x), host(pos), host(wgt), host(sidx)), rtol=1e-5, atol=1e-5)
+    go = torch.randn_like(agg)
+    agg.backward(go)
+    gi, gp, gw = oracle.aggregation_cl_grad(host(x), host(pos), host(wgt), host(sidx), host(go))
+    np.testing.assert_allclose(host(x.grad), gi, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(pos.grad), gp, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(wgt.grad), gw, rtol=1e-4, atol=1e-4)
+    # interpolation: fused op == torch gather form
+    f = torch.randn(500, 10, device=DEV, requires_grad=True)
+    i2 = P.interpolation2(new_xyz, xyz, f, no, o)
+    np.testing.assert_allclose(host(i2), host(P.interpolation(new_xyz, xyz, f.detach(), no, o)), rtol=1e-5, atol=1e-6)
+    i2.sum().backward()
+    assert torch.isfinite(f.grad).all()
+
+
+def test_transformer_group_and_graph_feature(oracle):
+    from geot_amd.openpoints.models.backbone.transformer_ops import Group, fps_downsample, get_graph_feature
+    from geot_amd.knn_cuda import KNN
+    xyz_np, _ = make_batch(2, 24000, start_index=1, dup_frac=0.01)
+    xyz = dev(xyz_np)
+    neigh, center, idx = Group(num_group=512, group_size=32)(xyz)
+    fi = oracle.fps_dense(xyz_np, 512, 512, True)                       # pointnet2._ext FPS (origin-skip)
+    wc = np.take_along_axis(xyz_np, fi[..., None].astype(np.int64).repeat(3, -1), 1)
+    ki, _ = oracle.knn_sorted(wc, xyz_np, 32)
+    flat = (ki.astype(np.int64) + np.arange(2)[:, None, None] * 24000).reshape(-1)
+    assert np.array_equal(host(center), wc) and np.array_equal(host(idx), flat)
+    np.testing.assert_allclose(host(neigh), xyz_np.reshape(-1, 3)[flat].reshape(2, 512, 32, 3) - wc[:, :, None, :], rtol=0, atol=0)
+    # DGCNN propagation glue at the dgcnn_pro_2 shapes (512 -> 4096, k = 4)
+    coor_q = dev(np.ascontiguousarray(xyz_np[:, :4096].transpose(0, 2, 1)))
+    coor_k = dev(np.ascontiguousarray(wc.transpose(0, 2, 1)))
+    x_k = torch.randn(2, 6, 512, device=DEV)
+    x_q = torch.randn(2, 6, 4096, device=DEV)
+    feat = get_graph_feature(KNN(k=4, transpose_mode=False), coor_q, x_q, coor_k, x_k)
+    assert feat.shape == (2, 12, 4096, 4)
+    gi, _ = oracle.knn_sorted(xyz_np[:, :4096], wc, 4)                  # (B, Nq, k)
+    xk = host(x_k)
+    want = np.stack([xk[b][:, gi[b]] for b in range(2)])                # (B, C, Nq, k)
+    np.testing.assert_allclose(host(feat[:, :6]), want - host(x_q)[..., None], rtol=1e-6, atol=1e-6)
+    nc, nx = fps_downsample(coor_q, x_q, 256)
+    sel = oracle.fps_dense(xyz_np[:, :4096], 256, 512, True)
+    assert np.array_equal(host(nc), np.take_along_axis(host(coor_q), sel[:, None, :].astype(np.int64).repeat(3, 1), 2))
+
+
+def test_alias_installer_resolves_reference_import_names():
+    import importlib
+    import geot_amd.aliases as aliases
+    names = aliases.install()
+    for n in names + ["pointnet2_ops.pointnet2_utils", "pytorch_utils", "openpoints.cpp.pointnet2_batch"]:
+        importlib.import_module(n)
+    import pointnet2._ext as ext
+    import pointops_cuda
+    from knn_cuda import KNN
+    from openpoints.cpp.pointnet2_batch import pointnet2_cuda
+    x = torch.rand(1, 300, 3, device=DEV)
+    assert ext.furthest_point_sampling(x, 16).shape == (1, 16)
+    assert hasattr(pointops_cuda, "knnquery_cuda") and hasattr(pointnet2_cuda, "three_nn_wrapper")
+    assert KNN(3, transpose_mode=True)(x, x[:, :5].contiguous())[1].shape == (1, 5, 3)
