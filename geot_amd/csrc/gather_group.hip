@@ -243,6 +243,65 @@ __global__ __launch_bounds__(GG_THREADS) void aggregation_cl_grad_kernel(
     }
 }
 
+// ---- atomic-friendly backward: accumulate channels-last, then transpose ------------------------
+// In the reference layout (B,C,N) a scatter-add "grad[b,c,idx] += g" puts the 64 lanes of a wave on
+// 64 different rows; MI355X executes float atomics at the memory side, one request per touched
+// 64-byte segment, so that shape runs ~17x below the atomic rate (MI355X_MICROARCH.md "Global float
+// atomics").  Here the wave's lanes are 64 consecutive CHANNELS of one target point in a (B,M,C)
+// workspace -- each atomic wave-instruction is one contiguous 256-B row segment -- and a tiled
+// transpose-add folds the workspace into the caller's (B,C,M) gradient afterwards.
+constexpr int SC_TILE = 64;
+
+// src (B,C,L) channels-first; item e (< L) scatters src[b,:,e]*w[e,t] to ws[b, tgt[e,t], :], t < NT.
+template <int NT, bool WEIGHTED>
+__global__ __launch_bounds__(256) void scatter_rows_cl_kernel(
+    int c, int L, int M, const float *__restrict__ src, const int *__restrict__ tgt,
+    const float *__restrict__ w, float *__restrict__ ws)
+{
+    __shared__ float tile[SC_TILE][SC_TILE + 1];
+    const int b = blockIdx.z, c0 = blockIdx.y * SC_TILE, e0 = blockIdx.x * SC_TILE;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < SC_TILE / 4; ++r) {
+        int cc = r * 4 + ty;
+        tile[cc][tx] = (c0 + cc < c && e0 + tx < L) ? src[((size_t)b * c + c0 + cc) * L + e0 + tx] : 0.f;
+    }
+    __syncthreads();
+    const int lane = tx, wave = ty;
+    if (c0 + lane >= c) return;
+    for (int q = wave; q < SC_TILE; q += 4) {
+        int e = e0 + q;
+        if (e >= L) break;
+        float g = tile[lane][q];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int k = tgt[((size_t)b * L + e) * NT + t];
+            float v = WEIGHTED ? g * w[((size_t)b * L + e) * NT + t] : g;
+            atomicAdd(ws + ((size_t)b * M + k) * c + c0 + lane, v);
+        }
+    }
+}
+
+// dst[b,c,k] += ws[b,k,c]
+__global__ __launch_bounds__(256) void transpose_add_kernel(int c, int M, const float *__restrict__ ws,
+                                                            float *__restrict__ dst)
+{
+    __shared__ float tile[SC_TILE][SC_TILE + 1];
+    const int b = blockIdx.z, c0 = blockIdx.y * SC_TILE, k0 = blockIdx.x * SC_TILE;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < SC_TILE / 4; ++r) {
+        int kk = r * 4 + ty;
+        tile[kk][tx] = (k0 + kk < M && c0 + tx < c) ? ws[((size_t)b * M + k0 + kk) * c + c0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SC_TILE / 4; ++r) {
+        int cc = r * 4 + ty;
+        if (c0 + cc < c && k0 + tx < M) dst[((size_t)b * c + c0 + cc) * M + k0 + tx] += tile[tx][cc];
+    }
+}
+
 static inline dim3 grid3(long long inner, int c, int b)
 {
     return dim3((unsigned)((inner + GG_THREADS - 1) / GG_THREADS), (unsigned)((c + GG_CCHUNK - 1) / GG_CCHUNK),
@@ -332,6 +391,39 @@ GEOT_EXPORT int geot_three_interpolate_grad(int b, int c, int n, int m, const fl
     GEOT_CHECK_DIMS3(b, c);
     hipLaunchKernelGGL(three_interpolate_grad_kernel, grid3(n, c, b), dim3(GG_THREADS), 0,
                        (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out,
+                                               const int *idx, const float *weight, float *grad_points,
+                                               float *workspace, void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || m < 0 || !workspace) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || n == 0 || m == 0) return hipSuccess;
+    if (b > 65535) return hipErrorInvalidValue;
+    dim3 g1((n + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
+    hipLaunchKernelGGL((scatter_rows_cl_kernel<3, true>), g1, dim3(256), 0, (hipStream_t)stream, c, n, m,
+                       grad_out, idx, weight, workspace);
+    dim3 g2((m + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
+    hipLaunchKernelGGL(transpose_add_kernel, g2, dim3(256), 0, (hipStream_t)stream, c, m, workspace,
+                       grad_points);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_group_points_grad_ws(int b, int c, int n, int npoints, int nsample,
+                                          const float *grad_out, const int *idx, float *grad_points,
+                                          float *workspace, void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || npoints < 0 || nsample < 0 || !workspace) return hipErrorInvalidValue;
+    long long npns = (long long)npoints * nsample;
+    if (b == 0 || c == 0 || npns == 0 || n == 0) return hipSuccess;
+    if (npns > 0x7fffffffLL || b > 65535) return hipErrorInvalidValue;
+    dim3 g1((unsigned)((npns + SC_TILE - 1) / SC_TILE), (c + SC_TILE - 1) / SC_TILE, b);
+    hipLaunchKernelGGL((scatter_rows_cl_kernel<1, false>), g1, dim3(256), 0, (hipStream_t)stream, c,
+                       (int)npns, n, grad_out, idx, nullptr, workspace);
+    dim3 g2((n + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
+    hipLaunchKernelGGL(transpose_add_kernel, g2, dim3(256), 0, (hipStream_t)stream, c, n, workspace,
+                       grad_points);
     return hipGetLastError();
 }
 

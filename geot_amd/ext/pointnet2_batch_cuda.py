@@ -7,6 +7,8 @@ reference (which only checks ball_query and exit(-1)s) every call validates its
 tensors and raises RuntimeError.  Outputs may be uninitialised
 (torch.cuda.FloatTensor(...)); they are written in full.
 """
+import torch
+
 from ._common import f32, i32, same_device, need, call, ptr
 
 
@@ -59,7 +61,12 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     dev = same_device(grad_out, idx, grad_points)
     need(grad_out.numel() == b * c * npoints * nsample and idx.numel() == b * npoints * nsample
          and grad_points.numel() == b * c * n, "group_grad size mismatch")
-    call("geot_group_points_grad", dev, b, c, n, npoints, nsample, ptr(grad_out), ptr(idx), ptr(grad_points))
+    if c < 16:
+        call("geot_group_points_grad", dev, b, c, n, npoints, nsample, ptr(grad_out), ptr(idx), ptr(grad_points))
+        return 1
+    ws = torch.zeros((b, n, c), dtype=torch.float32, device=dev)       # channels-last accumulator
+    call("geot_group_points_grad_ws", dev, b, c, n, npoints, nsample, ptr(grad_out), ptr(idx), ptr(grad_points),
+         ptr(ws))
     return 1
 
 
@@ -84,4 +91,9 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     dev = same_device(grad_out, idx, weight, grad_points)
     need(grad_out.numel() == b * c * n and idx.numel() == b * n * 3 and weight.numel() == b * n * 3
          and grad_points.numel() == b * c * m, "three_interpolate_grad size mismatch")
-    call("geot_three_interpolate_grad", dev, b, c, n, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(grad_points))
+    if c < 16:
+        call("geot_three_interpolate_grad", dev, b, c, n, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(grad_points))
+        return
+    ws = torch.zeros((b, m, c), dtype=torch.float32, device=dev)       # channels-last accumulator
+    call("geot_three_interpolate_grad_ws", dev, b, c, n, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(grad_points),
+         ptr(ws))

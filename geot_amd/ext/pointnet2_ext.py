@@ -73,7 +73,12 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     b, c, n = grad_out.shape
     need(tuple(idx.shape) == (b, n, 3) and tuple(weight.shape) == (b, n, 3), "idx/weight must be (B, n, 3)")
     out = torch.zeros((b, c, int(m)), dtype=torch.float32, device=dev)
-    call("geot_three_interpolate_grad", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out))
+    if c < 16:   # too few channels to fill a wave's 256-B atomic row: direct scatter
+        call("geot_three_interpolate_grad", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out))
+        return out
+    ws = torch.zeros((b, int(m), c), dtype=torch.float32, device=dev)   # channels-last accumulator
+    call("geot_three_interpolate_grad_ws", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out),
+         ptr(ws))
     return out
 
 
@@ -105,5 +110,10 @@ def group_points_grad(grad_out, idx, n):
     b, c, npoints, nsample = grad_out.shape
     need(tuple(idx.shape) == (b, npoints, nsample), "idx shape mismatch")
     out = torch.zeros((b, c, int(n)), dtype=torch.float32, device=dev)
-    call("geot_group_points_grad", dev, b, c, int(n), npoints, nsample, ptr(grad_out), ptr(idx), ptr(out))
+    if c < 16:
+        call("geot_group_points_grad", dev, b, c, int(n), npoints, nsample, ptr(grad_out), ptr(idx), ptr(out))
+        return out
+    ws = torch.zeros((b, int(n), c), dtype=torch.float32, device=dev)   # channels-last accumulator
+    call("geot_group_points_grad_ws", dev, b, c, int(n), npoints, nsample, ptr(grad_out), ptr(idx), ptr(out),
+         ptr(ws))
     return out

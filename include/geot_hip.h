@@ -82,6 +82,16 @@ int geot_group_points(int b, int c, int n, int npoints, int nsample, const float
 int geot_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                            const int *idx, float *grad_points, void *stream);
 
+/* Same result as geot_group_points_grad / geot_three_interpolate_grad (up to fp32 summation order),
+ * several times faster: accumulates in a channels-last workspace where every atomic wave-instruction
+ * is one contiguous 256-B row, then transposes into grad_points.  workspace: b*n*c (group) or b*m*c
+ * (interpolate) floats, ZERO-FILLED by the caller. */
+int geot_group_points_grad_ws(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                              const int *idx, float *grad_points, float *workspace, void *stream);
+int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                   const float *weight, float *grad_points, float *workspace,
+                                   void *stream);
+
 /* ---- three_nn / three_interpolate ------------------------------------------
  * pointnet2/_ext_src/src/interpolate_gpu.cu:64-71, 106-115, 148-157
  * openpoints/cpp/pointnet2_batch/src/interpolate_gpu.cu (…_launcher_fast)
