@@ -48,9 +48,12 @@ class _SigTMeanFn(Function):
         raw = torch.empty_like(g)
         call("geot_ntm_sig_t_mean_grad_raw", p.device, b, n, c, ptr(p), ptr(W), ptr(cm), ptr(g), ptr(raw))
         # weight gradient = the Linear layers' own backward GEMMs (tiny: 289 x BN x 34)
-        flat = p.permute(0, 2, 1).reshape(b * n, c)                       # (BN, C)
-        gwa = torch.einsum("iko,ij->koj", raw, flat)                       # (C, C, C)
-        gwb = raw.sum(0).unsqueeze(2) * cm.unsqueeze(1)                    # (C, C, C): [kk][o][j] = S[kk][o]*cm[kk][j]
+        # One GEMM gives both halves: [p_i | 1] as the right operand -> columns 0..C-1 are the p-part,
+        # column C is sum_i raw (which multiplies the constant cm[kk] inputs).
+        aug = torch.cat([p.permute(0, 2, 1).reshape(b * n, c), torch.ones((b * n, 1), device=p.device)], dim=1)
+        G = raw.view(b * n, c * c).t() @ aug                               # (C*C, C+1)
+        gwa = G[:, :c].reshape(c, c, c)
+        gwb = G[:, c].reshape(c, c, 1) * cm.unsqueeze(1)                   # [kk][o][j] = S[kk][o] * cm[kk][j]
         return None, None, torch.cat([gwa, gwb], dim=2)
 
 

@@ -33,12 +33,35 @@ def knn(x, src, k, transpose=False):
     return idx.long(), dists.view(b, n, k)
 
 
+# The backbone samples the SAME cloud three times (8192 / 4096 / 2048 targets,
+# openpoints/models/backbone/transformer.py:1037-1039).  FPS is greedy from a fixed start and the
+# tie rule depends only on n, so the k-sample result is the first k entries of any longer one
+# (SURVEY.md App. A.1 "prefix property"): keep the longest result for the last tensor seen and
+# slice it.  The entry holds a reference to the tensor (its storage cannot be recycled) and its
+# version counter (in-place edits invalidate it).
+_FPS_CACHE = {"x": None, "version": -1, "idx": None}
+
+
+def fps_indices(x, k):
+    """x (B,n,3) contiguous -> int64 global indices (B,k) into x.view(-1,3)."""
+    b, n, _ = x.shape
+    c = _FPS_CACHE
+    if c["x"] is x and c["version"] == x._version and c["idx"] is not None and c["idx"].shape[1] >= k:
+        return c["idx"][:, :k]
+    flat = x.reshape(-1, 3)
+    idx = furthestsampling(flat, _uniform_offsets(b, n, x.device), _uniform_offsets(b, k, x.device)).long()
+    idx = idx.view(b, k)
+    c["x"], c["version"], c["idx"] = x, x._version, idx
+    return idx
+
+
 def fps(x, k):
     """x (B,n,3) -> sampled points (B,k,3); first pick = point 0 of each cloud."""
     b, n, _ = x.shape
-    x = x.reshape(-1, 3)
-    idx = furthestsampling(x, _uniform_offsets(b, n, x.device), _uniform_offsets(b, k, x.device)).long()
-    return x[idx].view(b, k, 3)
+    if not x.is_contiguous():
+        x = x.contiguous()
+    idx = fps_indices(x, k)
+    return x.reshape(-1, 3)[idx.reshape(-1)].view(b, k, 3)
 
 
 def fps_weight(x, k, weight=None):

@@ -1,0 +1,94 @@
+"""Synthetic hot-path workloads at the BASELINE shapes, shared by bench.py and the tests.
+
+``backbone_hotpath_step`` replays, with the reference's shapes and call order, every sampling /
+grouping / interpolation op that one forward+backward of the configured backbone
+``PointTransformer_seg_T`` issues per batch -- and nothing else:
+the dense layers between them (mini-PointNet encoder, 12 transformer blocks, SharedMLP / Conv2d /
+GroupNorm stacks) are stock PyTorch in the reference and out of scope here, so they are replaced by
+nothing (features are random tensors of the right shape).  ``ntm_step`` does the same for the
+unlabelled half of a FixMatch+NTM step (train.py:505-571).
+"""
+import torch
+
+from .pointnet2 import pointnet2_utils as pu
+from .pointops.functions import pointops
+from .knn_cuda import KNN
+from .openpoints.models.backbone.transformer_ops import Group, get_graph_feature
+from . import ntm as ntm_mod
+
+TRANS_DIM, GROUPS, GROUP_SIZE = 384, 512, 32   # cfgs/tooth_semi/transformer_finetune_fixmatch_ntm.yaml:6-15
+
+
+def _fp(unknown, known, feats):
+    """PointnetFPModule front end (pointnet2_modules.py:619-626): three_nn -> weights -> interpolate."""
+    dist, idx = pu.three_nn(unknown, known)
+    r = 1.0 / (dist + 1e-8)
+    return pu.three_interpolate(feats, idx, r / torch.sum(r, dim=2, keepdim=True))
+
+
+class BackboneHotPath(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.group = Group(GROUPS, GROUP_SIZE)
+        self.knn4 = KNN(k=4, transpose_mode=False)
+
+    def forward(self, pts, tokens):
+        """pts (B,N,3); tokens (B,384,512) stands for the transformer output at the 512 group centres.
+        Returns the (B,384,N) propagated features (sum of the interpolation outputs feeds backward)."""
+        B, N, _ = pts.shape
+        neighborhood, center, _ = self.group(pts)                                  # FPS 512 + kNN 32 + gather
+        c8192, c4096 = pointops.fps(pts, 8192), pointops.fps(pts, 4096)            # one FPS run (prefix reuse)
+        pointops.fps(pts, 2048)                                                    # computed, unused (reference)
+        f_l2 = _fp(c4096, center, tokens)                                          # propogation_2: 512 -> 4096
+        f_l1 = _fp(c8192, center, tokens)                                          # propogation_1: 512 -> 8192
+        ct, c4t, c8t = (center.transpose(1, 2).contiguous(), c4096.transpose(1, 2).contiguous(),
+                        c8192.transpose(1, 2).contiguous())
+        g2a = get_graph_feature(self.knn4, c4t, f_l2, ct, tokens)                  # dgcnn_pro_2: 512 -> 4096
+        g2b = get_graph_feature(self.knn4, c4t, f_l2, c4t, f_l2)                   #              4096 -> 4096
+        g1a = get_graph_feature(self.knn4, c8t, f_l1, c4t, f_l2)                   # dgcnn_pro_1: 4096 -> 8192
+        g1b = get_graph_feature(self.knn4, c8t, f_l1, c8t, f_l1)                   #              8192 -> 8192
+        f_l1 = f_l1 + g1a[:, :TRANS_DIM].amax(-1) + g1b[:, :TRANS_DIM].amax(-1)    # stand-in for conv+max
+        f_l2 = f_l2 + g2a[:, :TRANS_DIM].amax(-1) + g2b[:, :TRANS_DIM].amax(-1)
+        f_l0 = _fp(pts, c8192, f_l1)                                               # propogation_0: 8192 -> N
+        return f_l0, f_l2, neighborhood
+
+
+def backbone_hotpath_step(model, pts, tokens):
+    """forward + backward of the hot-path ops; returns the scalar that was differentiated."""
+    tokens = tokens.detach().requires_grad_(True)
+    pts = pts.clone()  # a new batch every step: the FPS prefix cache only helps WITHIN a forward
+    f_l0, f_l2, neighborhood = model(pts, tokens)
+    loss = f_l0.square().mean() + f_l2.mean() + neighborhood.mean()
+    loss.backward()
+    return loss.detach()
+
+
+class NtmHotPath(torch.nn.Module):
+    """Unlabelled half of a FixMatch+NTM step at threed_k=32, sigma=1, lambda=0.9 (yaml:78-96)."""
+
+    def __init__(self, num_classes=17, k=32):
+        super().__init__()
+        self.predictor = ntm_mod.Ins_T_mean(nclasses=num_classes)
+        self.loss3d = ntm_mod.threeD_space_loss(k=k, sigma=1.0, num_classes=num_classes)
+        self.sigma = torch.nn.Parameter(torch.ones(num_classes))
+        self.register_buffer("ema_t", torch.eye(num_classes) * 0.9 + 0.1 / num_classes)
+        self.register_buffer("cm", torch.eye(num_classes) * 0.9 + 0.1 / num_classes)
+
+    def forward(self, raw_pos, pred_weak, pred_strong):
+        eta = torch.softmax(pred_weak.detach(), dim=1)
+        _, label_u = torch.max(eta, dim=1)
+        ema_corr, ema_next, _, _ = ntm_mod.class_transition(eta, self.sigma, self.ema_t)
+        ins_t = self.predictor(torch.softmax(pred_strong, dim=1).detach(), self.cm)
+        corr = ntm_mod.correct_logits(pred_strong, ins_t, ema_corr, 0.9)
+        loss3d = self.loss3d(raw_pos, label_u, ins_t) * 0.1
+        self.ema_t.copy_(ema_next.detach())
+        return corr, loss3d
+
+
+def ntm_step(model, raw_pos, pred_weak, pred_strong):
+    pred_strong = pred_strong.detach().requires_grad_(True)
+    corr, loss3d = model(raw_pos, pred_weak, pred_strong)
+    loss = corr.square().mean() + loss3d
+    model.zero_grad(set_to_none=True)
+    loss.backward()
+    return loss.detach()

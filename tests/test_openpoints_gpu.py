@@ -171,3 +171,16 @@ def test_alias_installer_resolves_reference_import_names():
     assert ext.furthest_point_sampling(x, 16).shape == (1, 16)
     assert hasattr(pointops_cuda, "knnquery_cuda") and hasattr(pointnet2_cuda, "three_nn_wrapper")
     assert KNN(3, transpose_mode=True)(x, x[:, :5].contiguous())[1].shape == (1, 5, 3)
+
+
+def test_composite_workloads_run_and_are_finite():
+    """The bench / timing workloads (geot_amd/workloads.py) at a reduced size."""
+    from geot_amd import workloads as wl
+    xyz_np, _ = make_batch(2, 9000, start_index=5)
+    xyz = dev(xyz_np)
+    hot = wl.BackboneHotPath().to(DEV)
+    loss = wl.backbone_hotpath_step(hot, xyz, torch.randn(2, 384, 512, device=DEV))
+    assert torch.isfinite(loss)
+    nt = wl.NtmHotPath().to(DEV)
+    l2 = wl.ntm_step(nt, xyz, torch.randn(2, 17, 9000, device=DEV), torch.randn(2, 17, 9000, device=DEV))
+    assert torch.isfinite(l2) and torch.isfinite(nt.ema_t).all()

@@ -79,6 +79,30 @@ def main():
     rows.append(("knn_sorted 8192x8192 k=4", t, "%.1f Gpair/s" % (B * 8192 * 8192 / t / 1e6)))
     t = timeit(lambda: knn_sorted(xyz, xyz, 33), iters=3, warm=1)
     rows.append(("knn_sorted 24000x24000 k=33", t, "%.1f Gpair/s" % (B * N * N / t / 1e6)))
+    from geot_amd import workloads as wl
+    from geot_amd import ntm as ntm_mod
+    tokens = torch.randn(B, 384, 512, device=DEV)
+    hot = wl.BackboneHotPath().to(DEV)
+    t = timeit(lambda: wl.backbone_hotpath_step(hot, xyz, tokens), iters=5, warm=2)
+    rows.append(("backbone hot-path ops fwd+bwd B=%d" % B, t, "%.1f clouds/s" % (B / t * 1e3)))
+    C = 17
+    pw, ps = torch.randn(B, C, N, device=DEV), torch.randn(B, C, N, device=DEV)
+    nt = wl.NtmHotPath().to(DEV)
+    t = timeit(lambda: wl.ntm_step(nt, xyz, pw, ps), iters=5, warm=2)
+    rows.append(("NTM step (sig_t_mean+correct+3D loss) fwd+bwd B=%d" % B, t, "%.1f clouds/s" % (B / t * 1e3)))
+    cm = torch.softmax(torch.randn(C, C, device=DEV), 1)
+    prob = torch.softmax(ps, 1)
+    with torch.no_grad():
+        t = timeit(lambda: nt.predictor(prob, cm))
+        rows.append(("sig_t_mean fwd", t, "%.1f GB/s (write)" % (B * N * C * C * 4 / t / 1e6)))
+        insT = nt.predictor(prob, cm)
+        t = timeit(lambda: ntm_mod.correct_logits(ps, insT, cm, 0.9))
+        rows.append(("correct_logits fwd", t, "%.1f GB/s (read)" % (B * N * C * C * 4 / t / 1e6)))
+        crit = ntm_mod.threeD_space_loss(k=32)
+        nbr = crit.neighbours(xyz)
+        lab = torch.randint(0, 2, (B, N), device=DEV)
+        t = timeit(lambda: crit(xyz, lab, insT, nbr))
+        rows.append(("threeD_space_loss fwd (2 labels)", t, "%.1f GB/s (rows)" % (B * N * 33 * C * C * 4 / t / 1e6)))
     for name, ms, extra in rows:
         print("%-42s %10.3f ms   %s" % (name, ms, extra), flush=True)
 

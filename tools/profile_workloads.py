@@ -1,0 +1,25 @@
+"""Run the composite workloads a few times (for rocprofv3 --kernel-trace --stats)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from geot_amd.synth import make_batch  # noqa: E402
+from geot_amd import workloads as wl  # noqa: E402
+
+B = int(os.environ.get("B", "8"))
+which = os.environ.get("WHICH", "backbone")
+xyz = torch.from_numpy(make_batch(B, 24000)[0]).cuda()
+if which == "backbone":
+    hot = wl.BackboneHotPath().cuda()
+    tokens = torch.randn(B, 384, 512, device="cuda")
+    for _ in range(4):
+        wl.backbone_hotpath_step(hot, xyz, tokens)
+else:
+    nt = wl.NtmHotPath().cuda()
+    pw, ps = torch.randn(B, 17, 24000, device="cuda"), torch.randn(B, 17, 24000, device="cuda")
+    for _ in range(4):
+        wl.ntm_step(nt, xyz, pw, ps)
+torch.cuda.synchronize()
+print("done")
