@@ -214,6 +214,17 @@ struct FpsEntry { // one wave's published candidate
     uint32_t key;
     float x, y, z;
 };
+struct FpsEntry2 { // multi-commit variant: sortable (hi:lo) = (bits(max)+1 : ~key), runner-up bound v2
+    uint32_t lo, hi; // little-endian: the first 8 bytes read as one u64 give (hi << 32) | lo
+    float x, y;
+    float z;
+    int v2;
+    uint32_t pad[2];
+};
+#ifndef GEOT_FP_TMAX
+#define GEOT_FP_TMAX 6
+#endif
+constexpr int FP_TMAX = GEOT_FP_TMAX; // samples committed per round at most (<= 8: the 8 x 8 conflict matrix is one wave)
 
 // v[lane `lane`] = value, both wave-uniform.  v_writelane_b32 allows only one SGPR besides
 // M0 on gfx9, so the lane select goes through M0.
@@ -278,7 +289,7 @@ __device__ __forceinline__ uint32_t morton12(uint32_t cx, uint32_t cy, uint32_t 
 
 // NT threads (NW = NT/64 waves), PPT points per lane (<= CAP register slots; one slot per lane
 // for the box test, so PPT <= 32 < 64).
-template <int NT, int PPT, bool SKIP>
+template <int NT, int PPT, bool SKIP, int TMAX>
 __global__ __launch_bounds__(NT) void fps_pruned_kernel(
     const float *__restrict__ xyz, const int *__restrict__ offset,
     const int *__restrict__ new_offset, int n_dense, int m_dense, float *__restrict__ temp,
@@ -418,6 +429,205 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
         set_lane(smax, __builtin_amdgcn_readfirstlane(wave_max_i32(__float_as_int(t))), i);
     }
 
+    if constexpr (TMAX > 1) {
+    // =====================================================================================
+    // Multi-commit rounds.  FPS is sequential, but consecutive winners are usually far apart:
+    // once c1 is chosen, the runner-up wave candidate c2 IS the next sample whenever
+    //   (A) c1 does not lower c2's min-distance:  sqdist3(c2, c1) >= temp[c2]   (same fp32 expression
+    //       the update evaluates, so this is exact), and
+    //   (B) nothing left in c1's wave can beat c2:  V2(wave(c1)) < temp[c2], where V2 is an upper bound
+    //       of the wave's second-largest min-distance (values only decrease, so a stale V2 stays valid);
+    // every other wave's candidate already ranks below c2 in the (value desc, key asc) order.  By
+    // induction the first Tn candidates of that order are the next Tn samples as long as every pair
+    // (s < t) passes (A) and (B).  Each round therefore sorts the <= 16 wave candidates (rank by
+    // counting), checks the 8 x 8 conflict matrix with one lane per pair, commits the longest
+    // conflict-free prefix and applies all its updates before the next barrier.  Any doubt (ties, NaNs,
+    // a stale bound) only shortens the prefix; the result is bit-identical to one-at-a-time selection.
+    // =====================================================================================
+    __shared__ FpsEntry2 exch2[2][16];
+    __shared__ FpsEntry2 srt[TMAX];
+    __shared__ int res_tn;
+    int cM = -1, cslot = -1, cV2 = -1;
+    uint32_t ckey = KEY_NONE;
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    bool cand_ok = false;
+    float qx[TMAX], qy[TMAX], qz[TMAX];
+    qx[0] = P[0]; qy[0] = P[1]; qz[0] = P[2];
+#pragma unroll
+    for (int u = 1; u < TMAX; ++u) { qx[u] = 0.f; qy[u] = 0.f; qz[u] = 0.f; }
+    int Tn = 1, par = 0;
+#ifdef GEOT_LAB_STAMPS
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, t0, t1, rounds = 0;
+#define GEOT_STAMP(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
+#else
+#define GEOT_STAMP(acc) do {} while (0)
+#endif
+    for (int j = 1; j < m;) {
+#ifdef GEOT_LAB_STAMPS
+        t0 = __builtin_readcyclecounter();
+        ++rounds;
+#endif
+        // -- apply the Tn samples committed last round
+        bool redo = !cand_ok;
+#pragma unroll
+        for (int u = 0; u < TMAX; ++u) {
+            if (u < Tn) {
+                float dx = fmaxf(fmaxf(bx0 - qx[u], qx[u] - bx1), 0.f);
+                float dy = fmaxf(fmaxf(by0 - qy[u], qy[u] - by1), 0.f);
+                float dz = fmaxf(fmaxf(bz0 - qz[u], qz[u] - bz1), 0.f);
+                float lb2 = dx * dx + dy * dy + dz * dz;
+                unsigned long long mask = __ballot(!(lb2 > __int_as_float(smax) * 1.00001f));
+#ifdef GEOT_LAB_STATS
+                if (lane == 0) { atomicAdd(&geot_fps_dbg[0], (unsigned long long)__popcll(mask)); atomicAdd(&geot_fps_dbg[1], 1ull); }
+#endif
+                redo = redo || (cslot >= 0 && ((mask >> cslot) & 1ull));
+                while (mask) {
+                    int s = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    float d = sqdist3(X.get(s), Y.get(s), Z.get(s), qx[u], qy[u], qz[u]);
+                    float d2 = fmin_raw(d, D.get(s));
+                    D.set(s, d2);
+                    set_lane(smax, __builtin_amdgcn_readfirstlane(wave_max_i32_fast(__float_as_int(d2))), s);
+                }
+            }
+        }
+        GEOT_STAMP(tA);
+        // -- this wave's candidate + runner-up bound: recomputed only when its slot was touched
+        if (redo) {
+            cand_ok = true;
+            cM = __builtin_amdgcn_readfirstlane(wave_max_i32_fast(smax));
+            ckey = KEY_NONE;
+            cslot = -1;
+            cV2 = -1;
+            int owner = 0;
+            if (cM >= 0) {
+                unsigned long long cm = __ballot(smax == cM);
+                while (cm) {
+                    int s = __builtin_ctzll(cm);
+                    cm &= cm - 1;
+                    bool hit = __float_as_int(D.get(s)) == cM;
+                    uint32_t key = hit ? fps_key(perm[s * NT + tid], L) : KEY_NONE;
+                    uint32_t kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_fast(key));
+                    if (kmin < ckey) {
+                        ckey = kmin;
+                        cslot = s;
+                        owner = __builtin_ctzll(__ballot(key == kmin));
+                        cx = read_lane(X.get(s), owner);
+                        cy = read_lane(Y.get(s), owner);
+                        cz = read_lane(Z.get(s), owner);
+                    }
+                }
+            }
+            if (ckey == KEY_NONE) cM = -1;
+            else {
+                // runner-up bound: best of the other slots' maxima and of the candidate slot without its owner
+                int oth = __builtin_amdgcn_readfirstlane(wave_max_i32_fast(lane == cslot ? (int)0x80000000 : smax));
+                int ins = __builtin_amdgcn_readfirstlane(
+                    wave_max_i32_fast(lane == owner ? (int)0x80000000 : __float_as_int(D.get(cslot))));
+                cV2 = max(max(oth, ins), -1);
+            }
+        }
+        GEOT_STAMP(tB);
+        if (lane == 0) {
+            FpsEntry2 *mine = &exch2[par][wave];
+            mine->hi = (uint32_t)(cM + 1); mine->lo = ~ckey;
+            mine->x = cx; mine->y = cy; mine->z = cz; mine->v2 = cV2;
+        }
+        __syncthreads();
+        GEOT_STAMP(tC);
+        // -- wave 0 alone ranks the wave candidates and builds the conflict matrix (12 waves doing this
+        //    redundantly would just fight over the VALU issue slots); everybody else waits at a second
+        //    barrier and then reads the committed samples.
+        const FpsEntry2 *ex = exch2[par];
+        par ^= 1;
+        if (wave == 0) {
+            FpsEntry2 e = ex[lane & 15];
+            if ((lane & 15) >= NW) { e.hi = 0u; e.lo = 0u; }
+            const unsigned long long mine64 = ((unsigned long long)e.hi << 32) | e.lo;
+            int rank = 0; // (hi:lo) descending; rank = number of strictly better candidates
+#pragma unroll
+            for (int w0 = 0; w0 < NW; w0 += 4) { // wave-uniform (broadcast) LDS reads, four in flight
+                unsigned long long oth[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    oth[w] = w0 + w < NW ? *reinterpret_cast<const unsigned long long *>(&ex[w0 + w]) : 0ull;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) rank += oth[w] > mine64 ? 1 : 0;
+            }
+            const int nvalid = __popcll(__ballot(lane < NW && e.hi != 0u));
+            if (lane < NW && e.hi != 0u && rank < TMAX) srt[rank] = e;
+            // conflict matrix: lane p = (t = p / 8, s = p % 8), s < t
+            const int ct = lane >> 3, cs = lane & 7;
+            bool conflict = false;
+            if (cs < ct && ct < nvalid && ct < TMAX) {
+                const FpsEntry2 a = srt[cs], b = srt[ct];
+                const int Mt = (int)b.hi - 1;
+                const float d = sqdist3(b.x, b.y, b.z, a.x, a.y, a.z); // point first, sample second: as the update
+                conflict = !(__float_as_int(d) >= Mt && d >= 0.f) || !(a.v2 < Mt);
+            }
+            const unsigned long long cmask = __ballot(conflict);
+            int tn = 1;
+            if (nvalid > 0) {
+                int lim = min(min(nvalid, TMAX), m - j);
+                // first row t >= 1 with any conflict bit: fold every byte of the matrix onto its bit 0
+                unsigned long long rows = cmask;
+                rows |= rows >> 4; rows |= rows >> 2; rows |= rows >> 1;
+                rows &= 0x0101010101010100ull;
+                int first_bad = rows ? (__builtin_ctzll(rows) >> 3) : 8;
+                tn = min(lim, first_bad);
+                if (lane < tn) out[j + lane] = base + (int)fps_key_decode(~srt[lane].lo, L);
+            } else { // nobody has a candidate (e.g. every point origin-skipped): the sample is index 0
+                if (lane == 0) {
+                    out[j] = base;
+                    srt[0].x = P[0]; srt[0].y = P[1]; srt[0].z = P[2];
+                }
+            }
+            if (lane == 0) res_tn = tn;
+        }
+        __syncthreads();
+        {
+            FpsEntry2 c[TMAX];
+#pragma unroll
+            for (int u = 0; u < TMAX; ++u) c[u] = srt[u]; // wave-uniform, batched (stale beyond Tn: unused)
+            Tn = __builtin_amdgcn_readfirstlane(res_tn);
+#pragma unroll
+            for (int u = 0; u < TMAX; ++u) {
+                if (u < Tn) { qx[u] = uniform(c[u].x); qy[u] = uniform(c[u].y); qz[u] = uniform(c[u].z); }
+            }
+        }
+#ifdef GEOT_LAB_STATS
+        if (tid == 0) { atomicAdd(&geot_fps_dbg[2], (unsigned long long)Tn); atomicAdd(&geot_fps_dbg[3], 1ull); }
+#endif
+        j += Tn;
+        GEOT_STAMP(tD);
+    }
+    // The reference's temp buffer ends as "min-distance to samples 0..m-2" (the last pick is never
+    // applied).  The final round may have committed several samples: apply all but the last one.
+#pragma unroll
+    for (int u = 0; u < TMAX; ++u) {
+        if (u < Tn - 1) {
+            float dx = fmaxf(fmaxf(bx0 - qx[u], qx[u] - bx1), 0.f);
+            float dy = fmaxf(fmaxf(by0 - qy[u], qy[u] - by1), 0.f);
+            float dz = fmaxf(fmaxf(bz0 - qz[u], qz[u] - bz1), 0.f);
+            float lb2 = dx * dx + dy * dy + dz * dz;
+            unsigned long long mask = __ballot(!(lb2 > __int_as_float(smax) * 1.00001f));
+            while (mask) {
+                int s = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                float d = sqdist3(X.get(s), Y.get(s), Z.get(s), qx[u], qy[u], qz[u]);
+                D.set(s, fmin_raw(d, D.get(s)));
+            }
+        }
+    }
+#ifdef GEOT_LAB_STAMPS
+    if (lane == 0) {
+        atomicAdd(&geot_fps_dbg[0], tA); atomicAdd(&geot_fps_dbg[1], tB); atomicAdd(&geot_fps_dbg[2], tC);
+        atomicAdd(&geot_fps_dbg[3], tD); atomicAdd(&geot_fps_dbg[4], tE); atomicAdd(&geot_fps_dbg[5], (unsigned long long)(m - 1));
+        if (tid == 0) atomicAdd(&geot_fps_dbg[6], rounds);
+    }
+#endif
+#undef GEOT_STAMP
+    } else {
     // This wave's candidate, wave-uniform, carried across rounds.  Min-distances only ever
     // decrease, so it stays the wave's arg-max until its own slot (cslot) is updated.
     int cM = -1, cslot = -1;
@@ -527,6 +737,7 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
         atomicAdd(&geot_fps_dbg[3], tD); atomicAdd(&geot_fps_dbg[4], tE); atomicAdd(&geot_fps_dbg[5], (unsigned long long)(m - 1));
     }
 #endif
+    }
 #pragma unroll 1
     for (int i = 0; i < PPT; ++i) {
         int pos = i * NT + tid;
@@ -535,13 +746,13 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
     }
 }
 
-template <bool SKIP>
+template <bool SKIP, int TMAX>
 static hipError_t fps_pruned_launch(int b, int n_max, const float *xyz, const int *offset,
                                     const int *new_offset, int n_dense, int m_dense, float *temp,
                                     int *idxs, int L, hipStream_t s)
 {
 #define GEOT_FPP_CASE(NT, P)                                                                        \
-    hipLaunchKernelGGL((fps_pruned_kernel<NT, P, SKIP>), dim3(b), dim3(NT), 0, s, xyz, offset,      \
+    hipLaunchKernelGGL((fps_pruned_kernel<NT, P, SKIP, TMAX>), dim3(b), dim3(NT), 0, s, xyz, offset, \
                        new_offset, n_dense, m_dense, temp, idxs, L)
     if (n_max <= 8 * 512) GEOT_FPP_CASE(512, 8);
     else if (n_max <= 16 * 512) GEOT_FPP_CASE(512, 16);
@@ -551,12 +762,13 @@ static hipError_t fps_pruned_launch(int b, int n_max, const float *xyz, const in
     return hipGetLastError();
 }
 
-// GEOT_FPS_IMPL=basic forces the unpruned kernels (A/B testing); default = pruned when it applies.
-static bool fps_use_pruned(int n_max, bool weighted)
+// GEOT_FPS_IMPL (read per call so tests can A/B the kernels): "basic" = unpruned, "single" = pruned,
+// one sample per round; default = pruned with multi-commit rounds.  Returns 0 / 1 / 2.
+static int fps_impl(int n_max, bool weighted)
 {
-    const char *e = getenv("GEOT_FPS_IMPL"); // read per call so tests can A/B both kernels
-    bool pruned = !(e && e[0] == 'b');
-    return pruned && !weighted && n_max >= 1024 && n_max <= FP_MAX_N;
+    const char *e = getenv("GEOT_FPS_IMPL");
+    if ((e && e[0] == 'b') || weighted || n_max < 1024 || n_max > FP_MAX_N) return 0;
+    return (e && e[0] == 's') ? 1 : 2;
 }
 
 template <bool SKIP, bool WEIGHTED>
@@ -612,10 +824,16 @@ GEOT_EXPORT int geot_furthest_point_sampling(int b, int n, int m, const float *x
     if (b == 0 || n == 0 || m == 0) return hipSuccess;
     int L = geot::ref_log2_block(n, block_cap);
     hipStream_t s = (hipStream_t)stream;
-    if (geot::fps_use_pruned(n, false)) {
+    const int impl = geot::fps_impl(n, false);
+    if (impl == 2) {
         if (skip_origin)
-            return geot::fps_pruned_launch<true>(b, n, xyz, nullptr, nullptr, n, m, temp, idxs, L, s);
-        return geot::fps_pruned_launch<false>(b, n, xyz, nullptr, nullptr, n, m, temp, idxs, L, s);
+            return geot::fps_pruned_launch<true, geot::FP_TMAX>(b, n, xyz, nullptr, nullptr, n, m, temp, idxs, L, s);
+        return geot::fps_pruned_launch<false, geot::FP_TMAX>(b, n, xyz, nullptr, nullptr, n, m, temp, idxs, L, s);
+    }
+    if (impl == 1) {
+        if (skip_origin)
+            return geot::fps_pruned_launch<true, 1>(b, n, xyz, nullptr, nullptr, n, m, temp, idxs, L, s);
+        return geot::fps_pruned_launch<false, 1>(b, n, xyz, nullptr, nullptr, n, m, temp, idxs, L, s);
     }
     if (skip_origin)
         return geot::fps_launch<true, false>(b, n, xyz, nullptr, nullptr, n, m, nullptr, temp, idxs, L, s);
@@ -630,8 +848,11 @@ GEOT_EXPORT int geot_furthestsampling_offset(int b, int n_max, const float *xyz,
     if (b == 0 || n_max == 0) return hipSuccess;
     int L = geot::ref_log2_block(n_max, 1024);
     hipStream_t s = (hipStream_t)stream;
-    if (geot::fps_use_pruned(n_max, weights != nullptr))
-        return geot::fps_pruned_launch<false>(b, n_max, xyz, offset, new_offset, 0, 0, tmp, idx, L, s);
+    const int impl = geot::fps_impl(n_max, weights != nullptr);
+    if (impl == 2)
+        return geot::fps_pruned_launch<false, geot::FP_TMAX>(b, n_max, xyz, offset, new_offset, 0, 0, tmp, idx, L, s);
+    if (impl == 1)
+        return geot::fps_pruned_launch<false, 1>(b, n_max, xyz, offset, new_offset, 0, 0, tmp, idx, L, s);
     if (weights)
         return geot::fps_launch<false, true>(b, n_max, xyz, offset, new_offset, 0, 0, weights, tmp, idx, L, s);
     return geot::fps_launch<false, false>(b, n_max, xyz, offset, new_offset, 0, 0, nullptr, tmp, idx, L, s);

@@ -15,6 +15,8 @@ VARIANTS = {
     "base": [],
     "stats": ["-DGEOT_LAB_STATS"],
     "stamps": ["-DGEOT_LAB_STAMPS"],
+    "t4": ["-DGEOT_FP_TMAX=4"],
+    "t6": ["-DGEOT_FP_TMAX=6"],
 }
 for extra in sys.argv[2:]:
     if "=" in extra:
@@ -41,8 +43,10 @@ def run():
     from geot_amd.synth import make_batch
     tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
     ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
-    xyz_np, _ = make_batch(1, 24000)
+    NPTS = int(os.environ.get("NPTS", "24000"))
+    xyz_np, _ = make_batch(1, NPTS)
     xyz = torch.from_numpy(xyz_np).cuda()
+    print("N =", NPTS)
     for name in VARIANTS:
         path = os.path.join(LAB, "libfps_%s.so" % name)
         if not os.path.exists(path):
@@ -54,8 +58,8 @@ def run():
             out = torch.zeros(1, m, dtype=torch.int32, device="cuda")
 
             def go():
-                tmp = torch.full((1, 24000), 1e10, device="cuda")
-                err = f(1, 24000, m, xyz.data_ptr(), tmp.data_ptr(), out.data_ptr(), 1024, 0,
+                tmp = torch.full((1, NPTS), 1e10, device="cuda")
+                err = f(1, NPTS, m, xyz.data_ptr(), tmp.data_ptr(), out.data_ptr(), 1024, 0,
                         torch.cuda.current_stream().cuda_stream)
                 assert err == 0, err
             go()
@@ -66,10 +70,13 @@ def run():
                 go()
                 torch.cuda.synchronize()
                 lib.geot_lab_read_stats(st, 1)
-                wr = st[5]  # wave-rounds
-                print("  stamps m=%d (cycles per wave-round): test %.0f  update %.0f  cand %.0f  publish+barrier %.0f  "
-                      "reduce %.0f  total %.0f" % (m, st[0] / wr, st[1] / wr, st[2] / wr, st[3] / wr, st[4] / wr,
-                                                   sum(st[:5]) / wr), flush=True)
+                nw = st[5] / (m - 1)          # waves
+                rounds = max(st[6], 1)
+                wr = nw * rounds              # wave-rounds
+                print("  stamps m=%d: %.2f samples/round; cycles per wave-round: apply %.0f  search %.0f  "
+                      "publish+barrier %.0f  resolve %.0f  total %.0f  => %.0f cycles/sample"
+                      % (m, (m - 1) / rounds, st[0] / wr, st[1] / wr, st[2] / wr, st[3] / wr, sum(st[:4]) / wr,
+                         sum(st[:4]) / wr * rounds / (m - 1)), flush=True)
                 continue
             if name == "stats":
                 st = (ctypes.c_ulonglong * 8)()
@@ -78,8 +85,8 @@ def run():
                 torch.cuda.synchronize()
                 lib.geot_lab_read_stats(st, 1)
                 waves_rounds = st[1]
-                print("  stats m=%d: active slots/wave/round %.3f; waves with work %.3f; cand slots/wave/round %.3f"
-                      % (m, st[0] / waves_rounds, st[2] / waves_rounds, st[3] / waves_rounds), flush=True)
+                print("  stats m=%d: active slots per wave-test %.3f; samples committed per round %.2f"
+                      % (m, st[0] / waves_rounds, st[2] / max(st[3], 1)), flush=True)
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
