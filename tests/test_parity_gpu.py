@@ -40,9 +40,10 @@ def ext():
     return E
 
 
-@pytest.fixture(params=["pruned", "basic"])
+@pytest.fixture(params=["multi", "single", "basic"])
 def fps_impl(request, monkeypatch):
-    """Both FPS kernels (bucket-pruned default, unpruned GEOT_FPS_IMPL=basic) must be bit-exact."""
+    """All three FPS kernels must be bit-exact: bucket-pruned with multi-commit rounds (default),
+    bucket-pruned one sample per round (GEOT_FPS_IMPL=single), unpruned (GEOT_FPS_IMPL=basic)."""
     monkeypatch.setenv("GEOT_FPS_IMPL", request.param)
     return request.param
 

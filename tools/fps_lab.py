@@ -13,10 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAB = os.path.join(ROOT, "tools", "_lab")
 VARIANTS = {
     "base": [],
-    "stats": ["-DGEOT_LAB_STATS"],
+    "stats": ["-DGEOT_LAB_STATS", "-DGEOT_FP_TMAX=8"],
     "stamps": ["-DGEOT_LAB_STAMPS"],
-    "t4": ["-DGEOT_FP_TMAX=4"],
-    "t6": ["-DGEOT_FP_TMAX=6"],
+    "t8": ["-DGEOT_FP_TMAX=8"],
 }
 for extra in sys.argv[2:]:
     if "=" in extra:
@@ -85,8 +84,10 @@ def run():
                 torch.cuda.synchronize()
                 lib.geot_lab_read_stats(st, 1)
                 waves_rounds = st[1]
-                print("  stats m=%d: active slots per wave-test %.3f; samples committed per round %.2f"
-                      % (m, st[0] / waves_rounds, st[2] / max(st[3], 1)), flush=True)
+                print("  stats m=%d: active slots per wave-test %.3f; samples committed per round %.2f; "
+                      "prefix cut by (A) distance %.2f / (B) runner-up bound %.2f of rounds"
+                      % (m, st[0] / waves_rounds, st[2] / max(st[3], 1), st[4] / max(st[3], 1), st[5] / max(st[3], 1)),
+                      flush=True)
                 continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
