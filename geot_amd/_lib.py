@@ -44,6 +44,8 @@ PROTOTYPES = {
 PROTOTYPES.update({
     "geot_group_points_grad_ws": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_three_interpolate_grad_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_graph_feature": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
+    "geot_graph_feature_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean_grad_raw": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_correct": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _c_void_p],

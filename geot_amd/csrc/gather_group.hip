@@ -255,7 +255,7 @@ constexpr int SC_TILE = 64;
 // src (B,C,L) channels-first; item e (< L) scatters src[b,:,e]*w[e,t] to ws[b, tgt[e,t], :], t < NT.
 template <int NT, bool WEIGHTED>
 __global__ __launch_bounds__(256) void scatter_rows_cl_kernel(
-    int c, int L, int M, const float *__restrict__ src, const int *__restrict__ tgt,
+    int c, int L, int M, const float *__restrict__ src, size_t src_bstride, const int *__restrict__ tgt,
     const float *__restrict__ w, float *__restrict__ ws)
 {
     __shared__ float tile[SC_TILE][SC_TILE + 1];
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void scatter_rows_cl_kernel(
 #pragma unroll
     for (int r = 0; r < SC_TILE / 4; ++r) {
         int cc = r * 4 + ty;
-        tile[cc][tx] = (c0 + cc < c && e0 + tx < L) ? src[((size_t)b * c + c0 + cc) * L + e0 + tx] : 0.f;
+        tile[cc][tx] = (c0 + cc < c && e0 + tx < L) ? src[(size_t)b * src_bstride + (size_t)(c0 + cc) * L + e0 + tx] : 0.f;
     }
     __syncthreads();
     const int lane = tx, wave = ty;
@@ -300,6 +300,81 @@ __global__ __launch_bounds__(256) void transpose_add_kernel(int c, int M, const 
         int cc = r * 4 + ty;
         if (c0 + cc < c && k0 + tx < M) dst[((size_t)b * c + c0 + cc) * M + k0 + tx] += tile[tx][cc];
     }
+}
+
+// ---- EdgeConv graph feature (DGCNN_Propagation.get_graph_feature, transformer.py:343-364) -------
+// out[b, c,     i, j] = x_k[b, c, idx[b,i,j]] - x_q[b, c, i]        (c < C)
+// out[b, C + c, i, j] = x_q[b, c, i]
+// One pass instead of the reference's transpose + fancy-index gather + permute + expand + cat chain.
+// Lanes walk i (the contiguous dimension of x_q and, with j, of out); indices are loaded once per
+// lane and reused over GG_CCHUNK channels.  KMAX neighbours are held in registers.
+constexpr int GF_KMAX = 32;
+
+typedef float gf_f4 __attribute__((ext_vector_type(4)));
+
+template <int K4>   // K4 > 0: k == 4*K4 and rows are float4-aligned; 0: generic k
+__global__ __launch_bounds__(GG_THREADS) void graph_feature_kernel(
+    int c, int nq, int nk, int k, const float *__restrict__ x_q, const float *__restrict__ x_k,
+    const int *__restrict__ idx, float *__restrict__ out)
+{
+    const int bi = blockIdx.z, c0 = blockIdx.y * GG_CCHUNK;
+    const int i = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (i >= nq) return;
+    const int *I = idx + ((size_t)bi * nq + i) * k;
+    const int cend = min(c0 + GG_CCHUNK, c);
+    if constexpr (K4 > 0) {
+        int4 nb[K4];
+#pragma unroll
+        for (int q = 0; q < K4; ++q) nb[q] = reinterpret_cast<const int4 *>(I)[q];
+        for (int l = c0; l < cend; ++l) {
+            const float q = x_q[((size_t)bi * c + l) * nq + i];
+            const float *K = x_k + ((size_t)bi * c + l) * nk;
+            gf_f4 *o1 = reinterpret_cast<gf_f4 *>(out + (((size_t)bi * 2 * c + l) * nq + i) * k);
+            gf_f4 *o2 = reinterpret_cast<gf_f4 *>(out + (((size_t)bi * 2 * c + c + l) * nq + i) * k);
+#pragma unroll
+            for (int t = 0; t < K4; ++t) {
+                gf_f4 v = {K[nb[t].x] - q, K[nb[t].y] - q, K[nb[t].z] - q, K[nb[t].w] - q};
+                gf_f4 w = {q, q, q, q};
+                __builtin_nontemporal_store(v, o1 + t);
+                __builtin_nontemporal_store(w, o2 + t);
+            }
+        }
+    } else {
+        for (int l = c0; l < cend; ++l) {
+            const float q = x_q[((size_t)bi * c + l) * nq + i];
+            const float *K = x_k + ((size_t)bi * c + l) * nk;
+            float *o1 = out + (((size_t)bi * 2 * c + l) * nq + i) * k;
+            float *o2 = out + (((size_t)bi * 2 * c + c + l) * nq + i) * k;
+            for (int j = 0; j < k; ++j) {
+                o1[j] = K[I[j]] - q;
+                o2[j] = q;
+            }
+        }
+    }
+}
+
+// grad_xq[b,c,i] += sum_j (g[b,C+c,i,j] - g[b,c,i,j]); the x_k part is a scatter of g[:, :C] (below)
+template <int K4>
+__global__ __launch_bounds__(GG_THREADS) void graph_feature_grad_q_kernel(
+    int c, int nq, int k, const float *__restrict__ grad_out, float *__restrict__ grad_xq)
+{
+    const int bi = blockIdx.z, l = blockIdx.y;
+    const int i = blockIdx.x * GG_THREADS + threadIdx.x;
+    if (i >= nq) return;
+    const float *g1 = grad_out + (((size_t)bi * 2 * c + l) * nq + i) * k;
+    const float *g2 = grad_out + (((size_t)bi * 2 * c + c + l) * nq + i) * k;
+    float acc = 0.f;
+    if constexpr (K4 > 0) {
+#pragma unroll
+        for (int t = 0; t < K4; ++t) {   // same left-to-right order as the generic loop
+            const gf_f4 a = __builtin_nontemporal_load(reinterpret_cast<const gf_f4 *>(g1) + t);
+            const gf_f4 d = __builtin_nontemporal_load(reinterpret_cast<const gf_f4 *>(g2) + t);
+            acc += d.x - a.x; acc += d.y - a.y; acc += d.z - a.z; acc += d.w - a.w;
+        }
+    } else {
+        for (int j = 0; j < k; ++j) acc += g2[j] - g1[j];
+    }
+    grad_xq[((size_t)bi * c + l) * nq + i] += acc;
 }
 
 static inline dim3 grid3(long long inner, int c, int b)
@@ -403,7 +478,7 @@ GEOT_EXPORT int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const
     if (b > 65535) return hipErrorInvalidValue;
     dim3 g1((n + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
     hipLaunchKernelGGL((scatter_rows_cl_kernel<3, true>), g1, dim3(256), 0, (hipStream_t)stream, c, n, m,
-                       grad_out, idx, weight, workspace);
+                       grad_out, (size_t)c * n, idx, weight, workspace);
     dim3 g2((m + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
     hipLaunchKernelGGL(transpose_add_kernel, g2, dim3(256), 0, (hipStream_t)stream, c, m, workspace,
                        grad_points);
@@ -420,10 +495,50 @@ GEOT_EXPORT int geot_group_points_grad_ws(int b, int c, int n, int npoints, int 
     if (npns > 0x7fffffffLL || b > 65535) return hipErrorInvalidValue;
     dim3 g1((unsigned)((npns + SC_TILE - 1) / SC_TILE), (c + SC_TILE - 1) / SC_TILE, b);
     hipLaunchKernelGGL((scatter_rows_cl_kernel<1, false>), g1, dim3(256), 0, (hipStream_t)stream, c,
-                       (int)npns, n, grad_out, idx, nullptr, workspace);
+                       (int)npns, n, grad_out, (size_t)c * npns, idx, nullptr, workspace);
     dim3 g2((n + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
     hipLaunchKernelGGL(transpose_add_kernel, g2, dim3(256), 0, (hipStream_t)stream, c, n, workspace,
                        grad_points);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_graph_feature(int b, int c, int nq, int nk, int k, const float *x_q, const float *x_k,
+                                   const int *idx, float *out, void *stream)
+{
+    if (b < 0 || c < 0 || nq < 0 || nk < 0 || k < 0) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || nq == 0 || k == 0) return hipSuccess;
+    GEOT_CHECK_DIMS3(b, c);
+    const bool al = ((uintptr_t)idx % 16 == 0) && ((uintptr_t)out % 16 == 0);
+#define GF_LAUNCH(K4) hipLaunchKernelGGL(graph_feature_kernel<K4>, grid3(nq, c, b), dim3(GG_THREADS), 0, \
+                                         (hipStream_t)stream, c, nq, nk, k, x_q, x_k, idx, out)
+    if (al && k == 4) GF_LAUNCH(1);
+    else if (al && k == 8) GF_LAUNCH(2);
+    else if (al && k == 16) GF_LAUNCH(4);
+    else GF_LAUNCH(0);
+#undef GF_LAUNCH
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_graph_feature_grad(int b, int c, int nq, int nk, int k, const float *grad_out,
+                                        const int *idx, float *grad_xq, float *grad_xk, float *workspace,
+                                        void *stream)
+{
+    if (b < 0 || c < 0 || nq < 0 || nk < 0 || k < 0 || !workspace) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || nq == 0 || k == 0) return hipSuccess;
+    if (b > 65535 || c > 65535 || (long long)nq * k > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 gq((nq + GG_THREADS - 1) / GG_THREADS, c, b);
+    const bool al = (uintptr_t)grad_out % 16 == 0;
+    if (al && k == 4) hipLaunchKernelGGL(graph_feature_grad_q_kernel<1>, gq, dim3(GG_THREADS), 0, s, c, nq, k, grad_out, grad_xq);
+    else if (al && k == 8) hipLaunchKernelGGL(graph_feature_grad_q_kernel<2>, gq, dim3(GG_THREADS), 0, s, c, nq, k, grad_out, grad_xq);
+    else if (al && k == 16) hipLaunchKernelGGL(graph_feature_grad_q_kernel<4>, gq, dim3(GG_THREADS), 0, s, c, nq, k, grad_out, grad_xq);
+    else hipLaunchKernelGGL(graph_feature_grad_q_kernel<0>, gq, dim3(GG_THREADS), 0, s, c, nq, k, grad_out, grad_xq);
+    const int L = nq * k;
+    dim3 g1((L + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
+    hipLaunchKernelGGL((scatter_rows_cl_kernel<1, false>), g1, dim3(256), 0, s, c, L, nk, grad_out,
+                       (size_t)2 * c * L, idx, nullptr, workspace);
+    dim3 g2((nk + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
+    hipLaunchKernelGGL(transpose_add_kernel, g2, dim3(256), 0, s, c, nk, workspace, grad_xk);
     return hipGetLastError();
 }
 

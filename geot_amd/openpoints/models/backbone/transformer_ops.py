@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from ....pointnet2 import pointnet2_utils as pt_utils
 from ....knn_cuda import KNN
+from ....ext._common import f32, i32, same_device, need, call, ptr
 
 
 def fps(data, number):
@@ -43,8 +44,51 @@ def fps_downsample(coor, x, num_group):
     return combined[:, :3], combined[:, 3:]
 
 
+class _GraphFeatureFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_q, x_k, idx):
+        x_q, x_k = f32(x_q.contiguous(), "x_q", 3), f32(x_k.contiguous(), "x_k", 3)
+        idx = i32(idx.contiguous(), "idx", 3)
+        dev = same_device(x_q, x_k, idx)
+        b, c, nq = x_q.shape
+        nk, k = x_k.shape[2], idx.shape[2]
+        need(x_k.shape[:2] == (b, c) and tuple(idx.shape[:2]) == (b, nq), "graph feature shape mismatch")
+        out = torch.empty((b, 2 * c, nq, k), dtype=torch.float32, device=dev)
+        call("geot_graph_feature", dev, b, c, nq, nk, k, ptr(x_q), ptr(x_k), ptr(idx), ptr(out))
+        ctx.save_for_backward(idx)
+        ctx.dims = (b, c, nq, nk, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, = ctx.saved_tensors
+        b, c, nq, nk, k = ctx.dims
+        g = grad_out.contiguous()
+        gq = torch.zeros((b, c, nq), dtype=torch.float32, device=g.device)
+        gk = torch.zeros((b, c, nk), dtype=torch.float32, device=g.device)
+        ws = torch.zeros((b, nk, c), dtype=torch.float32, device=g.device)
+        call("geot_graph_feature_grad", g.device, b, c, nq, nk, k, ptr(g), ptr(idx), ptr(gq), ptr(gk), ptr(ws))
+        return gq, gk, None
+
+
+def graph_feature(x_q, x_k, idx):
+    """x_q (B,C,Nq), x_k (B,C,Nk), idx (B,Nq,k) int32 -> (B,2C,Nq,k) = cat(x_k[idx] - x_q, x_q), fused."""
+    return _GraphFeatureFn.apply(x_q, x_k, idx)
+
+
 def get_graph_feature(knn, coor_q, x_q, coor_k, x_k):
-    """EdgeConv features (B, 2C, Nq, k) = cat(x_k[nbr] - x_q, x_q); knn = KNN(k, transpose_mode=False)."""
+    """EdgeConv features (B, 2C, Nq, k) = cat(x_k[nbr] - x_q, x_q); knn = KNN(k, transpose_mode=False).
+    Same result as the reference's gather/permute/expand/cat chain, from one fused kernel (and the kNN
+    indices are consumed as (B,Nq,k) int32 directly instead of being transposed to (B,k,Nq) int64)."""
+    from ....knn_cuda import knn_sorted
+    with torch.no_grad():
+        _, idx = knn_sorted(coor_q.transpose(1, 2).contiguous().float(), coor_k.transpose(1, 2).contiguous().float(),
+                            knn.k)
+    return graph_feature(x_q, x_k, idx)
+
+
+def get_graph_feature_unfused(knn, coor_q, x_q, coor_k, x_k):
+    """The reference's own op sequence (kept for A/B tests)."""
     k = knn.k
     batch_size, num_dims, num_points_k = x_k.shape
     num_points_q = x_q.size(2)

@@ -92,6 +92,16 @@ int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad
                                    const float *weight, float *grad_points, float *workspace,
                                    void *stream);
 
+/* EdgeConv graph feature = DGCNN_Propagation.get_graph_feature
+ * (openpoints/models/backbone/transformer.py:343-364: transpose + fancy-index gather + permute +
+ * expand + cat), in one pass:  x_q (b,c,nq), x_k (b,c,nk), idx (b,nq,k) int32 neighbours in x_k ->
+ * out (b,2c,nq,k) = cat(x_k[idx] - x_q, x_q).  _grad accumulates into grad_xq (b,c,nq) and grad_xk
+ * (b,c,nk); workspace = b*nk*c zero-filled floats. */
+int geot_graph_feature(int b, int c, int nq, int nk, int k, const float *x_q, const float *x_k,
+                       const int *idx, float *out, void *stream);
+int geot_graph_feature_grad(int b, int c, int nq, int nk, int k, const float *grad_out, const int *idx,
+                            float *grad_xq, float *grad_xk, float *workspace, void *stream);
+
 /* ---- three_nn / three_interpolate ------------------------------------------
  * pointnet2/_ext_src/src/interpolate_gpu.cu:64-71, 106-115, 148-157
  * openpoints/cpp/pointnet2_batch/src/interpolate_gpu.cu (…_launcher_fast)

@@ -152,6 +152,32 @@ def test_transformer_group_and_graph_feature(oracle):
     xk = host(x_k)
     want = np.stack([xk[b][:, gi[b]] for b in range(2)])                # (B, C, Nq, k)
     np.testing.assert_allclose(host(feat[:, :6]), want - host(x_q)[..., None], rtol=1e-6, atol=1e-6)
+    # fused kernel == the reference's own op chain, forward bit for bit and backward to rounding
+    from geot_amd.openpoints.models.backbone.transformer_ops import get_graph_feature_unfused
+    knn4 = KNN(k=4, transpose_mode=False)
+    xq1, xk1 = x_q.clone().requires_grad_(True), x_k.clone().requires_grad_(True)
+    xq2, xk2 = x_q.clone().requires_grad_(True), x_k.clone().requires_grad_(True)
+    f1 = get_graph_feature(knn4, coor_q, xq1, coor_k, xk1)
+    f2 = get_graph_feature_unfused(knn4, coor_q, xq2, coor_k, xk2)
+    assert torch.equal(f1, f2)
+    g = torch.randn_like(f1)
+    f1.backward(g); f2.backward(g)
+    np.testing.assert_allclose(host(xq1.grad), host(xq2.grad), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(xk1.grad), host(xk2.grad), rtol=1e-5, atol=1e-4)   # ~32 atomics per row
+    for c_, nq_, nk_, k_ in ((1, 1, 1, 1), (19, 333, 77, 5), (9, 70, 300, 20)):          # ragged shapes
+        a = torch.randn(2, c_, nq_, device=DEV, requires_grad=True)
+        bk = torch.randn(2, c_, nk_, device=DEV, requires_grad=True)
+        ii = torch.randint(0, nk_, (2, nq_, k_), device=DEV, dtype=torch.int32)
+        from geot_amd.openpoints.models.backbone.transformer_ops import graph_feature
+        o = graph_feature(a, bk, ii)
+        nb = torch.gather(bk.unsqueeze(2).expand(-1, -1, nq_, -1), 3, ii.long().unsqueeze(1).expand(-1, c_, -1, -1))
+        ref = torch.cat((nb - a.unsqueeze(-1), a.unsqueeze(-1).expand(-1, -1, -1, k_)), 1)
+        assert torch.equal(o, ref)
+        go = torch.randn_like(o)
+        ga, gb = torch.autograd.grad(o, (a, bk), go)
+        ra, rb = torch.autograd.grad(ref, (a, bk), go)
+        np.testing.assert_allclose(host(ga), host(ra), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(host(gb), host(rb), rtol=1e-5, atol=1e-4)
     nc, nx = fps_downsample(coor_q, x_q, 256)
     sel = oracle.fps_dense(xyz_np[:, :4096], 256, 512, True)
     assert np.array_equal(host(nc), np.take_along_axis(host(coor_q), sel[:, None, :].astype(np.int64).repeat(3, 1), 2))
