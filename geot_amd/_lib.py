@@ -52,6 +52,9 @@ PROTOTYPES.update({
     "geot_ntm_correct_grad": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_threed_loss": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_threed_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_feature_loss": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_feature_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P,
+                                   _c_void_p],
 })
 # entry points that do not follow the "(..., stream) -> hipError_t" shape
 PLAIN = {

@@ -199,9 +199,11 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
 // forward : per_point[i] = sum_j w_ij |T_i - T_j|^2 / (sum_j w_ij + 1e-3)
 // backward: grad_T[i] += coef_i * sum_j w_ij (T_i - T_j);  grad_T[j] -= coef_i * w_ij (T_i - T_j)
 //           with coef_i = 2 * gscale / (sum_j w_ij + 1e-3)     (gscale = upstream grad / (B*N))
-template <int CC, bool BACKWARD>
+// SIGNED (feature_space_loss, insT_loss.py:9-58): w_ij = (label_i == label_j ? +1 : -1) * exp(..) over
+// pd-dimensional features and the per-point sum is NOT normalised (the caller divides by B*N*k).
+template <int CC, bool BACKWARD, bool SIGNED>
 __global__ __launch_bounds__(256) void threed_loss_kernel(
-    int total_pts, int n, int k, float inv2s2, float gscale, const float *__restrict__ pos,
+    int total_pts, int n, int k, int pd, float inv2s2, float gscale, const float *__restrict__ pos,
     const int *__restrict__ labels, const float *__restrict__ T, const int *__restrict__ nbr,
     float *__restrict__ per_point, float *__restrict__ grad_T)
 {
@@ -213,21 +215,28 @@ __global__ __launch_bounds__(256) void threed_loss_kernel(
         float ti[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) ti[r] = (lane + 64 * r < CC) ? Ti[lane + 64 * r] : 0.f;
-        const float px = pos[(size_t)i * 3], py = pos[(size_t)i * 3 + 1], pz = pos[(size_t)i * 3 + 2];
         const int li = labels[i];
         // lanes 0..k-1 evaluate the k weights in parallel
         int j = -1;
         float w = 0.f;
         if (lane < k) {
             j = b * n + nbr[(size_t)i * k + lane];
-            float dx = px - pos[(size_t)j * 3], dy = py - pos[(size_t)j * 3 + 1], dz = pz - pos[(size_t)j * 3 + 2];
-            float d2 = dx * dx + dy * dy + dz * dz;
-            w = labels[j] == li ? __expf(-d2 * inv2s2) : 0.f;
+            const float *pi = pos + (size_t)i * pd, *pj = pos + (size_t)j * pd;
+            float d2 = 0.f;
+            for (int d = 0; d < pd; ++d) {
+                float dx = pi[d] - pj[d];
+                d2 += dx * dx;
+            }
+            const float e = __expf(-d2 * inv2s2);
+            w = labels[j] == li ? e : (SIGNED ? -e : 0.f);
         }
-        float S = w;
+        float S = 1.f;
+        if (!SIGNED) {
+            S = w;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) S += __shfl_xor(S, o);
-        S += 0.001f;
+            for (int o = 32; o >= 1; o >>= 1) S += __shfl_xor(S, o);
+            S += 0.001f;
+        }
         unsigned long long live = __ballot(w != 0.f);
         float acc = 0.f, gi[R];
 #pragma unroll
@@ -356,9 +365,41 @@ GEOT_EXPORT int geot_ntm_threed_loss(int b, int n, int c, int k, float sigma, co
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL((threed_loss_kernel<CC, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr,
+    hipLaunchKernelGGL((threed_loss_kernel<CC, false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       b * n, n, k, 3, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr,
                        per_point, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_feature_loss(int b, int n, int c, int k, int feat_dim, float sigma, const float *feats,
+                                      const int *labels, const float *ins_T, const int *nbr,
+                                      float *per_point, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || feat_dim < 1 || !(sigma > 0.f))
+        return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
+    int blocks = (b * n + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((threed_loss_kernel<CC, false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), 0.f, feats, labels, ins_T, nbr,
+                       per_point, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_feature_loss_grad(int b, int n, int c, int k, int feat_dim, float sigma,
+                                           float grad_scale, const float *feats, const int *labels,
+                                           const float *ins_T, const int *nbr, float *grad_ins_T, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || feat_dim < 1 || !(sigma > 0.f))
+        return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
+    int blocks = (b * n + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((threed_loss_kernel<CC, true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), grad_scale, feats, labels, ins_T,
+                       nbr, nullptr, grad_ins_T);
     return hipGetLastError();
 }
 
@@ -371,8 +412,8 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigm
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL((threed_loss_kernel<CC, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, 1.f / (2.f * sigma * sigma), grad_scale, positions, labels, ins_T, nbr,
+    hipLaunchKernelGGL((threed_loss_kernel<CC, true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       b * n, n, k, 3, 1.f / (2.f * sigma * sigma), grad_scale, positions, labels, ins_T, nbr,
                        nullptr, grad_ins_T);
     return hipGetLastError();
 }

@@ -214,3 +214,84 @@ class threeD_space_loss(nn.Module):
         if nbr is None:
             nbr = self.neighbours(positions)
         return _ThreeDLossFn.apply(positions, labels.to(torch.int32), ins_T, nbr, self.sigma)
+
+
+# ---------------------------------------------------------------------------------------------
+class _FeatureLossFn(Function):
+    @staticmethod
+    def forward(ctx, feats, labels, ins_T, nbr, sigma):
+        feats = f32(feats.contiguous(), "logits", 3)
+        ins_T = f32(ins_T.contiguous(), "ins_T", 3)
+        labels = i32(labels.contiguous(), "labels", 2)
+        nbr = i32(nbr.contiguous(), "nbr", 3)
+        dev = same_device(feats, labels, ins_T, nbr)
+        b, n, d = feats.shape
+        c, k = ins_T.shape[1], nbr.shape[2]
+        need(tuple(ins_T.shape) == (b * n, c, c) and tuple(labels.shape) == (b, n) and tuple(nbr.shape) == (b, n, k),
+             "feature_space_loss shape mismatch")
+        per_point = torch.empty(b * n, dtype=torch.float32, device=dev)
+        call("geot_ntm_feature_loss", dev, b, n, c, k, d, float(sigma), ptr(feats), ptr(labels), ptr(ins_T),
+             ptr(nbr), ptr(per_point))
+        ctx.save_for_backward(feats, labels, ins_T, nbr)
+        ctx.sigma = float(sigma)
+        return per_point.sum() / (b * n * k)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, labels, ins_T, nbr = ctx.saved_tensors
+        b, n, d = feats.shape
+        c, k = ins_T.shape[1], nbr.shape[2]
+        g = torch.zeros_like(ins_T)
+        call("geot_ntm_feature_loss_grad", feats.device, b, n, c, k, d, ctx.sigma, float(grad_out.item()) / (b * n * k),
+             ptr(feats), ptr(labels), ptr(ins_T), ptr(nbr), ptr(g))
+        return None, None, g, None, None
+
+
+class feature_space_loss(nn.Module):
+    """utils/insT_loss.py:9-58 (use_feat_loss; off in the shipped cfg).  forward(logits (B,C,N), labels
+    (B,N), ins_T (B*N,C,C)) -> mean_{i,j} s_ij exp(-|l_i-l_j|^2/(2 sigma^2)) |T_i-T_j|^2 over the k nearest
+    other points in LOGIT space, s_ij = +1 for equal labels else -1.  Weights are detached, as there."""
+
+    def __init__(self, k=7, sigma=1.0, num_classes=17):
+        super().__init__()
+        self.k, self.sigma, self.num_classes = k, sigma, num_classes
+
+    def forward(self, logits, labels, ins_T, nbr=None):
+        feats = logits.detach().permute(0, 2, 1).contiguous()
+        if nbr is None:
+            from .openpoints.models.layers.knn import knn_point
+            nbr = knn_point(self.k + 1, feats, feats)[1][:, :, 1:]
+        return _FeatureLossFn.apply(feats, labels.to(torch.int32), ins_T, nbr.to(torch.int32), self.sigma)
+
+
+class Idenyity_loss(nn.Module):
+    """utils/insT_loss.py:117-132 (sic): mean_i sum((T_i - I)^2 * I) / sum(I), without the (BN,C,C) repeat."""
+
+    def forward(self, insT, Identity):
+        ident = Identity.reshape(1, -1)
+        diff = (insT.reshape(insT.size(0), -1) - ident).pow(2)
+        return (torch.sum(diff * ident, dim=1) / torch.sum(ident)).mean()
+
+
+@torch.no_grad()
+def cal_mean_feature(batches, num_classes=17):
+    """train.py:868-897 with the model call factored out: ``batches`` yields (logits (B,C,N) raw model
+    output, target (B,N) int64).  Reproduces the reference arithmetic literally -- including
+    ``cur_feats = logits[target]`` (rows of the flattened softmax selected BY LABEL VALUE, not by a
+    class mask), so every visited class receives the same running mean."""
+    cm = c_num = None
+    for logits, target in batches:
+        c = num_classes
+        if cm is None:
+            cm = torch.zeros((c, c), device=logits.device)
+            c_num = torch.zeros((c,), device=logits.device)
+        b, _, n = logits.shape
+        sm = torch.softmax(logits, dim=1).permute(0, 2, 1).contiguous().view(b * n, c)
+        target = target.view(-1)
+        mean_feats = sm[target].mean(0)
+        counts = torch.bincount(target, minlength=c)[:c].to(cm.dtype)
+        seen = counts > 0
+        upd = (cm * c_num[:, None] + mean_feats[None, :] * counts[:, None]) / (c_num + counts).clamp_min(1)[:, None]
+        cm = torch.where(seen[:, None], upd, cm)
+        c_num = c_num + counts
+    return cm.to(torch.float32)

@@ -9,8 +9,21 @@ from ....knn_cuda import knn_sorted
 
 
 def _knn(query, support, k):
+    if query.shape[-1] != 3:
+        return _knn_nd(query, support, k)
     d2, idx = knn_sorted(query.contiguous().float(), support.contiguous().float(), k)
     return torch.sqrt(d2), idx
+
+
+def _knn_nd(query, support, k, chunk=2048):
+    """Feature-space neighbours (D != 3; only feature_space_loss, disabled in the shipped cfg, asks for
+    them): the reference's own cdist + topk, in query chunks so the (M, N) matrix is never whole."""
+    dist, idx = [], []
+    for s in range(0, query.shape[1], chunk):
+        top = torch.cdist(query[:, s:s + chunk], support).topk(k=k, dim=-1, largest=False, sorted=True)
+        dist.append(top.values)
+        idx.append(top.indices.to(torch.int32))
+    return torch.cat(dist, 1), torch.cat(idx, 1)
 
 
 @torch.no_grad()

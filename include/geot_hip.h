@@ -204,6 +204,17 @@ int geot_ntm_threed_loss(int b, int n, int c, int k, float sigma, const float *p
 int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigma, float grad_scale,
                               const float *positions, const int *labels, const float *ins_T,
                               const int *nbr, float *grad_ins_T, void *stream);
+/* feature_space_loss (utils/insT_loss.py:9-58; disabled in the shipped cfg, use_feat_loss): same graph
+ * kernel over feat_dim-dimensional features (b,n,feat_dim) with SIGNED weights
+ * w_ij = (label_i == label_j ? +1 : -1) exp(-|f_i-f_j|^2/(2 sigma^2)) and no per-point normalisation:
+ * per_point (b*n) = sum_j w_ij |T_i-T_j|^2; the reference's loss is sum(per_point) / (b*n*k).
+ * _grad: pass grad_scale = upstream_grad / (b*n*k). */
+int geot_ntm_feature_loss(int b, int n, int c, int k, int feat_dim, float sigma, const float *feats,
+                          const int *labels, const float *ins_T, const int *nbr, float *per_point,
+                          void *stream);
+int geot_ntm_feature_loss_grad(int b, int n, int c, int k, int feat_dim, float sigma, float grad_scale,
+                               const float *feats, const int *labels, const float *ins_T, const int *nbr,
+                               float *grad_ins_T, void *stream);
 
 #ifdef __cplusplus
 }

@@ -147,3 +147,53 @@ def threed_space_loss(positions, labels, ins_T, nbr, sigma=1.0):
     grad = contrib.sum(1)
     np.subtract.at(grad, gidx.reshape(-1), contrib.reshape(-1, T.shape[1]))
     return loss, grad.reshape(np.asarray(ins_T).shape), per_point
+
+
+def feature_space_loss(logits, labels, ins_T, nbr, sigma=1.0):
+    """utils/insT_loss.py:16-58: logits (B,C,N), labels (B,N), ins_T (BN,C,C), nbr (B,N,k) neighbour ids in
+    logit space (self excluded) -> (loss, grad wrt ins_T, per_point sums).  distance_map = -1 / +1 by label
+    equality (:44-46), times exp(-|l_i-l_j|^2/(2 sigma^2)), detached; loss = mean over (BN, k)."""
+    F = np.asarray(logits, dtype=np.float64).transpose(0, 2, 1)
+    B, N, D = F.shape
+    k = nbr.shape[2]
+    T = np.asarray(ins_T, dtype=np.float64).reshape(B * N, -1)
+    gidx = (np.asarray(nbr, dtype=np.int64) + (np.arange(B)[:, None, None] * N)).reshape(B * N, k)
+    P = F.reshape(B * N, D)
+    Lb = np.asarray(labels).reshape(B * N)
+    sign = np.where(Lb[:, None] == Lb[gidx], 1.0, -1.0)
+    w = sign * np.exp(-((P[:, None, :] - P[gidx]) ** 2).sum(2) / (2 * sigma ** 2))
+    diff = T[:, None, :] - T[gidx]
+    per_point = (w * (diff ** 2).sum(2)).sum(1)
+    loss = per_point.sum() / (B * N * k)
+    contrib = (2.0 / (B * N * k)) * w[:, :, None] * diff
+    grad = contrib.sum(1)
+    np.subtract.at(grad, gidx.reshape(-1), contrib.reshape(-1, T.shape[1]))
+    return loss, grad.reshape(np.asarray(ins_T).shape), per_point
+
+
+def identity_loss(ins_T, identity):
+    """utils/insT_loss.py:122-132 (class Idenyity_loss)."""
+    T = np.asarray(ins_T, dtype=np.float64)
+    num = T.shape[0]
+    I = np.broadcast_to(np.asarray(identity, dtype=np.float64), T.shape).reshape(num, -1)
+    diff = (T.reshape(num, -1) - I) ** 2
+    return ((diff * I).sum(1) / I.sum(1)).mean()
+
+
+def cal_mean_feature(batches, c=17):
+    """train.py:868-897, literal (model call factored out: batches of (raw logits (B,C,N), target (B,N)))."""
+    cm = np.zeros((c, c))
+    c_num = np.zeros(c)
+    for logits, target in batches:
+        z = np.asarray(logits, dtype=np.float64)
+        e = np.exp(z - z.max(1, keepdims=True))
+        sm = (e / e.sum(1, keepdims=True)).transpose(0, 2, 1).reshape(-1, c)
+        t = np.asarray(target).reshape(-1)
+        for kk in range(c):
+            cur_num = (t == kk).sum()
+            if cur_num == 0:
+                continue
+            mean_feats = sm[t].mean(0)                     # :891  logits[target] -- indexed by label VALUE
+            cm[kk] = (cm[kk] * c_num[kk] + mean_feats * cur_num) / (c_num[kk] + cur_num)
+            c_num[kk] += cur_num
+    return cm.astype(np.float32)

@@ -133,3 +133,52 @@ def test_threed_space_loss_matches_torch_transcription():
     assert np.isclose(ml.item(), loss, rtol=1e-12)
     ml.backward()
     assert np.allclose(tT.grad.numpy(), grad, atol=1e-12)
+
+
+def test_feature_space_and_identity_loss_match_torch_transcription():
+    rng = np.random.default_rng(5)
+    B, N, k = 2, 90, 7
+    logits = _softmax(rng.normal(size=(B, C, N)), 1)
+    labels = rng.integers(0, 3, (B, N))
+    insT = np_ntm.l1_normalize(rng.random((B * N, C, C)) + 0.01, 2)
+    # torch transcription of utils/insT_loss.py:16-58 (knn_point = cdist + topk, index_select/cat loop)
+    lg = torch.tensor(logits).permute(0, 2, 1).contiguous()
+    top = torch.cdist(lg, lg).topk(k=k + 1, dim=-1, largest=False, sorted=True).indices[:, :, 1:]
+    loss, grad, _ = np_ntm.feature_space_loss(logits, labels, insT, top.numpy(), sigma=1.0)
+    tT = torch.tensor(insT, requires_grad=True)
+    factor = torch.arange(B).unsqueeze(-1).repeat(1, N)
+    P, L = lg.view(B * N, -1), torch.tensor(labels).view(-1)
+    nP, nL, nT = [], [], []
+    for i in range(k):
+        cur = (top[:, :, i] + factor * N).view(-1)
+        nP.append(torch.index_select(P, 0, cur).unsqueeze(1))
+        nL.append(torch.index_select(L, 0, cur).unsqueeze(1))
+        nT.append(torch.index_select(tT, 0, cur).unsqueeze(1))
+    nP, nL, nT = torch.cat(nP, 1), torch.cat(nL, 1), torch.cat(nT, 1)
+    dm = -torch.ones(B * N, k, dtype=torch.float64)
+    dm[L.unsqueeze(1).repeat(1, k) == nL] = 1
+    dm = dm * torch.exp(-torch.sum((P.unsqueeze(1).repeat(1, k, 1) - nP) ** 2, dim=2) / 2.0)
+    td = torch.sum((tT.unsqueeze(1).repeat(1, k, 1, 1).view(B * N, k, -1) - nT.view(B * N, k, -1)) ** 2, dim=2)
+    ml = torch.mean(dm.detach() * td)
+    assert np.isclose(ml.item(), loss, rtol=1e-12)
+    ml.backward()
+    assert np.allclose(tT.grad.numpy(), grad, atol=1e-12)
+    # Idenyity_loss, insT_loss.py:122-132
+    ident = torch.eye(C, dtype=torch.float64)
+    t2 = torch.tensor(insT)
+    num = t2.size(0)
+    I = ident.repeat(num, 1, 1).view(num, -1)
+    want = (torch.sum((t2.view(num, -1) - I).pow(2) * I, dim=1) / torch.sum(I, dim=1)).mean().item()
+    assert np.isclose(np_ntm.identity_loss(insT, np.eye(C)), want, rtol=1e-12)
+
+
+def test_cal_mean_feature_quirk():
+    rng = np.random.default_rng(6)
+    batches = [(rng.normal(size=(2, C, 50)), rng.integers(0, 5, (2, 50))) for _ in range(3)]
+    cm = np_ntm.cal_mean_feature(batches, C)
+    assert cm.shape == (C, C) and np.all(cm[5:] == 0)          # unseen classes stay zero
+    # within one batch every visited class receives the SAME mean (logits[target] indexes rows by label
+    # value, not by a class mask); across batches the rows differ only through the count weighting
+    one = np_ntm.cal_mean_feature(batches[:1], C)
+    assert np.allclose(one[0], one[1]) and np.allclose(one[0], one[4]) and one[0].sum() > 0
+    assert np.allclose(cm[:5].sum(1), 1.0, atol=1e-6)

@@ -107,6 +107,43 @@ def test_threed_space_loss_forward_backward(B, N, k, nlab, oracle):
     np.testing.assert_allclose(tT.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
 
 
+@pytest.mark.parametrize("B,N,k,nlab", [(2, 300, 7, 3), (1, 1500, 16, 17)])
+def test_feature_space_loss_forward_backward(B, N, k, nlab):
+    from geot_amd.ntm import feature_space_loss, Idenyity_loss
+    rng = np.random.default_rng(4)
+    logits = _softmax(rng.normal(size=(B, C, N)) * 2, 1).astype(np.float32)
+    labels = rng.integers(0, nlab, (B, N))
+    insT = np_ntm.l1_normalize(rng.random((B * N, C, C)) + 0.01, 2).astype(np.float32)
+    crit = feature_space_loss(k=k, sigma=1.0, num_classes=C)
+    tl, tT = T(logits), T(insT).requires_grad_(True)
+    from geot_amd.openpoints.models.layers.knn import knn_point
+    feats = tl.permute(0, 2, 1).contiguous()
+    nbr = knn_point(k + 1, feats, feats)[1][:, :, 1:]
+    # neighbour ids: every returned neighbour is at least as close as the true (k+1)-th (fp64 brute force)
+    f64 = logits.transpose(0, 2, 1).astype(np.float64)
+    d = np.sqrt(((f64[:, :, None, :] - f64[:, None, :, :]) ** 2).sum(-1)) if N <= 400 else None
+    if d is not None:
+        kth = np.sort(d, axis=2)[:, :, k]
+        got = np.take_along_axis(d, nbr.cpu().numpy().astype(np.int64), 2)
+        assert np.all(got <= kth[..., None] + 1e-5)
+    loss = crit(tl, T(labels, torch.int64), tT, nbr=nbr)
+    want, wgrad, _ = np_ntm.feature_space_loss(logits, labels, insT, nbr.cpu().numpy(), 1.0)
+    assert abs(loss.item() - want) <= 2e-5 * abs(want) + 1e-7
+    loss.backward()
+    np.testing.assert_allclose(tT.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
+    ident = torch.eye(C, device=DEV)
+    il = Idenyity_loss()(T(insT), ident).item()
+    assert abs(il - np_ntm.identity_loss(insT, np.eye(C))) <= 1e-5 * abs(il)
+
+
+def test_cal_mean_feature_matches_oracle():
+    from geot_amd.ntm import cal_mean_feature
+    rng = np.random.default_rng(6)
+    batches = [(rng.normal(size=(2, C, 500)).astype(np.float32), rng.integers(0, 9, (2, 500))) for _ in range(3)]
+    got = cal_mean_feature(((T(l), T(t, torch.int64)) for l, t in batches), C).cpu().numpy()
+    np.testing.assert_allclose(got, np_ntm.cal_mean_feature(batches, C), rtol=1e-5, atol=1e-7)
+
+
 def test_ntm_step_composition():
     """The unlabelled half of one FixMatch+NTM step (train.py:505-571) end to end: shapes, finiteness,
     gradients reach the T-predictor, sigma and the student logits."""

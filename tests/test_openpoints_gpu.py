@@ -210,3 +210,77 @@ def test_composite_workloads_run_and_are_finite():
     nt = wl.NtmHotPath().to(DEV)
     l2 = wl.ntm_step(nt, xyz, torch.randn(2, 17, 9000, device=DEV), torch.randn(2, 17, 9000, device=DEV))
     assert torch.isfinite(l2) and torch.isfinite(nt.ema_t).all()
+
+
+def test_openpoints_sa_msg_and_fp_modules(oracle):
+    """openpoints PointNetSAModuleMSG / ConvPool / PointNetFPModule mirrors: composed path == fused eval
+    path, sampling + grouping indices == oracle, FP module == numpy restatement of its front end."""
+    from geot_amd.openpoints.models.backbone.pointnetv2 import PointNetSAModuleMSG, PointNetFPModule
+    torch.manual_seed(0)
+    B, N, C = 2, 2048, 6
+    xyz_np, _ = make_batch(B, N, start_index=7)
+    xyz = dev(xyz_np)
+    feats = torch.randn(B, C, N, device=DEV)
+    sa = PointNetSAModuleMSG(stride=4, radii=[0.15, 0.3], nsamples=[16, 32], channel_list=[[C, 32, 64], [C, 32, 64]],
+                             aggr_args={'feature_type': 'dp_fj', 'reduction': 'max'},
+                             group_args={'NAME': 'ballquery', 'normalize_dp': True}, conv_args={},
+                             norm_args={'norm': 'bn'}, act_args={'act': 'relu'}).to(DEV)
+    for m in sa.modules():                                    # non-trivial running statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    sa.eval()
+    with torch.no_grad():
+        q_f, out_f = sa(xyz, feats)                           # fused kernel
+    for la in sa.local_aggregations:
+        la.SA_CONFIG_operator.fused_eval = False
+    with torch.no_grad():
+        q_c, out_c = sa(xyz, feats)                           # composed ops
+    want_idx = oracle.fps_dense(xyz_np, N // 4, 1024, False)  # K1' rule (no origin skip, block cap 1024)
+    want_q = np.take_along_axis(xyz_np, want_idx[..., None].astype(np.int64).repeat(3, -1), 1)
+    assert np.array_equal(host(q_f), want_q) and np.array_equal(host(q_c), want_q)
+    assert out_f.shape == (B, 128, N // 4)
+    np.testing.assert_allclose(host(out_f), host(out_c), rtol=2e-4, atol=2e-4)
+    # training-mode path gives gradients to the features
+    sa.train()
+    f2 = feats.clone().requires_grad_(True)
+    sa(xyz, f2)[1].sum().backward()
+    assert torch.isfinite(f2.grad).all() and f2.grad.abs().sum() > 0
+    # FP module
+    fp = PointNetFPModule([64 + C, 32, 16]).to(DEV).eval()
+    known, kf = q_f, torch.randn(B, 64, N // 4, device=DEV)
+    with torch.no_grad():
+        got = fp(xyz, known, feats, kf)
+    d2, idx = oracle.three_nn(xyz_np, host(known))
+    r = 1.0 / (np.sqrt(d2.astype(np.float32)) + np.float32(1e-8))
+    w = (r / r.sum(2, keepdims=True)).astype(np.float32)
+    interp = oracle.three_interpolate(host(kf), idx, w)
+    with torch.no_grad():
+        want = fp.convs(torch.cat([feats, dev(interp)], 1))
+    np.testing.assert_allclose(host(got), host(want), rtol=1e-4, atol=1e-5)
+
+
+def test_get_pred_whole_matches_oracle(oracle):
+    from geot_amd.validation import get_pred_whole
+    rng = np.random.default_rng(11)
+    B, N, C = 2, 3000, 17
+    pts_np, _ = make_batch(B, N, start_index=30)
+    logits = rng.normal(size=(B, C, N)).astype(np.float32) * 3
+    center = [rng.normal(size=(1, 3)).astype(np.float32) for _ in range(B)]
+    scale = [np.float32(rng.uniform(20, 40)) for _ in range(B)]
+    whole = [(rng.normal(size=(m, 3)).astype(np.float32) * 0.4 * scale[i] + center[i]) for i, m in enumerate((20011, 12345))]
+    preds = get_pred_whole(dev(logits), dev(pts_np), [torch.from_numpy(w) for w in whole],
+                           [torch.from_numpy(c) for c in center], [torch.tensor(s) for s in scale])
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    sm = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    for i in range(B):
+        p = (pts_np[i] * scale[i] + center[i]).astype(np.float32)
+        d2, idx = oracle.three_nn(whole[i][None], p[None])
+        r = 1.0 / (np.sqrt(d2) + np.float32(1e-8))
+        w = r / r.sum(2, keepdims=True)
+        lw = oracle.three_interpolate(sm[i][None], idx, w.astype(np.float32))[0]      # (C, M)
+        top2 = np.sort(lw, 0)[-2:]
+        clear = (top2[1] - top2[0]) > 1e-5                     # ignore numerically tied vertices
+        got = preds[i][0].cpu().numpy()
+        assert got.shape == (whole[i].shape[0],)
+        assert np.array_equal(got[clear], lw.argmax(0)[clear]) and clear.mean() > 0.99
