@@ -35,6 +35,7 @@ import torch  # noqa: E402
 N_POINTS = 24000
 NPOINT, RADIUS, NSAMPLE, MLP = 6000, 0.1, 32, [3, 64, 64, 128]
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (= fp32 MFMA) rate
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (same figure)
 HBM_PEAK_GBS = 8000.0
 FPS_FLOP_PER_UPDATE = 10          # 3 sub, 3 mul, 2 add, min, compare
 
@@ -56,6 +57,24 @@ def build_module(device):
     torch.manual_seed(1609)
     sa = PointnetSAModuleVotes(mlp=list(MLP), npoint=NPOINT, radius=RADIUS, nsample=NSAMPLE, use_xyz=True)
     return sa.to(device).eval()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
+    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH
+    doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the
+    process, so the figure is the profiled one, not a live one; None if no profile is committed."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        prof = json.load(f)
+    for name, rec in prof.get("kernels", {}).items():
+        if kernel in name:
+            return rec.get("traffic_bytes")
+    return None
 
 
 class FpsTimer:
@@ -84,7 +103,9 @@ def cpu_baseline(xyz_np, feats_np, sa_cpu, steps):
     FPS / ball query / grouping + the same SharedMLP on torch-CPU.  Checker code, used here
     only as the reported baseline, never as the thing shipped."""
     from oracle import capi
-    cores = os.cpu_count() or 1
+    # the GPU box gives a one-GPU job a 16-core share; use what the affinity mask allows up to that
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cores = capi.set_threads(cores)
     torch.set_num_threads(cores)
 
     def one():
@@ -105,7 +126,7 @@ def cpu_baseline(xyz_np, feats_np, sa_cpu, steps):
     dt = time.perf_counter() - t0
     return {"value": xyz_np.shape[0] * steps / dt, "unit": "clouds/s", "cores": cores, "kind": "port",
             "sample": "%d SetAbstraction forwards of %d cloud(s) x %d pts (oracle C/OpenMP FPS+ball_query+group, "
-                      "torch-CPU SharedMLP+max), %.1f s" % (steps, xyz_np.shape[0], N_POINTS, dt)}
+                      "torch-CPU SharedMLP+max; FPS rounds are sequential so its share runs on 1 thread per cloud), %.1f s" % (steps, xyz_np.shape[0], N_POINTS, dt)}
 
 
 def main():
@@ -168,6 +189,11 @@ def main():
     if patch_owner is not None:
         orig_fn = getattr(patch_owner, patch_name)
         setattr(patch_owner, patch_name, timer.wrap(orig_fn))
+    mlp_timer = FpsTimer()
+    if workload == "sa":
+        import geot_amd.sa_fused as sa_fused_mod
+        orig_mlp = sa_fused_mod.fused_group_mlp_max
+        sa_fused_mod.fused_group_mlp_max = mlp_timer.wrap(orig_mlp)
     torch.cuda.synchronize()
     dist_utils.barrier()
     torch.cuda.synchronize()
@@ -180,6 +206,8 @@ def main():
     elapsed = time.perf_counter() - t0
     if patch_owner is not None:
         setattr(patch_owner, patch_name, orig_fn)
+    if workload == "sa":
+        sa_fused_mod.fused_group_mlp_max = orig_mlp
     elapsed = dist_utils.max_over_ranks(elapsed, dev)
     assert torch.isfinite(out).all()
 
@@ -203,7 +231,8 @@ def main():
                    "parallelism": "independent clouds per rank, no collective"},
         "roofline": {"kernel": "fps_pruned_kernel", "bound": "valu",
                      "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
+                     "traffic": pmc_traffic("fps_pruned_kernel") if workload == "sa" and B == 1 else None,
                      "avg_launch_ms": fps_ms,
                      "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic "
                              "flop = clouds*N*(m-1) updates * 10 (what the reference executes); the pruned kernel "
@@ -211,6 +240,17 @@ def main():
     }
     if workload == "ntm":
         result["roofline"] = None
+    if workload == "sa" and mlp_timer.pairs:
+        mlp_ms = mlp_timer.mean_ms()
+        widths = [MLP[0] + 3] + MLP[1:]   # use_xyz: 3 relative coordinates + 3 features
+        mlp_flop = 2.0 * B * NPOINT * NSAMPLE * sum(a * b for a, b in zip(widths[:-1], widths[1:]))
+        mlp_tf = mlp_flop / (mlp_ms * 1e-3) / 1e12
+        result["roofline_secondary"] = {
+            "kernel": "sa_group_mlp_max_kernel", "bound": "mfma", "achieved": mlp_tf, "peak": FP32_MATRIX_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": mlp_tf / FP32_MATRIX_PEAK_TFLOPS,
+            "traffic": pmc_traffic("sa_group_mlp_max_kernel") if B == 1 else None, "avg_launch_ms": mlp_ms,
+            "note": "fused group + [6,64,64,128] 1x1-conv stack on fp32 MFMA + max over nsample; algorithmic flop = "
+                    "2*rows*sum(Cin*Cout) with the unpadded 3+3 input channels"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and workload == "sa":
         sa_cpu = build_module("cpu")
         sa_cpu.load_state_dict(sa.state_dict())

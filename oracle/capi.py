@@ -56,6 +56,11 @@ def block_size(n, cap):
     return int(lib().geot_ref_block_size(int(n), int(cap)))
 
 
+def set_threads(n):
+    """-> the number of OpenMP threads the C restatement will use from now on."""
+    return int(lib().geot_ref_set_threads(int(n)))
+
+
 def fps_dense(xyz, m, cap=512, skip_origin=True, return_temp=False):
     """xyz (B,N,3) -> idx (B,m) int32.  cap=512+skip: pointnet2._ext; cap=1024: pointnet2_batch."""
     xyz = _f32(xyz)
