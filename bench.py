@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--clouds", type=int, default=None, help="clouds per GPU per step (sa: 1, backbone_ops/ntm: 8)")
     ap.add_argument("--workload", choices=["sa", "backbone_ops", "ntm"], default="sa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=24)
     return ap.parse_args()
 
 

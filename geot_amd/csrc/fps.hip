@@ -222,7 +222,7 @@ struct FpsEntry2 { // multi-commit variant: sortable (hi:lo) = (bits(max)+1 : ~k
     uint32_t pad[2];
 };
 #ifndef GEOT_FP_TMAX
-#define GEOT_FP_TMAX 6
+#define GEOT_FP_TMAX 8
 #endif
 constexpr int FP_TMAX = GEOT_FP_TMAX; // samples committed per round at most (<= 8: the 8 x 8 conflict matrix is one wave)
 
@@ -270,6 +270,61 @@ __device__ __forceinline__ uint32_t wave_min_u32_fast(uint32_t v)
     return min(min(a, b), min(c, d));
 }
 
+// Multiset top-2 of one int per lane over the wave (t1 >= t2, both wave-uniform), optionally together with
+// the min of a u32 key: ONE butterfly instead of two or three dependent ones.  Per step
+//   n1 = max(m1, p1);  n2 = max(min(m1, p1), max(m2, p2))      (p = partner's pair; the sets are disjoint)
+// with the three DPP ops independent of each other.  Register ping-pong keeps every DPP read two
+// instructions behind the write it depends on (the required wait states), so no s_nop between steps.
+#define GEOT_T2_STEP(A1, A2, B1, B2, CTRL)                                                   \
+    "v_max_i32_dpp " B1 ", " A1 ", " A1 " " CTRL " row_mask:0xf bank_mask:0xf\n\t"           \
+    "v_min_i32_dpp %[u], " A1 ", " A1 " " CTRL " row_mask:0xf bank_mask:0xf\n\t"             \
+    "v_max_i32_dpp %[w], " A2 ", " A2 " " CTRL " row_mask:0xf bank_mask:0xf\n\t"             \
+    "v_max_i32 " B2 ", %[u], %[w]\n\t"
+#define GEOT_T2K_STEP(A1, A2, B1, B2, CTRL)                                                  \
+    "v_max_i32_dpp " B1 ", " A1 ", " A1 " " CTRL " row_mask:0xf bank_mask:0xf\n\t"           \
+    "v_min_i32_dpp %[u], " A1 ", " A1 " " CTRL " row_mask:0xf bank_mask:0xf\n\t"             \
+    "v_max_i32_dpp %[w], " A2 ", " A2 " " CTRL " row_mask:0xf bank_mask:0xf\n\t"             \
+    "v_min_u32_dpp %[k], %[k], %[k] " CTRL " row_mask:0xf bank_mask:0xf\n\t"                 \
+    "v_max_i32 " B2 ", %[u], %[w]\n\t"
+__device__ __forceinline__ void top2_merge_rows(int a1, int a2, int &t1, int &t2)
+{
+    int x1 = __builtin_amdgcn_readlane(a1, 0), x2 = __builtin_amdgcn_readlane(a2, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        int y1 = __builtin_amdgcn_readlane(a1, r), y2 = __builtin_amdgcn_readlane(a2, r);
+        x2 = max(min(x1, y1), max(x2, y2));
+        x1 = max(x1, y1);
+    }
+    t1 = x1; t2 = x2;
+}
+__device__ __forceinline__ void wave_top2_i32(int v, int &t1, int &t2)
+{
+    int a1 = v, a2 = (int)0x80000000, b1, b2, u, w;
+    asm volatile("s_nop 1\n\t"
+                 GEOT_T2_STEP("%[a1]", "%[a2]", "%[b1]", "%[b2]", "quad_perm:[1,0,3,2]")
+                 GEOT_T2_STEP("%[b1]", "%[b2]", "%[a1]", "%[a2]", "quad_perm:[2,3,0,1]")
+                 GEOT_T2_STEP("%[a1]", "%[a2]", "%[b1]", "%[b2]", "row_half_mirror")
+                 GEOT_T2_STEP("%[b1]", "%[b2]", "%[a1]", "%[a2]", "row_mirror")
+                 : [a1] "+v"(a1), [a2] "+v"(a2), [b1] "=&v"(b1), [b2] "=&v"(b2), [u] "=&v"(u), [w] "=&v"(w));
+    top2_merge_rows(a1, a2, t1, t2);
+}
+__device__ __forceinline__ void wave_top2_i32_min_u32(int v, uint32_t key, int &t1, int &t2, uint32_t &kmin)
+{
+    int a1 = v, a2 = (int)0x80000000, b1, b2, u, w;
+    uint32_t k = key;
+    asm volatile("s_nop 1\n\t"
+                 GEOT_T2K_STEP("%[a1]", "%[a2]", "%[b1]", "%[b2]", "quad_perm:[1,0,3,2]")
+                 GEOT_T2K_STEP("%[b1]", "%[b2]", "%[a1]", "%[a2]", "quad_perm:[2,3,0,1]")
+                 GEOT_T2K_STEP("%[a1]", "%[a2]", "%[b1]", "%[b2]", "row_half_mirror")
+                 GEOT_T2K_STEP("%[b1]", "%[b2]", "%[a1]", "%[a2]", "row_mirror")
+                 : [a1] "+v"(a1), [a2] "+v"(a2), [b1] "=&v"(b1), [b2] "=&v"(b2), [u] "=&v"(u), [w] "=&v"(w),
+                   [k] "+v"(k));
+    top2_merge_rows(a1, a2, t1, t2);
+    uint32_t ka = __builtin_amdgcn_readlane(k, 0), kb = __builtin_amdgcn_readlane(k, 16);
+    uint32_t kc = __builtin_amdgcn_readlane(k, 32), kd = __builtin_amdgcn_readlane(k, 48);
+    kmin = min(min(ka, kb), min(kc, kd));
+}
+
 // LDS 64-bit max without return value (the atomic optimizer would wrap atomicMax in
 // wave-election code although we are already down to one lane).
 __device__ __forceinline__ void lds_max_u64(unsigned long long *addr, unsigned long long v)
@@ -305,7 +360,8 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
     __shared__ float red[NW][6];
     __shared__ uint32_t wsum[8];
 
-    const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // wave-uniform for the compiler too (scalar branches)
     int start_n, n, start_m, m, base;
     if (offset) {
         start_n = bid ? offset[bid - 1] : 0;
@@ -451,178 +507,237 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
     uint32_t ckey = KEY_NONE;
     float cx = 0.f, cy = 0.f, cz = 0.f;
     bool cand_ok = false;
-    float qx[TMAX], qy[TMAX], qz[TMAX];
-    qx[0] = P[0]; qy[0] = P[1]; qz[0] = P[2];
-#pragma unroll
-    for (int u = 1; u < TMAX; ++u) { qx[u] = 0.f; qy[u] = 0.f; qz[u] = 0.f; }
+    // committed samples of the current round: lane u holds sample u (read back with v_readlane)
+    float qxv = P[0], qyv = P[1], qzv = P[2];
     int Tn = 1, par = 0;
 #ifdef GEOT_LAB_STAMPS
     unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, t0, t1, rounds = 0;
+    unsigned long long w0 = __builtin_readcyclecounter(), wredo = 0, nredo = 0;
+    __shared__ unsigned int lab_max;
+    if (tid == 0) lab_max = 0;
 #define GEOT_STAMP(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
 #else
 #define GEOT_STAMP(acc) do {} while (0)
 #endif
-    for (int j = 1; j < m;) {
+#ifdef GEOT_LAB_STATS
+#define GEOT_APPLY_STAT(mask) \
+    if (lane == 0) { atomicAdd(&geot_fps_dbg[0], (unsigned long long)__popcll(mask)); atomicAdd(&geot_fps_dbg[1], 1ull); }
+#else
+#define GEOT_APPLY_STAT(mask)
+#endif
+    // one committed sample: box test by lanes (= slots), then update of the surviving slots
+#define GEOT_APPLY(AX, AY, AZ, REDO)                                                                   \
+    do {                                                                                               \
+        float dx_ = fmaxf(fmaxf(bx0 - (AX), (AX) - bx1), 0.f);                                         \
+        float dy_ = fmaxf(fmaxf(by0 - (AY), (AY) - by1), 0.f);                                         \
+        float dz_ = fmaxf(fmaxf(bz0 - (AZ), (AZ) - bz1), 0.f);                                         \
+        float lb2_ = dx_ * dx_ + dy_ * dy_ + dz_ * dz_;                                                \
+        unsigned long long mask_ = __ballot(!(lb2_ > __int_as_float(smax) * 1.00001f));                \
+        GEOT_APPLY_STAT(mask_)                                                                         \
+        REDO = REDO || (cslot >= 0 && ((mask_ >> cslot) & 1ull));                                      \
+        while (mask_) {                                                                                \
+            int s_ = __builtin_ctzll(mask_);                                                           \
+            mask_ &= mask_ - 1;                                                                        \
+            float d_ = sqdist3(X.get(s_), Y.get(s_), Z.get(s_), (AX), (AY), (AZ));                     \
+            float d2_ = fmin_raw(d_, D.get(s_));                                                       \
+            D.set(s_, d2_);                                                                            \
+            set_lane(smax, __builtin_amdgcn_readfirstlane(wave_max_i32_fast(__float_as_int(d2_))), s_); \
+        }                                                                                              \
+    } while (0)
+
+    // The loop body alternates two phases around ONE apply site (LLVM keeps the 4 x 32 point registers
+    // in place only if they are written at a single static location; a second site makes it copy
+    // whole 32-register vectors around the branch):
+    //   phase 0: [apply the rest of last round's samples] search, publish, barrier, then wave 0 ranks the
+    //            candidates while the other waves fetch the top one -- the next sample for certain -- and
+    //   phase 1: [apply it, overlapping wave 0's ranking] barrier, read the committed prefix.
+    int j = 1, phase = 0, ua = 0, ub = 1;
+    bool redo_acc = false, early = false, done = false;
+    for (;;) {
 #ifdef GEOT_LAB_STAMPS
         t0 = __builtin_readcyclecounter();
-        ++rounds;
 #endif
-        // -- apply the Tn samples committed last round
-        bool redo = !cand_ok;
-#pragma unroll
-        for (int u = 0; u < TMAX; ++u) {
-            if (u < Tn) {
-                float dx = fmaxf(fmaxf(bx0 - qx[u], qx[u] - bx1), 0.f);
-                float dy = fmaxf(fmaxf(by0 - qy[u], qy[u] - by1), 0.f);
-                float dz = fmaxf(fmaxf(bz0 - qz[u], qz[u] - bz1), 0.f);
-                float lb2 = dx * dx + dy * dy + dz * dz;
-                unsigned long long mask = __ballot(!(lb2 > __int_as_float(smax) * 1.00001f));
-#ifdef GEOT_LAB_STATS
-                if (lane == 0) { atomicAdd(&geot_fps_dbg[0], (unsigned long long)__popcll(mask)); atomicAdd(&geot_fps_dbg[1], 1ull); }
-#endif
-                redo = redo || (cslot >= 0 && ((mask >> cslot) & 1ull));
-                while (mask) {
-                    int s = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    float d = sqdist3(X.get(s), Y.get(s), Z.get(s), qx[u], qy[u], qz[u]);
-                    float d2 = fmin_raw(d, D.get(s));
-                    D.set(s, d2);
-                    set_lane(smax, __builtin_amdgcn_readfirstlane(wave_max_i32_fast(__float_as_int(d2))), s);
-                }
-            }
+#pragma unroll 1
+        for (int u = ua; u < ub; ++u) {
+            const float ax = read_lane(qxv, u), ay = read_lane(qyv, u), az = read_lane(qzv, u);
+            GEOT_APPLY(ax, ay, az, redo_acc);
         }
-        GEOT_STAMP(tA);
-        // -- this wave's candidate + runner-up bound: recomputed only when its slot was touched
-        if (redo) {
-            cand_ok = true;
-            cM = __builtin_amdgcn_readfirstlane(wave_max_i32_fast(smax));
-            ckey = KEY_NONE;
-            cslot = -1;
-            cV2 = -1;
-            int owner = 0;
-            if (cM >= 0) {
-                unsigned long long cm = __ballot(smax == cM);
-                while (cm) {
-                    int s = __builtin_ctzll(cm);
-                    cm &= cm - 1;
-                    bool hit = __float_as_int(D.get(s)) == cM;
-                    uint32_t key = hit ? fps_key(perm[s * NT + tid], L) : KEY_NONE;
-                    uint32_t kmin = __builtin_amdgcn_readfirstlane(wave_min_u32_fast(key));
-                    if (kmin < ckey) {
-                        ckey = kmin;
-                        cslot = s;
-                        owner = __builtin_ctzll(__ballot(key == kmin));
-                        cx = read_lane(X.get(s), owner);
-                        cy = read_lane(Y.get(s), owner);
-                        cz = read_lane(Z.get(s), owner);
+        if (done) break;
+        if (phase == 0) {
+            GEOT_STAMP(tA);
+#ifdef GEOT_LAB_STAMPS
+            ++rounds;
+#endif
+            // -- this wave's candidate + runner-up bound: recomputed only when its slot was touched
+            if (!cand_ok || redo_acc) {
+                cand_ok = true;
+                int m2; // max and (multiset) runner-up of the per-slot maxima in one butterfly
+                wave_top2_i32(smax, cM, m2);
+                ckey = KEY_NONE;
+                cslot = -1;
+                cV2 = -1;
+                int ins = (int)0x80000000;
+                if (cM >= 0) {
+                    unsigned long long cm = __ballot(smax == cM);
+                    while (cm) {
+                        int s = __builtin_ctzll(cm);
+                        cm &= cm - 1;
+                        const int dbits = __float_as_int(D.get(s));
+                        bool hit = dbits == cM;
+                        int tl = tid;
+                        asm volatile("" : "+v"(tl)); // keep the perm address out of the loop-carried VGPRs
+                        uint32_t key = hit ? fps_key(perm[s * NT + tl], L) : KEY_NONE;
+                        int d1, d2;
+                        uint32_t kmin; // tie key among the hits + runner-up inside the slot, one butterfly
+                        wave_top2_i32_min_u32(dbits, key, d1, d2, kmin);
+                        if (kmin < ckey) {
+                            ckey = kmin;
+                            cslot = s;
+                            ins = d2;
+                            const int owner = __builtin_ctzll(__ballot(key == kmin));
+                            cx = read_lane(X.get(s), owner);
+                            cy = read_lane(Y.get(s), owner);
+                            cz = read_lane(Z.get(s), owner);
+                        }
                     }
                 }
+                // runner-up bound: the best of the other slots' maxima (= m2: equal maxima count twice) and of
+                // the candidate slot without its owner (= the slot's second value, again as a multiset)
+                if (ckey == KEY_NONE) cM = -1;
+                else cV2 = max(max(m2, ins), -1);
             }
-            if (ckey == KEY_NONE) cM = -1;
-            else {
-                // runner-up bound: best of the other slots' maxima and of the candidate slot without its owner
-                int oth = __builtin_amdgcn_readfirstlane(wave_max_i32_fast(lane == cslot ? (int)0x80000000 : smax));
-                int ins = __builtin_amdgcn_readfirstlane(
-                    wave_max_i32_fast(lane == owner ? (int)0x80000000 : __float_as_int(D.get(cslot))));
-                cV2 = max(max(oth, ins), -1);
+#ifdef GEOT_LAB_STAMPS
+            {
+                unsigned long long work = __builtin_readcyclecounter() - w0;
+                if (redo_acc) { wredo += work; ++nredo; }
+                if (lane == 0) atomicMax(&lab_max, (unsigned int)work);
             }
-        }
-        GEOT_STAMP(tB);
-        if (lane == 0) {
-            FpsEntry2 *mine = &exch2[par][wave];
-            mine->hi = (uint32_t)(cM + 1); mine->lo = ~ckey;
-            mine->x = cx; mine->y = cy; mine->z = cz; mine->v2 = cV2;
-        }
-        __syncthreads();
-        GEOT_STAMP(tC);
-        // -- wave 0 alone ranks the wave candidates and builds the conflict matrix (12 waves doing this
-        //    redundantly would just fight over the VALU issue slots); everybody else waits at a second
-        //    barrier and then reads the committed samples.
-        const FpsEntry2 *ex = exch2[par];
-        par ^= 1;
-        if (wave == 0) {
-            FpsEntry2 e = ex[lane & 15];
-            if ((lane & 15) >= NW) { e.hi = 0u; e.lo = 0u; }
-            const unsigned long long mine64 = ((unsigned long long)e.hi << 32) | e.lo;
-            int rank = 0; // (hi:lo) descending; rank = number of strictly better candidates
-#pragma unroll
-            for (int w0 = 0; w0 < NW; w0 += 4) { // wave-uniform (broadcast) LDS reads, four in flight
-                unsigned long long oth[4];
-#pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    oth[w] = w0 + w < NW ? *reinterpret_cast<const unsigned long long *>(&ex[w0 + w]) : 0ull;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) rank += oth[w] > mine64 ? 1 : 0;
-            }
-            const int nvalid = __popcll(__ballot(lane < NW && e.hi != 0u));
-            if (lane < NW && e.hi != 0u && rank < TMAX) srt[rank] = e;
-            // conflict matrix: lane p = (t = p / 8, s = p % 8), s < t
-            const int ct = lane >> 3, cs = lane & 7;
-            bool conflict = false;
-            if (cs < ct && ct < nvalid && ct < TMAX) {
-                const FpsEntry2 a = srt[cs], b = srt[ct];
-                const int Mt = (int)b.hi - 1;
-                const float d = sqdist3(b.x, b.y, b.z, a.x, a.y, a.z); // point first, sample second: as the update
-                conflict = !(__float_as_int(d) >= Mt && d >= 0.f) || !(a.v2 < Mt);
-            }
-            const unsigned long long cmask = __ballot(conflict);
-            int tn = 1;
-            if (nvalid > 0) {
-                int lim = min(min(nvalid, TMAX), m - j);
-                // first row t >= 1 with any conflict bit: fold every byte of the matrix onto its bit 0
-                unsigned long long rows = cmask;
-                rows |= rows >> 4; rows |= rows >> 2; rows |= rows >> 1;
-                rows &= 0x0101010101010100ull;
-                int first_bad = rows ? (__builtin_ctzll(rows) >> 3) : 8;
-                tn = min(lim, first_bad);
-                if (lane < tn) out[j + lane] = base + (int)fps_key_decode(~srt[lane].lo, L);
-            } else { // nobody has a candidate (e.g. every point origin-skipped): the sample is index 0
-                if (lane == 0) {
-                    out[j] = base;
-                    srt[0].x = P[0]; srt[0].y = P[1]; srt[0].z = P[2];
-                }
-            }
-            if (lane == 0) res_tn = tn;
-        }
-        __syncthreads();
-        {
-            FpsEntry2 c[TMAX];
-#pragma unroll
-            for (int u = 0; u < TMAX; ++u) c[u] = srt[u]; // wave-uniform, batched (stale beyond Tn: unused)
-            Tn = __builtin_amdgcn_readfirstlane(res_tn);
-#pragma unroll
-            for (int u = 0; u < TMAX; ++u) {
-                if (u < Tn) { qx[u] = uniform(c[u].x); qy[u] = uniform(c[u].y); qz[u] = uniform(c[u].z); }
-            }
-        }
-#ifdef GEOT_LAB_STATS
-        if (tid == 0) { atomicAdd(&geot_fps_dbg[2], (unsigned long long)Tn); atomicAdd(&geot_fps_dbg[3], 1ull); }
 #endif
-        j += Tn;
-        GEOT_STAMP(tD);
-    }
-    // The reference's temp buffer ends as "min-distance to samples 0..m-2" (the last pick is never
-    // applied).  The final round may have committed several samples: apply all but the last one.
-#pragma unroll
-    for (int u = 0; u < TMAX; ++u) {
-        if (u < Tn - 1) {
-            float dx = fmaxf(fmaxf(bx0 - qx[u], qx[u] - bx1), 0.f);
-            float dy = fmaxf(fmaxf(by0 - qy[u], qy[u] - by1), 0.f);
-            float dz = fmaxf(fmaxf(bz0 - qz[u], qz[u] - bz1), 0.f);
-            float lb2 = dx * dx + dy * dy + dz * dz;
-            unsigned long long mask = __ballot(!(lb2 > __int_as_float(smax) * 1.00001f));
-            while (mask) {
-                int s = __builtin_ctzll(mask);
-                mask &= mask - 1;
-                float d = sqdist3(X.get(s), Y.get(s), Z.get(s), qx[u], qy[u], qz[u]);
-                D.set(s, fmin_raw(d, D.get(s)));
+            redo_acc = false;
+            GEOT_STAMP(tB);
+            if (lane == 0) {
+                FpsEntry2 *mine = &exch2[par][wave];
+                mine->hi = (uint32_t)(cM + 1); mine->lo = ~ckey;
+                mine->x = cx; mine->y = cy; mine->z = cz; mine->v2 = cV2;
+                lds_max_u64(&best[par], ((unsigned long long)(uint32_t)(cM + 1) << 32) | (uint32_t)~ckey);
             }
+            __syncthreads();
+            GEOT_STAMP(tC);
+            const FpsEntry2 *ex = exch2[par];
+            // Opaque copy of the lane id: everything derived from it below (LDS addresses, lane predicates)
+            // is loop-invariant, and LLVM would hoist a dozen such values into VGPRs this kernel does not
+            // have (128 of 168 hold the points); recomputing them costs a few VALU per round.
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            early = false;
+            ua = 0; ub = 0;
+            if (wave != 0) {
+                if (j + 1 < m) { // otherwise the top candidate is the LAST sample, which is never applied
+                    // keys are unique, so the low word of the arg-max identifies the winning wave
+                    const unsigned long long bw = best[par];
+                    const uint32_t elo = ex[ln & 15].lo;
+                    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(bw >> 32));
+                    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)bw);
+                    if (bhi != 0u) {
+                        const int wl = __builtin_ctzll(__ballot(elo == blo) & ((1ull << NW) - 1ull));
+                        qxv = ex[wl].x; qyv = ex[wl].y; qzv = ex[wl].z; // every lane: only lane 0 is read back
+                        early = true;
+                        ub = 1;
+                    }
+                }
+            } else {
+                // -- wave 0 alone ranks the wave candidates and builds the conflict matrix (12 waves doing
+                //    this redundantly would just fight over the VALU issue slots)
+                FpsEntry2 e = ex[ln & 15];
+                if ((ln & 15) >= NW) { e.hi = 0u; e.lo = 0u; }
+                const unsigned long long mine64 = ((unsigned long long)e.hi << 32) | e.lo;
+                int rank = 0; // (hi:lo) descending; rank = number of strictly better candidates
+#pragma unroll
+                for (int w = 0; w < NW; ++w) { // the other candidates come over v_readlane, not LDS
+                    const unsigned long long o =
+                        ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)e.hi, w) << 32) |
+                        (uint32_t)__builtin_amdgcn_readlane((int)e.lo, w);
+                    rank += o > mine64 ? 1 : 0;
+                }
+                const int nvalid = __popcll(__ballot(ln < NW && e.hi != 0u));
+                // sort: lane w pushes its entry to lane rank(w) (ds_permute; lanes >= 16 hold copies and push
+                // the same values to the same place; invalid entries all rank nvalid, outside the prefix)
+                const int dst = rank << 2;
+                const uint32_t s_hi = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)e.hi);
+                const uint32_t s_lo = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)e.lo);
+                const float s_x = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(e.x)));
+                const float s_y = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(e.y)));
+                const float s_z = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(e.z)));
+                const int s_v2 = __builtin_amdgcn_ds_permute(dst, e.v2);
+                if (ln < TMAX) { srt[ln].x = s_x; srt[ln].y = s_y; srt[ln].z = s_z; } // for the other waves
+                // conflict matrix: lane p = (t = p / 8, s = p % 8), s < t; operands pulled with ds_bpermute
+                const int ct = ln >> 3, cs = ln & 7;
+                const float a_x = __int_as_float(__builtin_amdgcn_ds_bpermute(cs << 2, __float_as_int(s_x)));
+                const float a_y = __int_as_float(__builtin_amdgcn_ds_bpermute(cs << 2, __float_as_int(s_y)));
+                const float a_z = __int_as_float(__builtin_amdgcn_ds_bpermute(cs << 2, __float_as_int(s_z)));
+                const int a_v2 = __builtin_amdgcn_ds_bpermute(cs << 2, s_v2);
+                const float b_x = __int_as_float(__builtin_amdgcn_ds_bpermute(ct << 2, __float_as_int(s_x)));
+                const float b_y = __int_as_float(__builtin_amdgcn_ds_bpermute(ct << 2, __float_as_int(s_y)));
+                const float b_z = __int_as_float(__builtin_amdgcn_ds_bpermute(ct << 2, __float_as_int(s_z)));
+                const int Mt = __builtin_amdgcn_ds_bpermute(ct << 2, (int)s_hi) - 1;
+                bool conflict = false;
+                if (cs < ct && ct < nvalid && ct < TMAX) {
+                    const float d = sqdist3(b_x, b_y, b_z, a_x, a_y, a_z); // point first, sample second: as the update
+                    conflict = !(__float_as_int(d) >= Mt && d >= 0.f) || !(a_v2 < Mt);
+                }
+                const unsigned long long cmask = __ballot(conflict);
+                int tn = 1;
+                if (nvalid > 0) {
+                    int lim = min(min(nvalid, TMAX), m - j);
+                    // first row t >= 1 with any conflict bit: fold every byte of the matrix onto its bit 0
+                    unsigned long long rows = cmask;
+                    rows |= rows >> 4; rows |= rows >> 2; rows |= rows >> 1;
+                    rows &= 0x0101010101010100ull;
+                    int first_bad = rows ? (__builtin_ctzll(rows) >> 3) : 8;
+                    tn = min(lim, first_bad);
+                    if (ln < tn) out[j + ln] = base + (int)fps_key_decode(~s_lo, L);
+                } else { // nobody has a candidate (e.g. every point origin-skipped): the sample is index 0
+                    if (ln == 0) {
+                        out[j] = base;
+                        srt[0].x = P[0]; srt[0].y = P[1]; srt[0].z = P[2];
+                    }
+                }
+                if (ln == 0) res_tn = tn;
+            }
+            phase = 1;
+        } else {
+            __syncthreads();
+            if (tid == 0) best[par] = 0ull; // next used by the publish of round + 2, i.e. after the next barrier
+            par ^= 1;
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            const FpsEntry2 *cq = &srt[ln < TMAX ? ln : 0]; // lane u <- sample u (stale beyond Tn: unused)
+            qxv = cq->x; qyv = cq->y; qzv = cq->z;
+            Tn = __builtin_amdgcn_readfirstlane(res_tn);
+#ifdef GEOT_LAB_STATS
+            if (tid == 0) { atomicAdd(&geot_fps_dbg[2], (unsigned long long)Tn); atomicAdd(&geot_fps_dbg[3], 1ull); }
+#endif
+            j += Tn;
+            // The reference's temp buffer ends as "min-distance to samples 0..m-2": the last pick of the
+            // whole run is never applied.
+            done = j >= m;
+            ua = early ? 1 : 0;
+            ub = done ? Tn - 1 : Tn;
+            phase = 0;
+            GEOT_STAMP(tD);
+#ifdef GEOT_LAB_STAMPS
+            if (tid == 0) { tE += lab_max; lab_max = 0; } // lab_max was final at barrier 1; next atomics come after this
+            w0 = __builtin_readcyclecounter();
+#endif
         }
     }
+#undef GEOT_APPLY
+#undef GEOT_APPLY_STAT
 #ifdef GEOT_LAB_STAMPS
     if (lane == 0) {
         atomicAdd(&geot_fps_dbg[0], tA); atomicAdd(&geot_fps_dbg[1], tB); atomicAdd(&geot_fps_dbg[2], tC);
         atomicAdd(&geot_fps_dbg[3], tD); atomicAdd(&geot_fps_dbg[4], tE); atomicAdd(&geot_fps_dbg[5], (unsigned long long)(m - 1));
+        atomicAdd(&geot_fps_dbg[7], (wredo << 24) | nredo); // lab only: both fit (cycles < 2^40, rounds < 2^24)
         if (tid == 0) atomicAdd(&geot_fps_dbg[6], rounds);
     }
 #endif

@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LAB = os.path.join(ROOT, "tools", "_lab")
 VARIANTS = {
     "base": [],
-    "stats": ["-DGEOT_LAB_STATS", "-DGEOT_FP_TMAX=8"],
+    "stats": ["-DGEOT_LAB_STATS"],
     "stamps": ["-DGEOT_LAB_STAMPS"],
-    "t8": ["-DGEOT_FP_TMAX=8"],
+    "t6": ["-DGEOT_FP_TMAX=6"],
 }
 for extra in sys.argv[2:]:
     if "=" in extra:
@@ -76,6 +76,9 @@ def run():
                       "publish+barrier %.0f  resolve %.0f  total %.0f  => %.0f cycles/sample"
                       % (m, (m - 1) / rounds, st[0] / wr, st[1] / wr, st[2] / wr, st[3] / wr, sum(st[:4]) / wr,
                          sum(st[:4]) / wr * rounds / (m - 1)), flush=True)
+                nred, wred = st[7] & 0xFFFFFF, st[7] >> 24
+                print("      slowest wave's apply+search per round %.0f cycles; waves that re-searched: %.2f per round, "
+                      "their apply+search %.0f cycles" % (st[4] / rounds, nred / rounds, wred / max(nred, 1)), flush=True)
                 continue
             if name == "stats":
                 st = (ctypes.c_ulonglong * 8)()
