@@ -44,6 +44,8 @@ PROTOTYPES = {
 PROTOTYPES.update({
     "geot_group_points_grad_ws": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_three_interpolate_grad_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_knn_sorted_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
+    "geot_three_nn_ws": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_graph_feature": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_graph_feature_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
@@ -59,6 +61,8 @@ PROTOTYPES.update({
 # entry points that do not follow the "(..., stream) -> hipError_t" shape
 PLAIN = {
     "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),
+    "geot_knn_grid_ws_bytes": ([_c_int, _c_int], ctypes.c_longlong),
+    "geot_knn_grid_eligible": ([_c_int, _c_int, _c_int, _c_int], _c_int),
 }
 
 _lib = None

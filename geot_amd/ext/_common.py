@@ -59,3 +59,15 @@ def call(name, dev, *args):
 
 def ptr(t):
     return t.data_ptr() if t is not None else None
+
+
+def knn_workspace(dev, b, nq, nr, k):
+    """(ptr, bytes) of scratch for the grid kNN path, or (None, 0) when the sizes do not qualify
+    (the C entry point then runs the brute-force kernel).  The tensor is returned too so that it stays
+    alive until the launch has been queued (torch's allocator is stream-ordered after that)."""
+    lib = _lib.load()
+    if not lib.geot_knn_grid_eligible(int(b), int(nq), int(nr), int(k)):
+        return None, 0, None
+    nbytes = int(lib.geot_knn_grid_ws_bytes(int(b), int(nr)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return ws.data_ptr(), nbytes, ws

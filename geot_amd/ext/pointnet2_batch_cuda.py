@@ -9,7 +9,7 @@ tensors and raises RuntimeError.  Outputs may be uninitialised
 """
 import torch
 
-from ._common import f32, i32, same_device, need, call, ptr
+from ._common import f32, i32, same_device, need, call, ptr, knn_workspace
 
 
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
@@ -75,7 +75,8 @@ def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
     dev = same_device(unknown, known, dist2, idx)
     need(unknown.numel() == b * n * 3 and known.numel() == b * m * 3 and dist2.numel() == b * n * 3
          and idx.numel() == b * n * 3, "three_nn size mismatch")
-    call("geot_three_nn", dev, b, n, m, ptr(unknown), ptr(known), ptr(dist2), ptr(idx))
+    wp, wb, _keep = knn_workspace(dev, b, n, m, 3)
+    call("geot_three_nn_ws", dev, b, n, m, ptr(unknown), ptr(known), ptr(dist2), ptr(idx), wp, wb)
 
 
 def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):

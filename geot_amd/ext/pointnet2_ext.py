@@ -8,7 +8,7 @@ ball_query.cpp:22-24; group_points.cpp:25-27,50-52; interpolate.cpp:26-31,58-60,
 """
 import torch
 
-from ._common import f32, i32, same_device, need, call, ptr
+from ._common import f32, i32, same_device, need, call, ptr, knn_workspace
 
 
 def gather_points(points, idx):
@@ -52,7 +52,8 @@ def three_nn(unknowns, knows):
     m = knows.shape[1]
     idx = torch.zeros((b, n, 3), dtype=torch.int32, device=dev)
     dist2 = torch.zeros((b, n, 3), dtype=torch.float32, device=dev)
-    call("geot_three_nn", dev, b, n, m, ptr(unknowns), ptr(knows), ptr(dist2), ptr(idx))
+    wp, wb, _keep = knn_workspace(dev, b, n, m, 3)
+    call("geot_three_nn_ws", dev, b, n, m, ptr(unknowns), ptr(knows), ptr(dist2), ptr(idx), wp, wb)
     return [dist2, idx]
 
 

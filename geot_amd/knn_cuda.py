@@ -12,7 +12,7 @@ Only D == 3 is accelerated, which is all the reference uses.
 import torch
 import torch.nn as nn
 
-from .ext._common import f32, same_device, need, call, ptr
+from .ext._common import f32, same_device, need, call, ptr, knn_workspace
 
 
 def knn_sorted(query, ref, k):
@@ -24,7 +24,8 @@ def knn_sorted(query, ref, k):
     nr = ref.shape[1]
     idx = torch.empty((b, nq, k), dtype=torch.int32, device=dev)
     dist2 = torch.empty((b, nq, k), dtype=torch.float32, device=dev)
-    call("geot_knn_sorted", dev, b, nq, nr, int(k), ptr(query), ptr(ref), ptr(idx), ptr(dist2))
+    wp, wb, _keep = knn_workspace(dev, b, nq, nr, int(k))   # grid search when the problem is big enough
+    call("geot_knn_sorted_ws", dev, b, nq, nr, int(k), ptr(query), ptr(ref), ptr(idx), ptr(dist2), wp, wb)
     return dist2, idx
 
 

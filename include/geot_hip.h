@@ -92,6 +92,19 @@ int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad
                                    const float *weight, float *grad_points, float *workspace,
                                    void *stream);
 
+/* Grid-accelerated variants of geot_knn_sorted / geot_three_nn (geot_amd/csrc/knn_grid.hip): identical
+ * outputs, bit for bit, but only the cells around each query are visited (exact: the search widens until
+ * the k-th distance is strictly inside the visited block).  workspace = geot_knn_grid_ws_bytes(b, nr)
+ * bytes of 16-byte-aligned scratch (contents irrelevant on entry).  Falls back to the brute-force kernel
+ * when workspace is NULL / too small or geot_knn_grid_eligible(b, nq, nr, k) is 0 (small problems, k > 64,
+ * or GEOT_NN_IMPL=basic|wave in the environment; GEOT_NN_IMPL=grid forces the grid where it is valid). */
+long long geot_knn_grid_ws_bytes(int b, int nr);
+int geot_knn_grid_eligible(int b, int nq, int nr, int k);
+int geot_knn_sorted_ws(int b, int nq, int nr, int k, const float *query, const float *ref, int *idx,
+                       float *dist2, void *workspace, long long ws_bytes, void *stream);
+int geot_three_nn_ws(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
+                     void *workspace, long long ws_bytes, void *stream);
+
 /* EdgeConv graph feature = DGCNN_Propagation.get_graph_feature
  * (openpoints/models/backbone/transformer.py:343-364: transpose + fancy-index gather + permute +
  * expand + cat), in one pass:  x_q (b,c,nq), x_k (b,c,nk), idx (b,nq,k) int32 neighbours in x_k ->

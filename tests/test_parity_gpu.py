@@ -435,3 +435,72 @@ def test_bad_arguments_raise(ext):
         ext.p2.gather_points(torch.zeros(1, 2, 8, device=DEV), torch.zeros(1, 4, dtype=torch.int64, device=DEV))
     with pytest.raises(RuntimeError):
         ext.p2.ball_query(x, x, 0.1, 10 ** 6)  # nsample beyond the LDS budget -> hipErrorInvalidValue
+
+
+# ---- grid kNN: bit-identical to the brute-force kernels -----------------------------------------
+def _adversarial_clouds(rng, n):
+    """Reference sets that stress the grid: volume, surface, clusters, a line, a plane with exact ties
+    (lattice), heavy duplicates, one far outlier (almost every cell empty), tiny extent."""
+    u = rng.random((n, 3)).astype(np.float32)
+    sph = rng.standard_normal((n, 3)).astype(np.float32)
+    sph /= np.linalg.norm(sph, axis=1, keepdims=True)
+    clus = (rng.integers(0, 5, (n, 1)) * 0.2 + rng.standard_normal((n, 3)) * 0.003).astype(np.float32)
+    line = np.zeros((n, 3), np.float32); line[:, 0] = np.linspace(-1, 1, n, dtype=np.float32)
+    side = int(np.ceil(np.sqrt(n)))
+    gx, gy = np.meshgrid(np.arange(side, dtype=np.float32), np.arange(side, dtype=np.float32))
+    lattice = np.stack([gx.ravel()[:n] / 64, gy.ravel()[:n] / 64, np.zeros(n, np.float32)], 1)   # exact ties
+    dup = u.copy(); dup[n // 2:] = dup[rng.integers(0, n // 2, n - n // 2)]
+    outl = u * 0.01; outl[7] = (50.0, -30.0, 10.0)
+    tiny = (1.0 + u * 1e-6).astype(np.float32)
+    return {"volume": u, "sphere": sph, "clusters": clus, "line": line, "lattice": lattice, "dups": dup,
+            "outlier": outl.astype(np.float32), "tiny": tiny}
+
+
+@pytest.mark.parametrize("k", [1, 3, 4, 33, 64])
+def test_knn_grid_matches_bruteforce_bit_for_bit(ext, k, monkeypatch):
+    from geot_amd.knn_cuda import knn_sorted
+    from geot_amd import _lib
+    rng = np.random.default_rng(100 + k)
+    n = 6000
+    clouds = _adversarial_clouds(rng, n)
+    names = list(clouds)
+    ref = np.stack([clouds[c] for c in names])                          # (8, n, 3)
+    # queries: the references themselves (self-kNN), points far outside the box, and random ones
+    q_out = (rng.standard_normal((len(names), 200, 3)) * 5).astype(np.float32)
+    qry = np.concatenate([ref[:, :1500], q_out, ref[:, -300:] + np.float32(1e-3)], 1)
+    monkeypatch.setenv("GEOT_NN_IMPL", "grid")
+    assert _lib.load().geot_knn_grid_eligible(len(names), qry.shape[1], n, k) == 1
+    d_g, i_g = knn_sorted(dev(qry), dev(ref), k)
+    monkeypatch.setenv("GEOT_NN_IMPL", "wave")
+    assert _lib.load().geot_knn_grid_eligible(len(names), qry.shape[1], n, k) == 0
+    d_b, i_b = knn_sorted(dev(qry), dev(ref), k)
+    for c, name in enumerate(names):
+        assert torch.equal(i_g[c], i_b[c]), name
+        assert torch.equal(d_g[c], d_b[c]), name
+
+
+def test_knn_grid_full_size_vs_oracle_and_three_nn(ext, oracle):
+    from geot_amd.knn_cuda import knn_sorted
+    from geot_amd import _lib
+    xyz, _ = make_batch(2, 24000, start_index=5, dup_frac=0.01)
+    d, i = knn_sorted(dev(xyz[:, :3000]), dev(xyz), 33)                 # threeD_space_loss shape, a slice of queries
+    wi, wd = oracle.knn_sorted(xyz[:, :3000], xyz, 33)
+    assert np.array_equal(host(i), wi) and np.array_equal(host(d), wd)
+    known = xyz[:, ::3].copy()                                          # 8000 known points: grid path for k = 3
+    assert _lib.load().geot_knn_grid_eligible(2, 24000, 8000, 3) == 1
+    d3, i3 = ext.p2.three_nn(dev(xyz), dev(known))
+    wd3, wi3 = oracle.three_nn(xyz, known)
+    assert np.array_equal(host(i3), wi3) and np.array_equal(host(d3), wd3)
+    # fewer references than k, NaN / Inf coordinates: same (inf, 0) padding as the brute-force kernel
+    few = xyz[:, :2100].copy()
+    few[0, 5] = np.nan; few[1, 9, 0] = np.inf
+    q = xyz[:, :2000].copy(); q[0, 3] = np.nan; q[1, 4, 2] = -np.inf
+    import os
+    os.environ["GEOT_NN_IMPL"] = "grid"
+    try:
+        dg, ig = knn_sorted(dev(q), dev(few), 64)
+        os.environ["GEOT_NN_IMPL"] = "wave"
+        db, ib = knn_sorted(dev(q), dev(few), 64)
+    finally:
+        del os.environ["GEOT_NN_IMPL"]
+    assert torch.equal(ig, ib) and torch.equal(torch.nan_to_num(dg, nan=-1.0), torch.nan_to_num(db, nan=-1.0))
