@@ -19,7 +19,10 @@
 namespace geot {
 
 constexpr int NTM_THREADS = 256;
-constexpr int NTM_TILE = 64; // points per LDS tile
+constexpr int NTM_TILE = 32; // points per LDS tile (32: 48-58 KB of LDS per block => 2-3 blocks per CU; 64 allowed one)
+constexpr int NTM_GROUPS = NTM_THREADS / NTM_TILE; // row groups: thread = (point, group)
+constexpr int NTM_TILE_SHIFT = 5;
+static_assert((1 << NTM_TILE_SHIFT) == NTM_TILE, "tile shift");
 
 template <int C>
 struct NtmLds {
@@ -65,7 +68,7 @@ __global__ __launch_bounds__(NTM_THREADS) void sig_t_mean_kernel(
         bias[e] = acc;
     }
     __syncthreads();
-    const int pt = threadIdx.x & (NTM_TILE - 1), grp = threadIdx.x >> 6; // 4 row groups
+    const int pt = threadIdx.x & (NTM_TILE - 1), grp = threadIdx.x >> NTM_TILE_SHIFT;
     for (int i0 = blockIdx.x * NTM_TILE; i0 < total_pts; i0 += gridDim.x * NTM_TILE) {
         const int cnt = min(NTM_TILE, total_pts - i0);
         if (BACKWARD) {
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(NTM_THREADS) void sig_t_mean_kernel(
             float pv[C];
 #pragma unroll
             for (int j = 0; j < C; ++j) pv[j] = p[((size_t)b * C + j) * n + ni];
-            for (int kk = grp; kk < C; kk += 4) {
+            for (int kk = grp; kk < C; kk += NTM_GROUPS) {
                 float raw[C], s = 0.f;
 #pragma unroll
                 for (int o = 0; o < C; ++o) {
@@ -123,11 +126,11 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
     extern __shared__ float ntm_lds[];
     float *El = ntm_lds;                         // [CC]
     float *accE = El + CC;                       // [CC] block partial of grad_E (backward)
-    float *part = accE + CC;                     // [4][NTM_TILE][C] partial outputs per row group
-    float *tile = part + 4 * NTM_TILE * C;       // [NTM_TILE][STRIDE]
+    float *part = accE + CC;                     // [NTM_GROUPS][NTM_TILE][C] partial outputs per row group
+    float *tile = part + NTM_GROUPS * NTM_TILE * C; // [NTM_TILE][STRIDE]
     for (int e = threadIdx.x; e < CC; e += NTM_THREADS) { El[e] = E[e]; accE[e] = 0.f; }
     __syncthreads();
-    const int pt = threadIdx.x & (NTM_TILE - 1), grp = threadIdx.x >> 6;
+    const int pt = threadIdx.x & (NTM_TILE - 1), grp = threadIdx.x >> NTM_TILE_SHIFT;
     for (int i0 = blockIdx.x * NTM_TILE; i0 < total_pts; i0 += gridDim.x * NTM_TILE) {
         const int cnt = min(NTM_TILE, total_pts - i0);
         ntm_tile_copy<C, true>(const_cast<float *>(insT) + (size_t)i0 * CC, tile, cnt);
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
 #pragma unroll
                 for (int c = 0; c < C; ++c) go[c] = grad_out[((size_t)b * C + c) * n + ni];
             }
-            for (int r = grp; r < C; r += 4) {
+            for (int r = grp; r < C; r += NTM_GROUPS) {
                 float *row = tile + pt * STRIDE + r * C;
                 const float l = logits[((size_t)b * C + r) * n + ni];
                 float v[C], s = 0.f;
@@ -179,8 +182,9 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
         if (!BACKWARD) {
             for (int e = threadIdx.x; e < cnt * C; e += NTM_THREADS) {
                 int c = e / cnt, q = e - c * cnt; // q fastest: coalesced along the point dimension
-                float v = part[(0 * NTM_TILE + q) * C + c] + part[(1 * NTM_TILE + q) * C + c] +
-                          part[(2 * NTM_TILE + q) * C + c] + part[(3 * NTM_TILE + q) * C + c];
+                float v = 0.f;
+#pragma unroll
+                for (int gq = 0; gq < NTM_GROUPS; ++gq) v += part[(gq * NTM_TILE + q) * C + c];
                 int gi = i0 + q, gb = gi / n, gn = gi - gb * n;
                 out[((size_t)gb * C + c) * n + gn] = v;
             }
@@ -286,7 +290,7 @@ static hipError_t set_lds(K kernel, size_t lds)
 static inline int ntm_blocks(int total_pts)
 {
     int tiles = (total_pts + NTM_TILE - 1) / NTM_TILE;
-    return tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles);
+    return tiles < 1 ? 1 : (tiles > 4096 ? 4096 : tiles);
 }
 
 } // namespace geot
@@ -330,7 +334,7 @@ GEOT_EXPORT int geot_ntm_correct(int b, int n, int c, float lam, const float *lo
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(2 * C * C + 4 * NTM_TILE * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
     hipError_t e = set_lds(ntm_correct_kernel<C, false>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ntm_correct_kernel<C, false>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
@@ -347,7 +351,7 @@ GEOT_EXPORT int geot_ntm_correct_grad(int b, int n, int c, float lam, const floa
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(2 * C * C + 4 * NTM_TILE * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
     hipError_t e = set_lds(ntm_correct_kernel<C, true>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ntm_correct_kernel<C, true>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
