@@ -48,6 +48,7 @@ PROTOTYPES.update({
     "geot_three_nn_ws": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_graph_feature": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_graph_feature_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_sig_t_mean_grad_w": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean_grad_raw": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_correct": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _c_void_p],
@@ -62,6 +63,7 @@ PROTOTYPES.update({
 PLAIN = {
     "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),
     "geot_knn_grid_ws_bytes": ([_c_int, _c_int], ctypes.c_longlong),
+    "geot_ntm_sig_t_mean_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_knn_grid_eligible": ([_c_int, _c_int, _c_int, _c_int], _c_int),
 }
 

@@ -114,6 +114,202 @@ __global__ __launch_bounds__(NTM_THREADS) void sig_t_mean_kernel(
     }
 }
 
+// ---- sig_t_mean on the matrix cores ---------------------------------------------------------
+// The 17 Linear(34 -> 17) heads are one GEMM per tile of 32 points:
+//     raw[pt][col] = sum_k A[pt][k] * Wt[k][col],   col = kk*17 + o (289, padded to 320),
+//     A[pt] = (p_0 .. p_16, 1),  Wt[k<17][col] = W[kk][o][k],  Wt[17][col] = sum_j cm[kk][j] W[kk][o][17+j]
+// i.e. K = 18 = 9 steps of v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation), 10 column
+// tiles shared by the 4 waves of a block.  The 32 x 289 result lands in an LDS tile that is the exact
+// image of the output block, rows are clamped + L1-normalised there by (point, row) threads, and the
+// tile leaves as 16-byte vectors: the kernel is a pure stream of the (B*N, 17, 17) output.
+// BACKWARD never materialises d raw: after recomputing raw it forms d raw in the tile and feeds it
+// straight into a second GEMM  G[k][col] += sum_pt A[pt][k] * draw[pt][col]  (K = the 32 points), whose
+// per-block partial sums are reduced by sig_t_mean_wgrad_reduce_kernel into the (17, 17, 34) weight
+// gradient (columns 17..33 of a head see the constant cm row: G[17][col] * cm[kk][j]).
+typedef float ntm_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SM_PTS = 32;
+
+template <int C>
+struct SigMfma {
+    static constexpr int CC = C * C;
+    static constexpr int KP = C + 1;               // 18: inputs + the constant 1 that carries the cm part
+    static constexpr int NCT = (CC + 31) / 32;     // 10 column tiles
+    static constexpr int CP = NCT * 32;            // 320
+    static constexpr int AT_STRIDE = KP + 1;       // 19 (odd)
+    static constexpr int LDS_FLOATS = KP * CP + SM_PTS * CC + SM_PTS * AT_STRIDE + 64;
+    static_assert(KP % 2 == 0, "K must be even for the 32x32x2 MFMA");
+};
+
+template <int C, bool BACKWARD>
+__global__ __launch_bounds__(256) void sig_t_mean_mfma_kernel(
+    int total_pts, int n, const float *__restrict__ p, const float *__restrict__ W,
+    const float *__restrict__ cm, const float *__restrict__ grad_out, float *__restrict__ out,
+    float *__restrict__ partial)
+{
+    using S = SigMfma<C>;
+    constexpr int CC = S::CC, KP = S::KP, CP = S::CP, NCT = S::NCT, ATS = S::AT_STRIDE;
+    constexpr int MYCT = (NCT + 3) / 4; // column tiles per wave (3, 3, 2, 2)
+    extern __shared__ float ntm_lds[];
+    float *Wt = ntm_lds;              // [KP][CP]
+    float *tile = Wt + KP * CP;       // [SM_PTS][CC]  (contiguous = the global layout of the block)
+    float *At = tile + SM_PTS * CC;   // [SM_PTS][ATS] (+ slack: the padded columns of the last row read past `tile`)
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int e = tid; e < KP * CP; e += 256) {
+        const int k = e / CP, col = e - k * CP;
+        float v = 0.f;
+        if (col < CC) {
+            if (k < C) v = W[(size_t)col * 2 * C + k];
+            else {
+                const int kk = col / C;
+                for (int j = 0; j < C; ++j) v += cm[kk * C + j] * W[(size_t)col * 2 * C + C + j];
+            }
+        }
+        Wt[e] = v;
+    }
+    for (int e = tid; e < SM_PTS * ATS + 64; e += 256) At[e] = 0.f;
+    ntm_f32x16 gacc[MYCT];
+#pragma unroll
+    for (int t = 0; t < MYCT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) gacc[t][e] = 0.f;
+    __syncthreads();
+
+    for (int i0 = blockIdx.x * SM_PTS; i0 < total_pts; i0 += gridDim.x * SM_PTS) {
+        const int cnt = min(SM_PTS, total_pts - i0);
+        // A fragment: lane (r = point, h) holds A[r][2*ks + h]
+        float a[KP / 2];
+        {
+            const int i = i0 + r;
+            const bool ok = r < cnt;
+            const int b = ok ? i / n : 0, ni = ok ? i - b * n : 0;
+#pragma unroll
+            for (int ks = 0; ks < KP / 2; ++ks) {
+                const int k = 2 * ks + h;
+                a[ks] = !ok ? 0.f : (k < C ? p[((size_t)b * C + k) * n + ni] : 1.f);
+                if (BACKWARD && wave == 0) At[r * ATS + k] = a[ks];
+            }
+        }
+        ntm_f32x16 acc[MYCT];
+#pragma unroll
+        for (int t = 0; t < MYCT; ++t) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KP / 2; ++ks) {
+#pragma unroll
+            for (int t = 0; t < MYCT; ++t) {
+                const int ct = wave + 4 * t;
+                if (ct < NCT) {
+                    const float bv = Wt[(2 * ks + h) * CP + ct * 32 + r];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        // D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
+#pragma unroll
+        for (int t = 0; t < MYCT; ++t) {
+            const int col = (wave + 4 * t) * 32 + r;
+            if (wave + 4 * t < NCT && col < CC) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * CC + col] = acc[t][e];
+            }
+        }
+        __syncthreads();
+        // (point, row) threads: clamp + L1-normalise (forward) or d raw (backward), in place
+        for (int rr = tid; rr < SM_PTS * C; rr += 256) {
+            const int pt = rr & (SM_PTS - 1), kk = rr >> 5;
+            float *row = tile + pt * CC + kk * C;
+            float raw[C], s = 0.f;
+#pragma unroll
+            for (int o = 0; o < C; ++o) {
+                raw[o] = row[o];
+                s += fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f); // clamped values are positive
+            }
+            const float den = fmaxf(s, 1e-12f);
+            if (!BACKWARD) {
+#pragma unroll
+                for (int o = 0; o < C; ++o) row[o] = fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) / den;
+            } else if (pt < cnt) {
+                const float *g = grad_out + ((size_t)(i0 + pt) * C + kk) * C;
+                float gv[C], dot = 0.f;
+#pragma unroll
+                for (int o = 0; o < C; ++o) {
+                    gv[o] = g[o];
+                    dot += gv[o] * (fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) / den);
+                }
+#pragma unroll
+                for (int o = 0; o < C; ++o) {
+                    const bool inside = raw[o] >= 1e-5f && raw[o] <= 1.f - 1e-5f;
+                    row[o] = inside ? (gv[o] - dot) / den : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int o = 0; o < C; ++o) row[o] = 0.f;
+            }
+        }
+        __syncthreads();
+        if (!BACKWARD) {
+            float *dst = out + (size_t)i0 * CC; // 16-byte aligned: i0 is a multiple of 32
+            const int total = cnt * CC, vec = total >> 2;
+            for (int e = tid; e < vec; e += 256)
+                reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(tile)[e];
+            for (int e = (vec << 2) + tid; e < total; e += 256) dst[e] = tile[e];
+        } else {
+            // G[k][col] += sum_pt A[pt][k] * draw[pt][col]:  M = k (rows r < 18 used), K = point
+#pragma unroll
+            for (int ks = 0; ks < SM_PTS / 2; ++ks) {
+                const int pt = 2 * ks + h;
+                const float av = r < KP ? At[pt * ATS + r] : 0.f;
+#pragma unroll
+                for (int t = 0; t < MYCT; ++t) {
+                    const int ct = wave + 4 * t;
+                    if (ct < NCT) {
+                        const float bv = tile[pt * CC + ct * 32 + r]; // cols >= 289: junk, discarded below
+                        gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, gacc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (BACKWARD) {
+        float *P = partial + (size_t)blockIdx.x * KP * CC;
+#pragma unroll
+        for (int t = 0; t < MYCT; ++t) {
+            const int col = (wave + 4 * t) * 32 + r;
+            if (wave + 4 * t < NCT && col < CC) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int k = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    if (k < KP) P[k * CC + col] = gacc[t][e];
+                }
+            }
+        }
+    }
+}
+
+// grad_W[kk][o][j] += sum_blk partial[blk][j][col];  grad_W[kk][o][C+j] += cm[kk][j] * sum_blk partial[blk][C][col]
+template <int C>
+__global__ __launch_bounds__(256) void sig_t_mean_wgrad_reduce_kernel(int nblk, const float *__restrict__ partial,
+                                                                      const float *__restrict__ cm,
+                                                                      float *__restrict__ grad_W)
+{
+    constexpr int CC = C * C, KP = C + 1;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= KP * CC) return;
+    const int k = e / CC, col = e - k * CC;
+    float s = 0.f;
+    for (int bkt = 0; bkt < nblk; ++bkt) s += partial[(size_t)bkt * KP * CC + e];
+    if (k < C) grad_W[(size_t)col * 2 * C + k] += s;
+    else {
+        const int kk = col / C;
+        for (int j = 0; j < C; ++j) grad_W[(size_t)col * 2 * C + C + j] += cm[kk * C + j] * s;
+    }
+}
+
 // ---- logit correction ----------------------------------------------------------------------
 // v = lam*E + (1-lam)*T_i; tn = v / max(sum_c |v|, eps); out[c] = sum_r logit[r] * tn[r][c].
 template <int C, bool BACKWARD>
@@ -299,17 +495,47 @@ using namespace geot;
 
 #define GEOT_NTM_C 17 /* the reference's num_classes (cfgs/tooth_semi/default.yaml:29) */
 
+static inline int sig_mfma_blocks(long long total_pts)
+{
+    long long tiles = (total_pts + SM_PTS - 1) / SM_PTS;
+    return (int)(tiles < 1 ? 1 : (tiles > 512 ? 512 : tiles)); // 2 blocks per CU x 256 CUs
+}
+
 GEOT_EXPORT int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const float *W, const float *cm,
                                     float *ins_T, void *stream)
 {
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(C * C * C + C * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
-    hipError_t e = set_lds(sig_t_mean_kernel<C, false>, lds);
+    size_t lds = (size_t)SigMfma<C>::LDS_FLOATS * sizeof(float);
+    hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sig_t_mean_kernel<C, false>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
-                       (hipStream_t)stream, b * n, n, p, W, cm, nullptr, ins_T);
+    hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, false>), dim3(sig_mfma_blocks((long long)b * n)), dim3(256), lds,
+                       (hipStream_t)stream, b * n, n, p, W, cm, nullptr, ins_T, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT long long geot_ntm_sig_t_mean_ws_floats(int b, int n)
+{
+    if (b < 0 || n < 0) return -1;
+    return (long long)sig_mfma_blocks((long long)b * n) * (GEOT_NTM_C + 1) * GEOT_NTM_C * GEOT_NTM_C;
+}
+
+GEOT_EXPORT int geot_ntm_sig_t_mean_grad_w(int b, int n, int c, const float *p, const float *W, const float *cm,
+                                           const float *grad_ins_T, float *grad_W, float *workspace,
+                                           void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0 || !workspace) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int C = GEOT_NTM_C;
+    size_t lds = (size_t)SigMfma<C>::LDS_FLOATS * sizeof(float);
+    hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, true>, lds);
+    if (e != hipSuccess) return e;
+    const int nblk = sig_mfma_blocks((long long)b * n);
+    hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, true>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, b * n, n,
+                       p, W, cm, grad_ins_T, nullptr, workspace);
+    hipLaunchKernelGGL((sig_t_mean_wgrad_reduce_kernel<C>), dim3(((C + 1) * C * C + 255) / 256), dim3(256), 0,
+                       (hipStream_t)stream, nblk, workspace, cm, grad_W);
     return hipGetLastError();
 }
 

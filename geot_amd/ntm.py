@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+from . import _lib
 from .ext._common import f32, i32, same_device, need, call, ptr
 from .knn_cuda import knn_sorted
 
@@ -45,16 +46,23 @@ class _SigTMeanFn(Function):
         p, cm, W = ctx.saved_tensors
         b, c, n = p.shape
         g = grad_out.contiguous()
-        raw = torch.empty_like(g)
-        call("geot_ntm_sig_t_mean_grad_raw", p.device, b, n, c, ptr(p), ptr(W), ptr(cm), ptr(g), ptr(raw))
-        # weight gradient = the Linear layers' own backward GEMMs (tiny: 289 x BN x 34)
-        # One GEMM gives both halves: [p_i | 1] as the right operand -> columns 0..C-1 are the p-part,
-        # column C is sum_i raw (which multiplies the constant cm[kk] inputs).
-        aug = torch.cat([p.permute(0, 2, 1).reshape(b * n, c), torch.ones((b * n, 1), device=p.device)], dim=1)
-        G = raw.view(b * n, c * c).t() @ aug                               # (C*C, C+1)
-        gwa = G[:, :c].reshape(c, c, c)
-        gwb = G[:, c].reshape(c, c, 1) * cm.unsqueeze(1)                   # [kk][o][j] = S[kk][o] * cm[kk][j]
-        return None, None, torch.cat([gwa, gwb], dim=2)
+        # the Linear heads' weight gradient, fused: d raw is formed on chip and contracted with [p_i | 1]
+        # by a second MFMA GEMM (train.py never needs d/dp: the predictor's input is detached)
+        lib = _lib.load()
+        ws = torch.empty(int(lib.geot_ntm_sig_t_mean_ws_floats(b, n)), dtype=torch.float32, device=p.device)
+        gw = torch.zeros_like(W)
+        call("geot_ntm_sig_t_mean_grad_w", p.device, b, n, c, ptr(p), ptr(W), ptr(cm), ptr(g), ptr(gw), ptr(ws))
+        return None, None, gw
+
+
+def sig_t_mean_grad_raw(p, cm, W, grad_out):
+    """d loss / d (pre-clamp rows), (B*N, C, C) -- the unfused building block (kept for tests / callers that
+    want d raw itself)."""
+    b, c, n = p.shape
+    g = grad_out.contiguous()
+    raw = torch.empty_like(g)
+    call("geot_ntm_sig_t_mean_grad_raw", p.device, b, n, c, ptr(p), ptr(W), ptr(cm), ptr(g), ptr(raw))
+    return raw
 
 
 class sig_t_mean(nn.Module):

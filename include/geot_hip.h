@@ -196,6 +196,11 @@ int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const float *W, con
                         float *ins_T, void *stream);
 int geot_ntm_sig_t_mean_grad_raw(int b, int n, int c, const float *p, const float *W, const float *cm,
                                  const float *grad_ins_T, float *grad_raw, void *stream);
+/* Weight gradient of sig_t_mean without materialising d raw: grad_W (c,c,2c) += d loss / d W given
+ * grad_ins_T (b*n,c,c); workspace = geot_ntm_sig_t_mean_ws_floats(b, n) floats of scratch. */
+long long geot_ntm_sig_t_mean_ws_floats(int b, int n);
+int geot_ntm_sig_t_mean_grad_w(int b, int n, int c, const float *p, const float *W, const float *cm,
+                               const float *grad_ins_T, float *grad_W, float *workspace, void *stream);
 /* Logit correction (examples/segmentation/train.py:549-552), fused:
  *   newT_i = L1-normalise(lam * ema_t + (1-lam) * ins_T_i); out[:, i] = logits[:, i]^T @ newT_i.
  *   logits/out (b,c,n), ins_T (b*n,c,c), ema_t (c,c).  _grad: grad_logits (b,c,n) and grad_ins_T are

@@ -21,7 +21,7 @@ def T(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dtype).to(DEV)
 
 
-@pytest.mark.parametrize("B,N", [(1, 64), (2, 500), (2, 24000)])
+@pytest.mark.parametrize("B,N", [(1, 64), (2, 500), (3, 1001), (1, 7), (2, 24000)])
 def test_sig_t_mean_forward_backward(B, N):
     from geot_amd.ntm import sig_t_mean, Ins_T_mean
     torch.manual_seed(0)
@@ -39,11 +39,18 @@ def test_sig_t_mean_forward_backward(B, N):
     # the fp32 reference has the same conditioning, so the bound is absolute on the normalised scale
     # (every row sums to 1): 2e-5.
     np.testing.assert_allclose(out.detach().cpu().numpy(), want, rtol=1e-5, atol=2e-5)
-    if N > 5000:
-        return
     g = rng.standard_normal(want.shape).astype(np.float32)
     (out * T(g)).sum().backward()
     got = torch.stack([l.weight.grad for l in mod.T_predictor.fc]).cpu().numpy()
+    # fused weight gradient == unfused building block (d raw kernel) + the Linear layers' own GEMM
+    from geot_amd.ntm import sig_t_mean_grad_raw
+    raw = sig_t_mean_grad_raw(T(p), T(cm), T(W), T(g))
+    aug = torch.cat([T(p).permute(0, 2, 1).reshape(B * N, C), torch.ones((B * N, 1), device=DEV)], 1).double()
+    G = raw.view(B * N, C * C).double().t() @ aug
+    unfused = torch.cat([G[:, :C].reshape(C, C, C), G[:, C].reshape(C, C, 1) * T(cm).double().unsqueeze(1)], 2)
+    np.testing.assert_allclose(got, unfused.cpu().numpy(), rtol=2e-4, atol=2e-4 * float(unfused.abs().max()))
+    if N > 5000:
+        return
     ref = np_ntm.sig_t_mean_grad_W(p, cm, W, g)
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
 
