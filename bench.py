@@ -176,7 +176,10 @@ def main():
         from geot_amd import workloads as wl
         from geot_amd import knn_cuda as kmod
         nt = wl.NtmHotPath().to(dev)
-        pw, ps = torch.randn(B, 17, N_POINTS, device=dev), torch.randn(B, 17, N_POINTS, device=dev)
+        from geot_amd.synth import make_logits
+        # spatially coherent predictions (weak and strong view of the same regions), see synth.region_labels
+        pw = torch.from_numpy(make_logits(xyz_np, index=2 * rank)).to(dev)
+        ps = torch.from_numpy(make_logits(xyz_np, index=2 * rank + 1, sharp=3.0)).to(dev)
         patch_owner, patch_name = None, None
         fps_rounds, desc = 0, ("configs[4] NTM half-step: sig_t_mean + class transition + logit correction + "
                                "threeD_space_loss(k=32) fwd+bwd on B_u clouds")

@@ -55,6 +55,8 @@ PROTOTYPES.update({
     "geot_ntm_correct_grad": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_threed_loss": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_threed_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_threed_loss_grad_ws": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _P,
+                                     ctypes.c_longlong, _c_void_p],
     "geot_ntm_feature_loss": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_feature_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P,
                                    _c_void_p],
@@ -64,6 +66,7 @@ PLAIN = {
     "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),
     "geot_knn_grid_ws_bytes": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_sig_t_mean_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
+    "geot_ntm_threed_loss_ws_bytes": ([_c_int, _c_int, _c_int], ctypes.c_longlong),
     "geot_knn_grid_eligible": ([_c_int, _c_int, _c_int, _c_int], _c_int),
 }
 

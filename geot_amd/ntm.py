@@ -14,6 +14,7 @@ bookkeeping of class_transition() is vectorised torch (no Python loop over class
 host round trips -- the reference does 289 scalar device ops per step there).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -197,8 +198,14 @@ class _ThreeDLossFn(Function):
         c, k = ins_T.shape[1], nbr.shape[2]
         g = torch.zeros_like(ins_T)
         scale = float(grad_out.item()) / (b * n) if grad_out.numel() == 1 else 1.0 / (b * n)
-        call("geot_ntm_threed_loss_grad", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
-             ptr(labels), ptr(ins_T), ptr(nbr), ptr(g))
+        if os.environ.get("GEOT_NTM_GRAD", "gather") == "atomic":   # the scatter form (A/B tests)
+            call("geot_ntm_threed_loss_grad", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
+                 ptr(labels), ptr(ins_T), ptr(nbr), ptr(g))
+        else:
+            nbytes = int(_lib.load().geot_ntm_threed_loss_ws_bytes(b, n, k))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=positions.device)
+            call("geot_ntm_threed_loss_grad_ws", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
+                 ptr(labels), ptr(ins_T), ptr(nbr), ptr(g), ptr(ws), nbytes)
         return None, None, g, None, None
 
 

@@ -222,6 +222,14 @@ int geot_ntm_threed_loss(int b, int n, int c, int k, float sigma, const float *p
 int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigma, float grad_scale,
                               const float *positions, const int *labels, const float *ins_T,
                               const int *nbr, float *grad_ins_T, void *stream);
+/* _grad_ws: the same gradient through an atomic-free gather over the kNN graph and its reverse (built in
+ * the workspace, geot_ntm_threed_loss_ws_bytes(b, n, k) bytes); 3x faster when labels are spatially
+ * coherent, i.e. on real scans, where most edges are live.  Falls back to _grad without a workspace. */
+long long geot_ntm_threed_loss_ws_bytes(int b, int n, int k);
+int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float sigma, float grad_scale,
+                                 const float *positions, const int *labels, const float *ins_T,
+                                 const int *nbr, float *grad_ins_T, void *workspace, long long ws_bytes,
+                                 void *stream);
 /* feature_space_loss (utils/insT_loss.py:9-58; disabled in the shipped cfg, use_feat_loss): same graph
  * kernel over feat_dim-dimensional features (b,n,feat_dim) with SIGNED weights
  * w_ij = (label_i == label_j ? +1 : -1) exp(-|f_i-f_j|^2/(2 sigma^2)) and no per-point normalisation:

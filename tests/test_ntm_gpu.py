@@ -112,6 +112,15 @@ def test_threed_space_loss_forward_backward(B, N, k, nlab, oracle):
     assert abs(loss.item() - want) <= 2e-5 * abs(want) + 1e-9
     loss.backward()
     np.testing.assert_allclose(tT.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
+    # the scatter (atomic) form of the backward gives the same gradient
+    import os
+    os.environ["GEOT_NTM_GRAD"] = "atomic"
+    try:
+        t2 = T(insT).requires_grad_(True)
+        crit(pos, T(labels, torch.int64), t2).backward()
+    finally:
+        del os.environ["GEOT_NTM_GRAD"]
+    np.testing.assert_allclose(t2.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
 
 
 @pytest.mark.parametrize("B,N,k,nlab", [(2, 300, 7, 3), (1, 1500, 16, 17)])

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from geot_amd.synth import make_batch  # noqa: E402
+from geot_amd.synth import make_batch, make_logits, region_labels  # noqa: E402
 from geot_amd.ext import pointnet2_ext as p2, pointops_cuda as pops  # noqa: E402
 from geot_amd.knn_cuda import knn_sorted  # noqa: E402
 
@@ -86,7 +86,8 @@ def main():
     t = timeit(lambda: wl.backbone_hotpath_step(hot, xyz, tokens), iters=5, warm=2)
     rows.append(("backbone hot-path ops fwd+bwd B=%d" % B, t, "%.1f clouds/s" % (B / t * 1e3)))
     C = 17
-    pw, ps = torch.randn(B, C, N, device=DEV), torch.randn(B, C, N, device=DEV)
+    pw = torch.from_numpy(make_logits(xyz_np, 0)).to(DEV)            # spatially coherent predictions
+    ps = torch.from_numpy(make_logits(xyz_np, 1, sharp=3.0)).to(DEV)
     nt = wl.NtmHotPath().to(DEV)
     t = timeit(lambda: wl.ntm_step(nt, xyz, pw, ps), iters=5, warm=2)
     rows.append(("NTM step (sig_t_mean+correct+3D loss) fwd+bwd B=%d" % B, t, "%.1f clouds/s" % (B / t * 1e3)))
@@ -100,9 +101,9 @@ def main():
         rows.append(("correct_logits fwd", t, "%.1f GB/s (read)" % (B * N * C * C * 4 / t / 1e6)))
         crit = ntm_mod.threeD_space_loss(k=32)
         nbr = crit.neighbours(xyz)
-        lab = torch.randint(0, 2, (B, N), device=DEV)
+        lab = torch.from_numpy(region_labels(xyz_np)).to(DEV)
         t = timeit(lambda: crit(xyz, lab, insT, nbr))
-        rows.append(("threeD_space_loss fwd (2 labels)", t, "%.1f GB/s (rows)" % (B * N * 33 * C * C * 4 / t / 1e6)))
+        rows.append(("threeD_space_loss fwd (region labels)", t, "%.1f GB/s (rows)" % (B * N * 33 * C * C * 4 / t / 1e6)))
     for name, ms, extra in rows:
         print("%-42s %10.3f ms   %s" % (name, ms, extra), flush=True)
 
