@@ -140,7 +140,17 @@ __global__ __launch_bounds__(256) void kg_bbox_kernel(int nr, const float *__res
     }
 }
 
-__global__ __launch_bounds__(256) void kg_count_kernel(int nr, int gtarget, const float *__restrict__ ref,
+__device__ __forceinline__ uint32_t kg_morton15(uint32_t x, uint32_t y, uint32_t z)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int bit = 0; bit < 5; ++bit)
+        m |= (((x >> bit) & 1u) << (3 * bit)) | (((y >> bit) & 1u) << (3 * bit + 1)) | (((z >> bit) & 1u) << (3 * bit + 2));
+    return m;
+}
+
+// morton = 0: x-fastest linear cell ids (what the kNN query walks); 1: Morton ids (geot_spatial_order)
+__global__ __launch_bounds__(256) void kg_count_kernel(int nr, int gtarget, int morton, const float *__restrict__ ref,
                                                        uint32_t *ws, size_t per_cloud, size_t off_tmp)
 {
     const float *R = ref + (size_t)blockIdx.y * nr * 3;
@@ -152,7 +162,8 @@ __global__ __launch_bounds__(256) void kg_count_kernel(int nr, int gtarget, cons
         int cx = kg_cell1(R[i * 3], g.lo[0], g.inv_h, g.dim[0]);
         int cy = kg_cell1(R[i * 3 + 1], g.lo[1], g.inv_h, g.dim[1]);
         int cz = kg_cell1(R[i * 3 + 2], g.lo[2], g.inv_h, g.dim[2]);
-        uint32_t cell = (uint32_t)((cz * g.dim[1] + cy) * g.dim[0] + cx);
+        uint32_t cell = morton ? kg_morton15((uint32_t)cx, (uint32_t)cy, (uint32_t)cz)
+                               : (uint32_t)((cz * g.dim[1] + cy) * g.dim[0] + cx);
         tmp[2 * i] = cell;
         tmp[2 * i + 1] = atomicAdd(&cnt[cell], 1u);
     }
@@ -352,6 +363,14 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void kg_order_kernel(int nr, const uint32_t *__restrict__ ws, size_t per_cloud,
+                                                       size_t off_rec, int *__restrict__ order)
+{
+    const float4 *rec = reinterpret_cast<const float4 *>(ws + (size_t)blockIdx.y * per_cloud + off_rec);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nr; i += gridDim.x * 256)
+        order[(size_t)blockIdx.y * nr + i] = blockIdx.y * nr + __float_as_int(rec[i].w);
+}
+
 static int kg_target(int nr, int k)
 {
     double g = std::sqrt(3.0 * (double)nr / (5.0 * (double)(k < 1 ? 1 : k)));
@@ -399,7 +418,7 @@ GEOT_EXPORT int geot_knn_sorted_ws(int b, int nq, int nr, int k, const float *qu
     const int pb = (nr + 255) / 256 < 96 ? (nr + 255) / 256 : 96;
     hipLaunchKernelGGL(kg_init_kernel, dim3((KG_CELLS + 1 + 255) / 256, b), dim3(256), 0, s, ws, L.per_cloud_words);
     hipLaunchKernelGGL(kg_bbox_kernel, dim3(pb, b), dim3(256), 0, s, nr, ref, ws, L.per_cloud_words);
-    hipLaunchKernelGGL(kg_count_kernel, dim3(pb, b), dim3(256), 0, s, nr, G, ref, ws, L.per_cloud_words, L.off_tmp);
+    hipLaunchKernelGGL(kg_count_kernel, dim3(pb, b), dim3(256), 0, s, nr, G, 0, ref, ws, L.per_cloud_words, L.off_tmp);
     hipLaunchKernelGGL(kg_scan_kernel, dim3(b), dim3(1024), 0, s, ws, L.per_cloud_words);
     hipLaunchKernelGGL(kg_scatter_kernel, dim3(pb, b), dim3(256), 0, s, nr, ref, ws, L.per_cloud_words, L.off_tmp,
                        L.off_rec);
@@ -416,4 +435,29 @@ GEOT_EXPORT int geot_three_nn_ws(int b, int n, int m, const float *unknown, cons
     if (!workspace || !geot_knn_grid_eligible(b, n, m, 3) || ws_bytes < geot_knn_grid_ws_bytes(b, m))
         return geot_three_nn(b, n, m, unknown, known, dist2, idx, stream);
     return geot_knn_sorted_ws(b, n, m, 3, unknown, known, idx, dist2, workspace, ws_bytes, stream);
+}
+
+// order (b*n) int32 <- the global point ids b*n + i sorted by (cloud, Morton cell of a 32^3 grid over the
+// cloud's bounding box): a processing order in which consecutive points are spatial neighbours, so that
+// kernels which gather per-point rows of a kNN graph find them in L2.  Arbitrary within a cell.
+GEOT_EXPORT int geot_spatial_order(int b, int n, const float *xyz, int *order, void *workspace, long long ws_bytes,
+                                   void *stream)
+{
+    if (b < 0 || n < 0 || !order) return hipErrorInvalidValue;
+    if (b == 0 || n == 0) return hipSuccess;
+    if (b > 65535 || !workspace || ws_bytes < geot_knn_grid_ws_bytes(b, n) || ((uintptr_t)workspace & 15) != 0)
+        return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    const KgLayout L = kg_layout(n);
+    uint32_t *ws = (uint32_t *)workspace;
+    const int pb = (n + 255) / 256 < 96 ? (n + 255) / 256 : 96;
+    hipLaunchKernelGGL(kg_init_kernel, dim3((KG_CELLS + 1 + 255) / 256, b), dim3(256), 0, s, ws, L.per_cloud_words);
+    hipLaunchKernelGGL(kg_bbox_kernel, dim3(pb, b), dim3(256), 0, s, n, xyz, ws, L.per_cloud_words);
+    hipLaunchKernelGGL(kg_count_kernel, dim3(pb, b), dim3(256), 0, s, n, KG_GMAX, 1, xyz, ws, L.per_cloud_words,
+                       L.off_tmp);
+    hipLaunchKernelGGL(kg_scan_kernel, dim3(b), dim3(1024), 0, s, ws, L.per_cloud_words);
+    hipLaunchKernelGGL(kg_scatter_kernel, dim3(pb, b), dim3(256), 0, s, n, xyz, ws, L.per_cloud_words, L.off_tmp,
+                       L.off_rec);
+    hipLaunchKernelGGL(kg_order_kernel, dim3(pb, b), dim3(256), 0, s, n, ws, L.per_cloud_words, L.off_rec, order);
+    return hipGetLastError();
 }

@@ -405,11 +405,12 @@ template <int CC, bool BACKWARD, bool SIGNED>
 __global__ __launch_bounds__(256) void threed_loss_kernel(
     int total_pts, int n, int k, int pd, float inv2s2, float gscale, const float *__restrict__ pos,
     const int *__restrict__ labels, const float *__restrict__ T, const int *__restrict__ nbr,
-    float *__restrict__ per_point, float *__restrict__ grad_T)
+    const int *__restrict__ order, float *__restrict__ per_point, float *__restrict__ grad_T)
 {
     constexpr int R = (CC + 63) / 64;
     const int lane = lane_id();
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total_pts; i += gridDim.x * 4) {
+    for (int ii = blockIdx.x * 4 + (threadIdx.x >> 6); ii < total_pts; ii += gridDim.x * 4) {
+        const int i = order ? order[ii] : ii; // spatial processing order: neighbour rows are then found in L2
         const int b = i / n;
         const float *Ti = T + (size_t)i * CC;
         float ti[R];
@@ -483,47 +484,75 @@ __global__ __launch_bounds__(256) void threed_loss_kernel(
 // per live edge: with spatially coherent labels -- real scans -- that is 1.8e9 atomics per 8 clouds.)
 // Pre-pass: per-point normaliser S and in-degree of the live edges; exclusive scan; fill of the
 // reverse adjacency (order within a list is arbitrary; only the fp32 summation order depends on it).
-__global__ __launch_bounds__(256) void tl_prep_kernel(int total_pts, int n, int k, float inv2s2,
-                                                      const float *__restrict__ pos, const int *__restrict__ labels,
-                                                      const int *__restrict__ nbr, float *__restrict__ S,
-                                                      int *__restrict__ deg)
+// Edge-parallel pre-pass: lane = one (point, slot) edge, SEG = next power of two >= k lanes per point.
+__device__ __forceinline__ float tl_edge_weight(const float *__restrict__ pos, const int *__restrict__ labels,
+                                                int i, int j, float inv2s2)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total_pts) return;
-    const int b = i / n;
-    const float px = pos[(size_t)i * 3], py = pos[(size_t)i * 3 + 1], pz = pos[(size_t)i * 3 + 2];
-    const int li = labels[i];
-    float s = 0.f;
-    for (int l = 0; l < k; ++l) {
-        const int j = b * n + nbr[(size_t)i * k + l];
-        if (labels[j] != li) continue;
-        const float dx = px - pos[(size_t)j * 3], dy = py - pos[(size_t)j * 3 + 1], dz = pz - pos[(size_t)j * 3 + 2];
-        float d2 = 0.f;
-        d2 += dx * dx; d2 += dy * dy; d2 += dz * dz;
-        const float w = __expf(-d2 * inv2s2);
-        s += w;
-        if (w != 0.f) atomicAdd(&deg[j], 1);
-    }
-    S[i] = s + 0.001f;
+    if (labels[j] != labels[i]) return 0.f;
+    const float dx = pos[(size_t)i * 3] - pos[(size_t)j * 3], dy = pos[(size_t)i * 3 + 1] - pos[(size_t)j * 3 + 1];
+    const float dz = pos[(size_t)i * 3 + 2] - pos[(size_t)j * 3 + 2];
+    float d2 = 0.f;
+    d2 += dx * dx; d2 += dy * dy; d2 += dz * dz;
+    return __expf(-d2 * inv2s2);
 }
 
-// exclusive scan of deg[0..total] in place (one block; a few hundred thousand entries at most per call)
-__global__ __launch_bounds__(1024) void tl_scan_kernel(int total, int *__restrict__ deg, int *__restrict__ cursor)
+__global__ __launch_bounds__(256) void tl_prep_kernel(int total_pts, int n, int k, int seg_shift, float inv2s2,
+                                                      const float *__restrict__ pos, const int *__restrict__ labels,
+                                                      const int *__restrict__ nbr, const int *__restrict__ order,
+                                                      float *__restrict__ S, float *__restrict__ wout,
+                                                      int *__restrict__ deg)
+{
+    const int seg = 1 << seg_shift;
+    const long long gl = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ii = (int)(gl >> seg_shift), l = (int)(gl & (seg - 1));
+    const int i = ii < total_pts ? (order ? order[ii] : ii) : total_pts;
+    float w = 0.f;
+    if (i < total_pts && l < k) {
+        const int j = (i / n) * n + nbr[(size_t)i * k + l];
+        w = tl_edge_weight(pos, labels, i, j, inv2s2);
+        wout[(size_t)i * k + l] = w;
+        if (w != 0.f) atomicAdd(&deg[j], 1);
+    }
+    float s = w;
+    for (int o = 1; o < seg; o <<= 1) s += __shfl_xor(s, o);
+    if (i < total_pts && l == 0) S[i] = s + 0.001f;
+}
+
+// exclusive scan of deg[0..total] in three small kernels (block-local scan, scan of the block sums, add)
+constexpr int TL_SCAN_CHUNK = 4096;
+__global__ __launch_bounds__(1024) void tl_scan_local_kernel(int total, int *__restrict__ deg, int *__restrict__ bsum)
+{
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.x * TL_SCAN_CHUNK + tid * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = base + e <= total ? deg[base + e] : 0; s += v[e]; }
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int run = woff + inc - s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { if (base + e <= total) deg[base + e] = run; run += v[e]; }
+    if (tid == 1023) bsum[blockIdx.x] = run;
+}
+__global__ __launch_bounds__(1024) void tl_scan_top_kernel(int nblk, int *__restrict__ bsum)
 {
     __shared__ int wsum[16];
     __shared__ int carry;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) carry = 0;
     __syncthreads();
-    for (int base = 0; base <= total; base += 1024 * 4) {
-        int v[4], s = 0;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = base + tid * 4 + e;
-            v[e] = idx < total ? deg[idx] : 0;
-            s += v[e];
-        }
-        int inc = s;
+    for (int base = 0; base < nblk; base += 1024) {
+        const int v = base + tid < nblk ? bsum[base + tid] : 0;
+        int inc = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             int o = __shfl_up(inc, d);
@@ -533,75 +562,74 @@ __global__ __launch_bounds__(1024) void tl_scan_kernel(int total, int *__restric
         __syncthreads();
         int woff = carry;
         for (int w = 0; w < wave; ++w) woff += wsum[w];
-        int run = woff + inc - s;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int idx = base + tid * 4 + e;
-            if (idx <= total) { deg[idx] = run; if (idx < total) cursor[idx] = 0; }
-            run += v[e];
-        }
+        if (base + tid < nblk) bsum[base + tid] = woff + inc - v;
         __syncthreads();
-        if (tid == 1023) carry = run;
+        if (tid == 1023) carry = woff + inc;
         __syncthreads();
     }
 }
-
-__global__ __launch_bounds__(256) void tl_fill_kernel(int total_pts, int n, int k, float inv2s2,
-                                                      const float *__restrict__ pos, const int *__restrict__ labels,
-                                                      const int *__restrict__ nbr, const int *__restrict__ off,
-                                                      int *__restrict__ cursor, int *__restrict__ rev)
+__global__ __launch_bounds__(1024) void tl_scan_add_kernel(int total, int *__restrict__ deg, const int *__restrict__ bsum,
+                                                           int *__restrict__ cursor)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total_pts) return;
-    const int b = i / n;
-    const float px = pos[(size_t)i * 3], py = pos[(size_t)i * 3 + 1], pz = pos[(size_t)i * 3 + 2];
-    const int li = labels[i];
-    for (int l = 0; l < k; ++l) {
-        const int j = b * n + nbr[(size_t)i * k + l];
-        if (labels[j] != li) continue;
-        const float dx = px - pos[(size_t)j * 3], dy = py - pos[(size_t)j * 3 + 1], dz = pz - pos[(size_t)j * 3 + 2];
-        float d2 = 0.f;
-        d2 += dx * dx; d2 += dy * dy; d2 += dz * dz;
-        if (__expf(-d2 * inv2s2) != 0.f) rev[off[j] + atomicAdd(&cursor[j], 1)] = i;
+    const int add = bsum[blockIdx.x];
+    const int base = blockIdx.x * TL_SCAN_CHUNK + threadIdx.x * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (base + e <= total) deg[base + e] += add;
+        if (base + e < total) cursor[base + e] = 0;
     }
+}
+
+// reverse adjacency: the in-edge (s -> i) is stored with its finished coefficient w_si / S_s
+__global__ __launch_bounds__(256) void tl_fill_kernel(int total_pts, int n, int k, int seg_shift,
+                                                      const int *__restrict__ nbr, const float *__restrict__ wout,
+                                                      const float *__restrict__ S, const int *__restrict__ off,
+                                                      const int *__restrict__ order, int *__restrict__ cursor,
+                                                      int *__restrict__ rev, float *__restrict__ revc)
+{
+    const int seg = 1 << seg_shift;
+    const long long gl = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ii = (int)(gl >> seg_shift), l = (int)(gl & (seg - 1));
+    if (ii >= total_pts || l >= k) return;
+    const int i = order ? order[ii] : ii;
+    const float w = wout[(size_t)i * k + l];
+    if (w == 0.f) return;
+    const int j = (i / n) * n + nbr[(size_t)i * k + l];
+    const int slot = off[j] + atomicAdd(&cursor[j], 1);
+    rev[slot] = i;
+    revc[slot] = w / S[i];
 }
 
 template <int CC>
 __global__ __launch_bounds__(256) void tl_grad_gather_kernel(
-    int total_pts, int n, int k, float inv2s2, float gscale, const float *__restrict__ pos,
-    const int *__restrict__ labels, const float *__restrict__ T, const int *__restrict__ nbr,
-    const float *__restrict__ S, const int *__restrict__ off, const int *__restrict__ rev,
+    int total_pts, int n, int k, float gscale, const float *__restrict__ T, const int *__restrict__ nbr,
+    const float *__restrict__ wout, const float *__restrict__ S, const int *__restrict__ off,
+    const int *__restrict__ rev, const float *__restrict__ revc, const int *__restrict__ order,
     float *__restrict__ grad_T)
 {
     constexpr int R = (CC + 63) / 64;
     const int lane = lane_id();
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total_pts; i += gridDim.x * 4) {
+    for (int ii = blockIdx.x * 4 + (threadIdx.x >> 6); ii < total_pts; ii += gridDim.x * 4) {
+        const int i = order ? order[ii] : ii;
         const int b = i / n;
         const float *Ti = T + (size_t)i * CC;
         float ti[R], acc[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) { ti[r] = (lane + 64 * r < CC) ? Ti[lane + 64 * r] : 0.f; acc[r] = 0.f; }
-        const float px = pos[(size_t)i * 3], py = pos[(size_t)i * 3 + 1], pz = pos[(size_t)i * 3 + 2];
-        const int li = labels[i];
-        const float ci = 2.f * gscale / S[i];
-        const int r0 = off[i], r1 = off[i + 1];
-        // edge list = the k out-neighbours, then the in-neighbours, 64 per pass
-        for (int e0 = -k; e0 < r1 - r0; e0 += 64) {
-            // first pass: lanes 0..k-1 are the out-edges (k <= 64), later passes: in-edges
-            int j = -1;
+        const float two_g = 2.f * gscale, inv_si = 1.f / S[i];
+        const int r0 = off[i], nin = off[i + 1] - r0;
+        // edge list = the k out-neighbours (first pass), then the in-neighbours, 64 per pass
+        for (int e0 = -64; e0 < nin; e0 += 64) {
+            int j = 0;
             float coef = 0.f;
             if (e0 < 0) {
                 if (lane < k) {
                     j = b * n + nbr[(size_t)i * k + lane];
-                    if (labels[j] != li) j = -1;
+                    coef = two_g * (wout[(size_t)i * k + lane] * inv_si);
                 }
-            } else if (e0 + lane < r1 - r0) j = rev[r0 + e0 + lane];
-            if (j >= 0) {
-                const float dx = px - pos[(size_t)j * 3], dy = py - pos[(size_t)j * 3 + 1], dz = pz - pos[(size_t)j * 3 + 2];
-                float d2 = 0.f;
-                d2 += dx * dx; d2 += dy * dy; d2 += dz * dz;
-                const float w = __expf(-d2 * inv2s2);
-                coef = (e0 < 0 ? ci : 2.f * gscale / S[j]) * w;
+            } else if (e0 + lane < nin) {
+                j = rev[r0 + e0 + lane];
+                coef = two_g * revc[r0 + e0 + lane];
             }
             unsigned long long live = __ballot(coef != 0.f);
             while (live) {
@@ -616,7 +644,6 @@ __global__ __launch_bounds__(256) void tl_grad_gather_kernel(
                     if (e < CC) acc[r] = fmaf(cf, ti[r] - Tj[e], acc[r]);
                 }
             }
-            if (e0 < 0) e0 = -64; // the next pass starts the in-edges at 0
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -746,7 +773,22 @@ GEOT_EXPORT int geot_ntm_threed_loss(int b, int n, int c, int k, float sigma, co
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((threed_loss_kernel<CC, false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, 3, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr,
+                       b * n, n, k, 3, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr, nullptr,
+                       per_point, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_threed_loss_ord(int b, int n, int c, int k, float sigma, const float *positions,
+                                         const int *labels, const float *ins_T, const int *nbr, const int *order,
+                                         float *per_point, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
+    int blocks = (b * n + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL((threed_loss_kernel<CC, false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       b * n, n, k, 3, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr, order,
                        per_point, nullptr);
     return hipGetLastError();
 }
@@ -755,41 +797,53 @@ GEOT_EXPORT long long geot_ntm_threed_loss_ws_bytes(int b, int n, int k)
 {
     if (b < 0 || n < 0 || k < 0) return -1;
     const long long t = (long long)b * n;
-    return 4 * (t /* S */ + (t + 1) /* offsets */ + t /* cursor */ + t * k /* reverse lists */) + 64;
+    const long long nblk = (t + 1 + TL_SCAN_CHUNK - 1) / TL_SCAN_CHUNK;
+    // S, offsets, cursor, block sums, then per edge: wout, rev, revc
+    return 4 * (t + (t + 1) + t + nblk + 3 * t * k) + 64;
 }
 
 // Same result as geot_ntm_threed_loss_grad (up to fp32 summation order) through the atomic-free gather
 // over the graph and its reverse.  workspace: geot_ntm_threed_loss_ws_bytes(b, n, k) bytes.
 GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float sigma, float grad_scale,
                                              const float *positions, const int *labels, const float *ins_T,
-                                             const int *nbr, float *grad_ins_T, void *workspace,
-                                             long long ws_bytes, void *stream)
+                                             const int *nbr, const int *order, float *grad_ins_T,
+                                             void *workspace, long long ws_bytes, void *stream)
 {
     if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
-    if ((long long)b * n * k > 0x7fffffffLL) return hipErrorInvalidValue;
+    if ((long long)b * n * 64 > 0x7fffffffLL) return hipErrorInvalidValue;
     if (!workspace || ws_bytes < geot_ntm_threed_loss_ws_bytes(b, n, k))
         return geot_ntm_threed_loss_grad(b, n, c, k, sigma, grad_scale, positions, labels, ins_T, nbr, grad_ins_T,
                                          stream);
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     hipStream_t s = (hipStream_t)stream;
     const int t = b * n;
+    const int nblk = (t + 1 + TL_SCAN_CHUNK - 1) / TL_SCAN_CHUNK;
     float *S = (float *)workspace;
     int *off = (int *)(S + t);
     int *cursor = off + t + 1;
-    int *rev = cursor + t;
+    int *bsum = cursor + t;
+    float *wout = (float *)(bsum + nblk);
+    int *rev = (int *)(wout + (size_t)t * k);
+    float *revc = (float *)(rev + (size_t)t * k);
     const float inv2s2 = 1.f / (2.f * sigma * sigma);
     hipError_t e = hipMemsetAsync(off, 0, (size_t)(t + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
-    const int pb = (t + 255) / 256;
-    hipLaunchKernelGGL(tl_prep_kernel, dim3(pb), dim3(256), 0, s, t, n, k, inv2s2, positions, labels, nbr, S, off);
-    hipLaunchKernelGGL(tl_scan_kernel, dim3(1), dim3(1024), 0, s, t, off, cursor);
-    hipLaunchKernelGGL(tl_fill_kernel, dim3(pb), dim3(256), 0, s, t, n, k, inv2s2, positions, labels, nbr, off, cursor,
-                       rev);
+    int seg_shift = 0;
+    while ((1 << seg_shift) < k) ++seg_shift;
+    const long long lanes = (long long)t << seg_shift;
+    const int eb = (int)((lanes + 255) / 256);
+    hipLaunchKernelGGL(tl_prep_kernel, dim3(eb), dim3(256), 0, s, t, n, k, seg_shift, inv2s2, positions, labels, nbr,
+                       order, S, wout, off);
+    hipLaunchKernelGGL(tl_scan_local_kernel, dim3(nblk), dim3(1024), 0, s, t, off, bsum);
+    hipLaunchKernelGGL(tl_scan_top_kernel, dim3(1), dim3(1024), 0, s, nblk, bsum);
+    hipLaunchKernelGGL(tl_scan_add_kernel, dim3(nblk), dim3(1024), 0, s, t, off, bsum, cursor);
+    hipLaunchKernelGGL(tl_fill_kernel, dim3(eb), dim3(256), 0, s, t, n, k, seg_shift, nbr, wout, S, off, order, cursor,
+                       rev, revc);
     int blocks = (t + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL((tl_grad_gather_kernel<CC>), dim3(blocks), dim3(256), 0, s, t, n, k, inv2s2, grad_scale,
-                       positions, labels, ins_T, nbr, S, off, rev, grad_ins_T);
+    hipLaunchKernelGGL((tl_grad_gather_kernel<CC>), dim3(blocks), dim3(256), 0, s, t, n, k, grad_scale, ins_T, nbr,
+                       wout, S, off, rev, revc, order, grad_ins_T);
     return hipGetLastError();
 }
 
@@ -804,7 +858,7 @@ GEOT_EXPORT int geot_ntm_feature_loss(int b, int n, int c, int k, int feat_dim, 
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((threed_loss_kernel<CC, false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), 0.f, feats, labels, ins_T, nbr,
+                       b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), 0.f, feats, labels, ins_T, nbr, nullptr,
                        per_point, nullptr);
     return hipGetLastError();
 }
@@ -821,7 +875,7 @@ GEOT_EXPORT int geot_ntm_feature_loss_grad(int b, int n, int c, int k, int feat_
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((threed_loss_kernel<CC, true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), grad_scale, feats, labels, ins_T,
-                       nbr, nullptr, grad_ins_T);
+                       nbr, nullptr, nullptr, grad_ins_T);
     return hipGetLastError();
 }
 
@@ -836,6 +890,6 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigm
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL((threed_loss_kernel<CC, true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        b * n, n, k, 3, 1.f / (2.f * sigma * sigma), grad_scale, positions, labels, ins_T, nbr,
-                       nullptr, grad_ins_T);
+                       nullptr, nullptr, grad_ins_T);
     return hipGetLastError();
 }

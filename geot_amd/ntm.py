@@ -185,15 +185,16 @@ class _ThreeDLossFn(Function):
         need(tuple(ins_T.shape) == (b * n, c, c) and tuple(labels.shape) == (b, n) and tuple(nbr.shape) == (b, n, k),
              "threeD_space_loss shape mismatch")
         per_point = torch.empty(b * n, dtype=torch.float32, device=dev)
-        call("geot_ntm_threed_loss", dev, b, n, c, k, float(sigma), ptr(positions), ptr(labels), ptr(ins_T),
-             ptr(nbr), ptr(per_point))
-        ctx.save_for_backward(positions, labels, ins_T, nbr)
+        order = spatial_order(positions)      # processing order only: neighbour rows then hit L2
+        call("geot_ntm_threed_loss_ord", dev, b, n, c, k, float(sigma), ptr(positions), ptr(labels), ptr(ins_T),
+             ptr(nbr), ptr(order), ptr(per_point))
+        ctx.save_for_backward(positions, labels, ins_T, nbr, order)
         ctx.sigma = float(sigma)
         return per_point.mean()
 
     @staticmethod
     def backward(ctx, grad_out):
-        positions, labels, ins_T, nbr = ctx.saved_tensors
+        positions, labels, ins_T, nbr, order = ctx.saved_tensors
         b, n, _ = positions.shape
         c, k = ins_T.shape[1], nbr.shape[2]
         g = torch.zeros_like(ins_T)
@@ -205,8 +206,23 @@ class _ThreeDLossFn(Function):
             nbytes = int(_lib.load().geot_ntm_threed_loss_ws_bytes(b, n, k))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=positions.device)
             call("geot_ntm_threed_loss_grad_ws", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
-                 ptr(labels), ptr(ins_T), ptr(nbr), ptr(g), ptr(ws), nbytes)
+                 ptr(labels), ptr(ins_T), ptr(nbr), ptr(order), ptr(g), ptr(ws), nbytes)
         return None, None, g, None, None
+
+
+@torch.no_grad()
+def spatial_order(positions):
+    """(B,N,3) -> int32 (B*N,) global point ids sorted by (cloud, Morton cell): the order in which the graph
+    kernels walk the points (GEOT_NTM_ORDER=off: None, memory order)."""
+    if os.environ.get("GEOT_NTM_ORDER", "on") == "off":
+        return None
+    b, n, _ = positions.shape
+    lib = _lib.load()
+    nbytes = int(lib.geot_knn_grid_ws_bytes(b, n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=positions.device)
+    order = torch.empty(b * n, dtype=torch.int32, device=positions.device)
+    call("geot_spatial_order", positions.device, b, n, ptr(positions), ptr(order), ptr(ws), nbytes)
+    return order
 
 
 class threeD_space_loss(nn.Module):

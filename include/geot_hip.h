@@ -228,8 +228,16 @@ int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigma, float gra
 long long geot_ntm_threed_loss_ws_bytes(int b, int n, int k);
 int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float sigma, float grad_scale,
                                  const float *positions, const int *labels, const float *ins_T,
-                                 const int *nbr, float *grad_ins_T, void *workspace, long long ws_bytes,
-                                 void *stream);
+                                 const int *nbr, const int *order, float *grad_ins_T, void *workspace,
+                                 long long ws_bytes, void *stream);
+/* `order` (b*n int32 global point ids, or NULL) = the order in which points are PROCESSED; results do not
+ * depend on it.  With geot_spatial_order's output consecutive waves work on spatial neighbours and the
+ * gathered (1156-byte) rows of a point's graph neighbours are found in L2: 1.5x on randomly ordered scans. */
+int geot_ntm_threed_loss_ord(int b, int n, int c, int k, float sigma, const float *positions,
+                             const int *labels, const float *ins_T, const int *nbr, const int *order,
+                             float *per_point, void *stream);
+int geot_spatial_order(int b, int n, const float *xyz, int *order, void *workspace, long long ws_bytes,
+                       void *stream); /* workspace: geot_knn_grid_ws_bytes(b, n) bytes, 16-byte aligned */
 /* feature_space_loss (utils/insT_loss.py:9-58; disabled in the shipped cfg, use_feat_loss): same graph
  * kernel over feat_dim-dimensional features (b,n,feat_dim) with SIGNED weights
  * w_ij = (label_i == label_j ? +1 : -1) exp(-|f_i-f_j|^2/(2 sigma^2)) and no per-point normalisation:

@@ -112,6 +112,10 @@ def test_threed_space_loss_forward_backward(B, N, k, nlab, oracle):
     assert abs(loss.item() - want) <= 2e-5 * abs(want) + 1e-9
     loss.backward()
     np.testing.assert_allclose(tT.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
+    # the processing order is a permutation of all points (and changes nothing but the speed)
+    from geot_amd.ntm import spatial_order
+    od = spatial_order(pos).cpu().numpy()
+    assert np.array_equal(np.sort(od), np.arange(B * N)) and np.all(od // N == np.repeat(np.arange(B), N))
     # the scatter (atomic) form of the backward gives the same gradient
     import os
     os.environ["GEOT_NTM_GRAD"] = "atomic"
