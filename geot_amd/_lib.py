@@ -53,6 +53,7 @@ PROTOTYPES.update({
     "geot_ntm_sig_t_mean_grad_raw": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_correct": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_correct_grad": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_correct_grad_ws": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_threed_loss": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_threed_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_threed_loss_grad_ws": [_c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _P, _P,
@@ -69,6 +70,7 @@ PLAIN = {
     "geot_knn_grid_ws_bytes": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_sig_t_mean_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_threed_loss_ws_bytes": ([_c_int, _c_int, _c_int], ctypes.c_longlong),
+    "geot_ntm_correct_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_knn_grid_eligible": ([_c_int, _c_int, _c_int, _c_int], _c_int),
 }
 

@@ -38,10 +38,24 @@ __device__ __forceinline__ void ntm_tile_copy(float *__restrict__ g, float *__re
 {
     constexpr int CC = C * C, STRIDE = NtmLds<C>::STRIDE;
     const int total = cnt * CC;
-    for (int e = threadIdx.x; e < total; e += NTM_THREADS) {
-        int pt = e / CC, w = e - pt * CC;
-        if (TO_LDS) lds[pt * STRIDE + w] = g[e];
-        else g[e] = lds[pt * STRIDE + w];
+    if constexpr (STRIDE == CC) {
+        // odd C: the LDS tile is the exact image of the global block -> 16-byte vectors, no index arithmetic
+        // (tiles start at multiples of NTM_TILE points = multiples of 16 bytes)
+        const int vec = total >> 2;
+        for (int e = threadIdx.x; e < vec; e += NTM_THREADS) {
+            if (TO_LDS) reinterpret_cast<float4 *>(lds)[e] = reinterpret_cast<const float4 *>(g)[e];
+            else reinterpret_cast<float4 *>(g)[e] = reinterpret_cast<const float4 *>(lds)[e];
+        }
+        for (int e = (vec << 2) + threadIdx.x; e < total; e += NTM_THREADS) {
+            if (TO_LDS) lds[e] = g[e];
+            else g[e] = lds[e];
+        }
+    } else {
+        for (int e = threadIdx.x; e < total; e += NTM_THREADS) {
+            int pt = e / CC, w = e - pt * CC;
+            if (TO_LDS) lds[pt * STRIDE + w] = g[e];
+            else g[e] = lds[pt * STRIDE + w];
+        }
     }
 }
 
@@ -56,7 +70,7 @@ __global__ __launch_bounds__(NTM_THREADS) void sig_t_mean_kernel(
     extern __shared__ float ntm_lds[];
     float *Wa = ntm_lds;            // [kk][o][j]
     float *bias = Wa + C * CC;      // [kk][o]
-    float *tile = bias + CC;        // [NTM_TILE][STRIDE]
+    float *tile = ntm_lds + ((C * CC + CC + 3) & ~3); // [NTM_TILE][STRIDE], 16-byte aligned
     for (int e = threadIdx.x; e < C * CC; e += NTM_THREADS) {
         int kk = e / CC, r = e - kk * CC, o = r / C, j = r - o * C;
         Wa[e] = W[((size_t)kk * C + o) * 2 * C + j];
@@ -297,16 +311,19 @@ __global__ __launch_bounds__(256) void sig_t_mean_wgrad_reduce_kernel(int nblk, 
                                                                       const float *__restrict__ cm,
                                                                       float *__restrict__ grad_W)
 {
+    // grid.y slices the block partials 32 at a time: 16x the parallelism of one thread per entry, and the
+    // final accumulation into grad_W (pre-zeroed or carrying earlier gradients) is a float atomic anyway
     constexpr int CC = C * C, KP = C + 1;
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= KP * CC) return;
     const int k = e / CC, col = e - k * CC;
+    const int b0 = blockIdx.y * 32, b1 = min(nblk, b0 + 32);
     float s = 0.f;
-    for (int bkt = 0; bkt < nblk; ++bkt) s += partial[(size_t)bkt * KP * CC + e];
-    if (k < C) grad_W[(size_t)col * 2 * C + k] += s;
+    for (int bkt = b0; bkt < b1; ++bkt) s += partial[(size_t)bkt * KP * CC + e];
+    if (k < C) atomicAdd(&grad_W[(size_t)col * 2 * C + k], s);
     else {
         const int kk = col / C;
-        for (int j = 0; j < C; ++j) grad_W[(size_t)col * 2 * C + C + j] += cm[kk * C + j] * s;
+        for (int j = 0; j < C; ++j) atomicAdd(&grad_W[(size_t)col * 2 * C + C + j], cm[kk * C + j] * s);
     }
 }
 
@@ -316,17 +333,26 @@ template <int C, bool BACKWARD>
 __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
     int total_pts, int n, float lam, const float *__restrict__ logits, const float *__restrict__ insT,
     const float *__restrict__ E, const float *__restrict__ grad_out, float *__restrict__ out,
-    float *__restrict__ grad_logits, float *__restrict__ grad_insT, float *__restrict__ grad_E)
+    float *__restrict__ grad_logits, float *__restrict__ grad_insT, float *__restrict__ grad_E,
+    float *__restrict__ grad_E_partial)
 {
     constexpr int CC = C * C, STRIDE = NtmLds<C>::STRIDE;
     extern __shared__ float ntm_lds[];
     float *El = ntm_lds;                         // [CC]
     float *accE = El + CC;                       // [CC] block partial of grad_E (backward)
     float *part = accE + CC;                     // [NTM_GROUPS][NTM_TILE][C] partial outputs per row group
-    float *tile = part + NTM_GROUPS * NTM_TILE * C; // [NTM_TILE][STRIDE]
+    float *tile = ntm_lds + ((2 * CC + NTM_GROUPS * NTM_TILE * C + 3) & ~3); // [NTM_TILE][STRIDE], 16-byte aligned
     for (int e = threadIdx.x; e < CC; e += NTM_THREADS) { El[e] = E[e]; accE[e] = 0.f; }
     __syncthreads();
     const int pt = threadIdx.x & (NTM_TILE - 1), grp = threadIdx.x >> NTM_TILE_SHIFT;
+    // backward: this thread's share of grad_E (rows grp, grp + 8, grp + 16) stays in registers over all its
+    // tiles; 289 x points LDS atomics on 289 addresses were the whole cost of the first version
+    constexpr int ROWS_PT = (C + NTM_GROUPS - 1) / NTM_GROUPS;
+    float eacc[ROWS_PT][C];
+#pragma unroll
+    for (int q = 0; q < ROWS_PT; ++q)
+#pragma unroll
+        for (int c = 0; c < C; ++c) eacc[q][c] = 0.f;
     for (int i0 = blockIdx.x * NTM_TILE; i0 < total_pts; i0 += gridDim.x * NTM_TILE) {
         const int cnt = min(NTM_TILE, total_pts - i0);
         ntm_tile_copy<C, true>(const_cast<float *>(insT) + (size_t)i0 * CC, tile, cnt);
@@ -341,7 +367,10 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
 #pragma unroll
                 for (int c = 0; c < C; ++c) go[c] = grad_out[((size_t)b * C + c) * n + ni];
             }
-            for (int r = grp; r < C; r += NTM_GROUPS) {
+#pragma unroll
+            for (int q = 0; q < ROWS_PT; ++q) {
+                const int r = grp + q * NTM_GROUPS;
+                if (r >= C) continue;
                 float *row = tile + pt * STRIDE + r * C;
                 const float l = logits[((size_t)b * C + r) * n + ni];
                 float v[C], s = 0.f;
@@ -365,7 +394,7 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
                         float sg = v[c] > 0.f ? 1.f : (v[c] < 0.f ? -1.f : 0.f);
                         float dv = s > 1e-12f ? (l * go[c] - sg * dot) / den : l * go[c] / den;
                         row[c] = (1.f - lam) * dv;
-                        atomicAdd(&accE[r * C + c], lam * dv);
+                        eacc[q][c] = fmaf(lam, dv, eacc[q][c]);
                     }
                 }
             }
@@ -389,8 +418,25 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
         }
         __syncthreads();
     }
-    if (BACKWARD)
-        for (int e = threadIdx.x; e < CC; e += NTM_THREADS) atomicAdd(grad_E + e, accE[e]);
+    if (BACKWARD) {
+        // sum over the 32 points of the half-wave (one row group per half-wave), then one atomic per entry
+#pragma unroll
+        for (int q = 0; q < ROWS_PT; ++q) {
+            const int r = grp + q * NTM_GROUPS;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float v = eacc[q][c];
+#pragma unroll
+                for (int o = NTM_TILE / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                if (pt == 0 && r < C) {
+                    // per-block partials when the caller gave a workspace: 289 addresses shared by a thousand
+                    // blocks serialise in one or two L2 channels otherwise
+                    if (grad_E_partial) grad_E_partial[(size_t)blockIdx.x * CC + r * C + c] = v;
+                    else atomicAdd(grad_E + r * C + c, v);
+                }
+            }
+        }
+    }
 }
 
 // ---- threeD_space_loss -----------------------------------------------------------------------
@@ -653,6 +699,18 @@ __global__ __launch_bounds__(256) void tl_grad_gather_kernel(
     }
 }
 
+// out[e] += sum over blocks of partial[blk][e]; grid.y slices the blocks 32 at a time
+__global__ __launch_bounds__(256) void ntm_partial_reduce_kernel(int nblk, int len, const float *__restrict__ partial,
+                                                                 float *__restrict__ out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= len) return;
+    const int b0 = blockIdx.y * 32, b1 = min(nblk, b0 + 32);
+    float s = 0.f;
+    for (int bkt = b0; bkt < b1; ++bkt) s += partial[(size_t)bkt * len + e];
+    atomicAdd(out + e, s);
+}
+
 template <typename K>
 static hipError_t set_lds(K kernel, size_t lds)
 {
@@ -663,7 +721,7 @@ static hipError_t set_lds(K kernel, size_t lds)
 static inline int ntm_blocks(int total_pts)
 {
     int tiles = (total_pts + NTM_TILE - 1) / NTM_TILE;
-    return tiles < 1 ? 1 : (tiles > 4096 ? 4096 : tiles);
+    return tiles < 1 ? 1 : (tiles > 1024 ? 1024 : tiles); // persistent-style: block prologues/epilogues (weights, grad_E atomics) amortise
 }
 
 } // namespace geot
@@ -711,7 +769,7 @@ GEOT_EXPORT int geot_ntm_sig_t_mean_grad_w(int b, int n, int c, const float *p, 
     const int nblk = sig_mfma_blocks((long long)b * n);
     hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, true>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, b * n, n,
                        p, W, cm, grad_ins_T, nullptr, workspace);
-    hipLaunchKernelGGL((sig_t_mean_wgrad_reduce_kernel<C>), dim3(((C + 1) * C * C + 255) / 256), dim3(256), 0,
+    hipLaunchKernelGGL((sig_t_mean_wgrad_reduce_kernel<C>), dim3(((C + 1) * C * C + 255) / 256, (nblk + 31) / 32), dim3(256), 0,
                        (hipStream_t)stream, nblk, workspace, cm, grad_W);
     return hipGetLastError();
 }
@@ -723,7 +781,7 @@ GEOT_EXPORT int geot_ntm_sig_t_mean_grad_raw(int b, int n, int c, const float *p
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(C * C * C + C * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    size_t lds = (size_t)(C * C * C + C * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
     hipError_t e = set_lds(sig_t_mean_kernel<C, true>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((sig_t_mean_kernel<C, true>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
@@ -737,12 +795,12 @@ GEOT_EXPORT int geot_ntm_correct(int b, int n, int c, float lam, const float *lo
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
     hipError_t e = set_lds(ntm_correct_kernel<C, false>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ntm_correct_kernel<C, false>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
                        (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, nullptr, out, nullptr,
-                       nullptr, nullptr);
+                       nullptr, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -754,12 +812,42 @@ GEOT_EXPORT int geot_ntm_correct_grad(int b, int n, int c, float lam, const floa
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
     hipError_t e = set_lds(ntm_correct_kernel<C, true>, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ntm_correct_kernel<C, true>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
                        (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, grad_out, nullptr,
-                       grad_logits, grad_ins_T, grad_ema_t);
+                       grad_logits, grad_ins_T, grad_ema_t, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT long long geot_ntm_correct_ws_floats(int b, int n)
+{
+    if (b < 0 || n < 0) return -1;
+    return (long long)ntm_blocks(b * n) * GEOT_NTM_C * GEOT_NTM_C;
+}
+
+// geot_ntm_correct_grad with the (c,c) grad_ema_t reduced through per-block partial sums in `workspace`
+// (geot_ntm_correct_ws_floats(b, n) floats) instead of ~3e5 atomics on 289 addresses.
+GEOT_EXPORT int geot_ntm_correct_grad_ws(int b, int n, int c, float lam, const float *logits,
+                                         const float *ins_T, const float *ema_t, const float *grad_out,
+                                         float *grad_logits, float *grad_ins_T, float *grad_ema_t,
+                                         float *workspace, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    if (!workspace)
+        return geot_ntm_correct_grad(b, n, c, lam, logits, ins_T, ema_t, grad_out, grad_logits, grad_ins_T, grad_ema_t,
+                                     stream);
+    constexpr int C = GEOT_NTM_C;
+    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    hipError_t e = set_lds(ntm_correct_kernel<C, true>, lds);
+    if (e != hipSuccess) return e;
+    const int nblk = ntm_blocks(b * n);
+    hipLaunchKernelGGL((ntm_correct_kernel<C, true>), dim3(nblk), dim3(NTM_THREADS), lds, (hipStream_t)stream, b * n,
+                       n, lam, logits, ins_T, ema_t, grad_out, nullptr, grad_logits, grad_ins_T, grad_ema_t, workspace);
+    hipLaunchKernelGGL(ntm_partial_reduce_kernel, dim3((C * C + 255) / 256, (nblk + 31) / 32), dim3(256), 0,
+                       (hipStream_t)stream, nblk, C * C, workspace, grad_ema_t);
     return hipGetLastError();
 }
 

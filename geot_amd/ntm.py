@@ -158,8 +158,9 @@ class _CorrectFn(Function):
         gl = torch.empty_like(logits)
         gi = torch.empty_like(ins_T)
         ge = torch.zeros_like(ema_t)
-        call("geot_ntm_correct_grad", logits.device, b, n, c, ctx.lam, ptr(logits), ptr(ins_T), ptr(ema_t),
-             ptr(g), ptr(gl), ptr(gi), ptr(ge))
+        ws = torch.empty(int(_lib.load().geot_ntm_correct_ws_floats(b, n)), dtype=torch.float32, device=logits.device)
+        call("geot_ntm_correct_grad_ws", logits.device, b, n, c, ctx.lam, ptr(logits), ptr(ins_T), ptr(ema_t),
+             ptr(g), ptr(gl), ptr(gi), ptr(ge), ptr(ws))
         return gl, gi, ge, None
 
 

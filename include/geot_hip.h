@@ -210,6 +210,11 @@ int geot_ntm_correct(int b, int n, int c, float lam, const float *logits, const 
 int geot_ntm_correct_grad(int b, int n, int c, float lam, const float *logits, const float *ins_T,
                           const float *ema_t, const float *grad_out, float *grad_logits,
                           float *grad_ins_T, float *grad_ema_t, void *stream);
+/* _grad_ws: as _grad, with grad_ema_t reduced through geot_ntm_correct_ws_floats(b, n) floats of scratch. */
+long long geot_ntm_correct_ws_floats(int b, int n);
+int geot_ntm_correct_grad_ws(int b, int n, int c, float lam, const float *logits, const float *ins_T,
+                             const float *ema_t, const float *grad_out, float *grad_logits,
+                             float *grad_ins_T, float *grad_ema_t, float *workspace, void *stream);
 /* threeD_space_loss (utils/insT_loss.py:68-110) over a given kNN graph:
  *   positions (b,n,3), labels (b,n) int32, ins_T (b*n,c,c), nbr (b,n,k) int32 local neighbour ids
  *   (the reference uses knn_point(k+1)[..., 1:]); per_point (b*n) = sum_j w_ij |T_i-T_j|^2 /
