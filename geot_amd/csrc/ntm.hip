@@ -455,7 +455,15 @@ __global__ __launch_bounds__(256) void threed_loss_kernel(
 {
     constexpr int R = (CC + 63) / 64;
     const int lane = lane_id();
-    for (int ii = blockIdx.x * 4 + (threadIdx.x >> 6); ii < total_pts; ii += gridDim.x * 4) {
+    // XCD-aware walk of the (spatially sorted) point order: workgroups are dealt round-robin to the 8 XCDs,
+    // so XCD x takes the x-th eighth of the order and its private L2 caches one region of the cloud instead of
+    // all eight L2s caching the same rows.  (Placement is a performance assumption only; any mapping is correct.)
+    const int xcd_chunk = (((total_pts + 7) >> 3) + 3) & ~3;
+    for (int t = blockIdx.x >> 3; ; t += gridDim.x >> 3) {
+        const int within = t * 4 + (threadIdx.x >> 6);
+        if (within >= xcd_chunk) break;
+        const int ii = (blockIdx.x & 7) * xcd_chunk + within;
+        if (ii >= total_pts) break;
         const int i = order ? order[ii] : ii; // spatial processing order: neighbour rows are then found in L2
         const int b = i / n;
         const float *Ti = T + (size_t)i * CC;
@@ -655,7 +663,15 @@ __global__ __launch_bounds__(256) void tl_grad_gather_kernel(
 {
     constexpr int R = (CC + 63) / 64;
     const int lane = lane_id();
-    for (int ii = blockIdx.x * 4 + (threadIdx.x >> 6); ii < total_pts; ii += gridDim.x * 4) {
+    // XCD-aware walk of the (spatially sorted) point order: workgroups are dealt round-robin to the 8 XCDs,
+    // so XCD x takes the x-th eighth of the order and its private L2 caches one region of the cloud instead of
+    // all eight L2s caching the same rows.  (Placement is a performance assumption only; any mapping is correct.)
+    const int xcd_chunk = (((total_pts + 7) >> 3) + 3) & ~3;
+    for (int t = blockIdx.x >> 3; ; t += gridDim.x >> 3) {
+        const int within = t * 4 + (threadIdx.x >> 6);
+        if (within >= xcd_chunk) break;
+        const int ii = (blockIdx.x & 7) * xcd_chunk + within;
+        if (ii >= total_pts) break;
         const int i = order ? order[ii] : ii;
         const int b = i / n;
         const float *Ti = T + (size_t)i * CC;
@@ -860,6 +876,7 @@ GEOT_EXPORT int geot_ntm_threed_loss(int b, int n, int c, int k, float sigma, co
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
     hipLaunchKernelGGL((threed_loss_kernel<CC, false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        b * n, n, k, 3, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr, nullptr,
                        per_point, nullptr);
@@ -875,6 +892,7 @@ GEOT_EXPORT int geot_ntm_threed_loss_ord(int b, int n, int c, int k, float sigma
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
     hipLaunchKernelGGL((threed_loss_kernel<CC, false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        b * n, n, k, 3, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr, order,
                        per_point, nullptr);
@@ -930,6 +948,7 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float s
                        rev, revc);
     int blocks = (t + 3) / 4;
     if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
     hipLaunchKernelGGL((tl_grad_gather_kernel<CC>), dim3(blocks), dim3(256), 0, s, t, n, k, grad_scale, ins_T, nbr,
                        wout, S, off, rev, revc, order, grad_ins_T);
     return hipGetLastError();
@@ -945,6 +964,7 @@ GEOT_EXPORT int geot_ntm_feature_loss(int b, int n, int c, int k, int feat_dim, 
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
     hipLaunchKernelGGL((threed_loss_kernel<CC, false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), 0.f, feats, labels, ins_T, nbr, nullptr,
                        per_point, nullptr);
@@ -961,6 +981,7 @@ GEOT_EXPORT int geot_ntm_feature_loss_grad(int b, int n, int c, int k, int feat_
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
     hipLaunchKernelGGL((threed_loss_kernel<CC, true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), grad_scale, feats, labels, ins_T,
                        nbr, nullptr, nullptr, grad_ins_T);
@@ -976,6 +997,7 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigm
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     int blocks = (b * n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
     hipLaunchKernelGGL((threed_loss_kernel<CC, true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        b * n, n, k, 3, 1.f / (2.f * sigma * sigma), grad_scale, positions, labels, ins_T, nbr,
                        nullptr, nullptr, grad_ins_T);
