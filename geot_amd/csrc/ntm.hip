@@ -15,6 +15,7 @@
 // C is a template parameter (the reference fixes num_classes = 17).
 #include "geot_common.h"
 #include "geot_hip.h"
+#include <cstdlib>
 
 namespace geot {
 
@@ -531,6 +532,87 @@ __global__ __launch_bounds__(256) void threed_loss_kernel(
     }
 }
 
+// ---- threeD_space_loss forward, G consecutive points of the spatial order per wave ------------
+// Points that follow each other in Morton order share most of their neighbours.  The wave keeps the G
+// neighbour lists in lanes, and every neighbour row it loads is applied to ALL of its points that list it
+// (membership = one ballot per point), so a row shared by 3 of the 4 points is fetched once, not 3 times.
+// The row gathers from L2 are what bounds this kernel; the arithmetic per (point, row) pair is unchanged.
+template <int CC, int G>
+__global__ __launch_bounds__(256) void threed_loss_shared_kernel(
+    int total_pts, int n, int k, float inv2s2, const float *__restrict__ pos, const int *__restrict__ labels,
+    const float *__restrict__ T, const int *__restrict__ nbr, const int *__restrict__ order,
+    float *__restrict__ per_point)
+{
+    constexpr int R = (CC + 63) / 64;
+    const int lane = lane_id();
+    const int xcd_chunk = (((total_pts + 7) >> 3) + 4 * G - 1) / (4 * G) * (4 * G);
+    for (int t = blockIdx.x >> 3;; t += gridDim.x >> 3) {
+        const int within = (t * 4 + (threadIdx.x >> 6)) * G;
+        if (within >= xcd_chunk) break;
+        const int ii0 = (blockIdx.x & 7) * xcd_chunk + within;
+        if (ii0 >= total_pts) break;
+        int pi[G], jl[G];
+        float wl[G], S[G], ti[G][R], acc[G];
+        unsigned long long live[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool ok = ii0 + g < total_pts && within + g < xcd_chunk;
+            const int i = ok ? (order ? order[ii0 + g] : ii0 + g) : -1;
+            pi[g] = i;
+            jl[g] = -1; wl[g] = 0.f; acc[g] = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) ti[g][r] = (i >= 0 && lane + 64 * r < CC) ? T[(size_t)i * CC + lane + 64 * r] : 0.f;
+            if (i >= 0 && lane < k) {
+                const int j = (i / n) * n + nbr[(size_t)i * k + lane];
+                jl[g] = j;
+                if (labels[j] == labels[i]) {
+                    const float dx = pos[(size_t)i * 3] - pos[(size_t)j * 3], dy = pos[(size_t)i * 3 + 1] - pos[(size_t)j * 3 + 1];
+                    const float dz = pos[(size_t)i * 3 + 2] - pos[(size_t)j * 3 + 2];
+                    float d2 = 0.f;
+                    d2 += dx * dx; d2 += dy * dy; d2 += dz * dz;
+                    wl[g] = __expf(-d2 * inv2s2);
+                }
+            }
+            float s = wl[g];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+            S[g] = s + 0.001f;
+            live[g] = __ballot(wl[g] != 0.f);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            while (live[g]) {
+                const int l = __builtin_ctzll(live[g]);
+                const int jj = __builtin_amdgcn_readlane(jl[g], l);
+                const float *Tj = T + (size_t)jj * CC;
+                float tj[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) tj[r] = (lane + 64 * r < CC) ? Tj[lane + 64 * r] : 0.f;
+#pragma unroll
+                for (int g2 = g; g2 < G; ++g2) { // point g finds its own entry the same way
+                    const unsigned long long m = __ballot(jl[g2] == jj) & live[g2];
+                    if (m) {
+                        const float wj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(wl[g2]), __builtin_ctzll(m)));
+                        live[g2] &= ~m;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const float d = ti[g2][r] - tj[r];
+                            acc[g2] = fmaf(wj * d, d, acc[g2]); // padded lanes: ti = tj = 0
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float a = acc[g];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+            if (lane == 0 && pi[g] >= 0) per_point[pi[g]] = a / S[g];
+        }
+    }
+}
+
 // ---- threeD_space_loss backward without atomics: gather over the graph and its reverse --------
 //   grad_T[i] = sum_{j in N(i)} c_i w_ij (T_i - T_j)  +  sum_{j : i in N(j)} c_j w_ij (T_i - T_j),
 //   c_x = 2 * gscale / (sum_l w_xl + 1e-3),  w symmetric in the positions and 0 across labels,
@@ -715,6 +797,108 @@ __global__ __launch_bounds__(256) void tl_grad_gather_kernel(
     }
 }
 
+// Gather backward, G consecutive points of the spatial order per wave, neighbour rows shared: a row is
+// loaded once and applied to every point of the wave that has it as an out- or an in-neighbour (most kNN
+// edges are mutual, so even a single point usually meets each neighbour twice).
+template <int CC, int G>
+__global__ __launch_bounds__(256) void tl_grad_gather_shared_kernel(
+    int total_pts, int n, int k, float gscale, const float *__restrict__ T, const int *__restrict__ nbr,
+    const float *__restrict__ wout, const float *__restrict__ S, const int *__restrict__ off,
+    const int *__restrict__ rev, const float *__restrict__ revc, const int *__restrict__ order,
+    float *__restrict__ grad_T)
+{
+    constexpr int R = (CC + 63) / 64;
+    const int lane = lane_id();
+    const float two_g = 2.f * gscale;
+    const int xcd_chunk = (((total_pts + 7) >> 3) + 4 * G - 1) / (4 * G) * (4 * G);
+    for (int t = blockIdx.x >> 3;; t += gridDim.x >> 3) {
+        const int within = (t * 4 + (threadIdx.x >> 6)) * G;
+        if (within >= xcd_chunk) break;
+        const int ii0 = (blockIdx.x & 7) * xcd_chunk + within;
+        if (ii0 >= total_pts) break;
+        int pi[G], jo[G], ji[G], r0[G], nin[G];
+        float co[G], ci[G], ti[G][R], acc[G][R];
+        unsigned long long lo[G], li[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const bool ok = ii0 + g < total_pts && within + g < xcd_chunk;
+            const int i = ok ? (order ? order[ii0 + g] : ii0 + g) : -1;
+            pi[g] = i;
+            jo[g] = -1; ji[g] = -1; co[g] = 0.f; ci[g] = 0.f; r0[g] = 0; nin[g] = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                ti[g][r] = (i >= 0 && lane + 64 * r < CC) ? T[(size_t)i * CC + lane + 64 * r] : 0.f;
+                acc[g][r] = 0.f;
+            }
+            if (i >= 0) {
+                r0[g] = off[i];
+                nin[g] = off[i + 1] - r0[g];
+                if (lane < k) {
+                    jo[g] = (i / n) * n + nbr[(size_t)i * k + lane];
+                    co[g] = two_g * (wout[(size_t)i * k + lane] / S[i]);
+                }
+                if (lane < nin[g]) { ji[g] = rev[r0[g] + lane]; ci[g] = two_g * revc[r0[g] + lane]; }
+            }
+            lo[g] = __ballot(co[g] != 0.f);
+            li[g] = __ballot(ci[g] != 0.f);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            while (lo[g] | li[g]) {
+                int jj;
+                if (lo[g]) jj = __builtin_amdgcn_readlane(jo[g], __builtin_ctzll(lo[g]));
+                else jj = __builtin_amdgcn_readlane(ji[g], __builtin_ctzll(li[g]));
+                const float *Tj = T + (size_t)jj * CC;
+                float tj[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) tj[r] = (lane + 64 * r < CC) ? Tj[lane + 64 * r] : 0.f;
+#pragma unroll
+                for (int g2 = g; g2 < G; ++g2) {
+                    const unsigned long long mo = __ballot(jo[g2] == jj) & lo[g2];
+                    const unsigned long long mi = __ballot(ji[g2] == jj) & li[g2];
+                    if (mo | mi) {
+                        float cf = 0.f;
+                        if (mo) cf += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(co[g2]), __builtin_ctzll(mo)));
+                        if (mi) cf += __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ci[g2]), __builtin_ctzll(mi)));
+                        lo[g2] &= ~mo;
+                        li[g2] &= ~mi;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[g2][r] = fmaf(cf, ti[g2][r] - tj[r], acc[g2][r]);
+                    }
+                }
+            }
+            // in-edges beyond the 64 kept in lanes (rare): unshared
+            for (int e0 = 64; e0 < nin[g]; e0 += 64) {
+                int j = 0;
+                float cf = 0.f;
+                if (e0 + lane < nin[g]) { j = rev[r0[g] + e0 + lane]; cf = two_g * revc[r0[g] + e0 + lane]; }
+                unsigned long long live = __ballot(cf != 0.f);
+                while (live) {
+                    const int l = __builtin_ctzll(live);
+                    live &= live - 1;
+                    const int jj = __builtin_amdgcn_readlane(j, l);
+                    const float c1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cf), l));
+                    const float *Tj = T + (size_t)jj * CC;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int e = lane + 64 * r;
+                        if (e < CC) acc[g][r] = fmaf(c1, ti[g][r] - Tj[e], acc[g][r]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (pi[g] < 0) continue;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int e = lane + 64 * r;
+                if (e < CC) grad_T[(size_t)pi[g] * CC + e] += acc[g][r];
+            }
+        }
+    }
+}
+
 // out[e] += sum over blocks of partial[blk][e]; grid.y slices the blocks 32 at a time
 __global__ __launch_bounds__(256) void ntm_partial_reduce_kernel(int nblk, int len, const float *__restrict__ partial,
                                                                  float *__restrict__ out)
@@ -890,12 +1074,18 @@ GEOT_EXPORT int geot_ntm_threed_loss_ord(int b, int n, int c, int k, float sigma
     if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
-    int blocks = (b * n + 3) / 4;
-    if (blocks > 16384) blocks = 16384;
-    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
-    hipLaunchKernelGGL((threed_loss_kernel<CC, false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, 3, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr, order,
-                       per_point, nullptr);
+    const char *ge = getenv("GEOT_NTM_G");
+    const int Gsel = ge ? atoi(ge) : 4;
+#define GEOT_TL_FWD(G)                                                                                              \
+    {                                                                                                               \
+        int blocks = (b * n + 4 * G - 1) / (4 * G);                                                                 \
+        if (blocks > 16384) blocks = 16384;                                                                         \
+        blocks = (blocks + 7) & ~7;                                                                                 \
+        hipLaunchKernelGGL((threed_loss_shared_kernel<CC, G>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,     \
+                           b * n, n, k, 1.f / (2.f * sigma * sigma), positions, labels, ins_T, nbr, order, per_point); \
+    }
+    if (Gsel == 2) GEOT_TL_FWD(2) else if (Gsel == 3) GEOT_TL_FWD(3) else if (Gsel == 6) GEOT_TL_FWD(6) else GEOT_TL_FWD(4)
+#undef GEOT_TL_FWD
     return hipGetLastError();
 }
 
@@ -946,11 +1136,18 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float s
     hipLaunchKernelGGL(tl_scan_add_kernel, dim3(nblk), dim3(1024), 0, s, t, off, bsum, cursor);
     hipLaunchKernelGGL(tl_fill_kernel, dim3(eb), dim3(256), 0, s, t, n, k, seg_shift, nbr, wout, S, off, order, cursor,
                        rev, revc);
-    int blocks = (t + 3) / 4;
-    if (blocks > 16384) blocks = 16384;
-    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
-    hipLaunchKernelGGL((tl_grad_gather_kernel<CC>), dim3(blocks), dim3(256), 0, s, t, n, k, grad_scale, ins_T, nbr,
-                       wout, S, off, rev, revc, order, grad_ins_T);
+    const char *ge = getenv("GEOT_NTM_G");
+    const int Gsel = ge ? atoi(ge) : 4;
+#define GEOT_TL_BWD(G)                                                                                              \
+    {                                                                                                               \
+        int blocks = (t + 4 * G - 1) / (4 * G);                                                                     \
+        if (blocks > 16384) blocks = 16384;                                                                         \
+        blocks = (blocks + 7) & ~7;                                                                                 \
+        hipLaunchKernelGGL((tl_grad_gather_shared_kernel<CC, G>), dim3(blocks), dim3(256), 0, s, t, n, k, grad_scale, \
+                           ins_T, nbr, wout, S, off, rev, revc, order, grad_ins_T);                                 \
+    }
+    if (Gsel == 2) GEOT_TL_BWD(2) else if (Gsel == 3) GEOT_TL_BWD(3) else if (Gsel == 6) GEOT_TL_BWD(6) else GEOT_TL_BWD(4)
+#undef GEOT_TL_BWD
     return hipGetLastError();
 }
 
