@@ -223,6 +223,9 @@ __global__ __launch_bounds__(256) void kg_scatter_kernel(int nr, const float *__
 }
 
 constexpr int KG_WAVES = 4;
+constexpr int KG_SLOTS = 12;    // 64-record register slots of the select fast path
+constexpr int KG_SEL_KMIN = 8;  // short lists are cheap to build by insertion
+constexpr int KG_SEL_KMAX = 48; // beyond that the window k <= count <= 64 is too narrow to be worth probing
 constexpr int KG_DPP_WAVE_SHR1 = 0x138;
 __device__ __forceinline__ float kg_shr1(float v)
 {
@@ -298,6 +301,111 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_kernel(
     // inserted -- as in the brute-force kernel, whose test is d < tau.
 
     const int rmax = max(max(max(cx, dx - 1 - cx), max(cy, dy - 1 - cy)), max(cz, dz - 1 - cz));
+
+    // ---- fast path: the whole 3 x 3 x 3 block in registers, threshold select + rank sort --------------
+    // Inserting candidates one by one costs ~25 dependent instructions each and a query sees ~3 k of them
+    // in arbitrary order (~k (1 + ln 3) insertions).  Instead: all distances of the block into <= KG_SLOTS
+    // register slots; a few counting probes (compare + ballot + popcount per slot) find a threshold tau with
+    // k <= #{d <= tau} <= 64 that is also STRICTLY inside the certified radius of the block (every unvisited
+    // point is farther than tau); those <= 64 survivors are compacted through LDS, ranked by (d2, index)
+    // with one readlane loop, and lanes with rank < k write the answer.  Anything unusual (rows too long,
+    // no such tau: heavy ties or the k-th neighbour outside the block) falls through to the general loop.
+    if (k >= KG_SEL_KMIN && k <= KG_SEL_KMAX) {
+        __shared__ float kg_sd[KG_WAVES][64];
+        __shared__ int kg_si[KG_WAVES][64];
+        int rs = 0, re = 0;
+        if (lane < 9) {
+            const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
+            if (y >= 0 && y < dy && z >= 0 && z < dz) {
+                const int base = (z * dy + y) * dx;
+                rs = start[base + max(cx - 1, 0)];
+                re = start[base + min(cx + 1, dx - 1) + 1];
+            }
+        }
+        int slots = (re - rs + 63) >> 6;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) slots += __shfl_xor(slots, o, 16); // lanes 0..15 (9 rows + zeros)
+        slots = __builtin_amdgcn_readfirstlane(slots);
+        float b2 = 3.0e38f; // largest admissible threshold: finite, and strictly inside the certified radius
+        if (rmax > 1) {
+            float bound = INFINITY;
+            if (cx - 1 > 0) bound = fminf(bound, qx - (g.lo[0] + (float)(cx - 1) * g.h));
+            if (cx + 1 < dx - 1) bound = fminf(bound, (g.lo[0] + (float)(cx + 2) * g.h) - qx);
+            if (cy - 1 > 0) bound = fminf(bound, qy - (g.lo[1] + (float)(cy - 1) * g.h));
+            if (cy + 1 < dy - 1) bound = fminf(bound, (g.lo[1] + (float)(cy + 2) * g.h) - qy);
+            if (cz - 1 > 0) bound = fminf(bound, qz - (g.lo[2] + (float)(cz - 1) * g.h));
+            if (cz + 1 < dz - 1) bound = fminf(bound, (g.lo[2] + (float)(cz + 2) * g.h) - qz);
+            bound = fmaxf(bound - g.h * 1e-3f, 0.f);
+            b2 = fminf(bound * bound * 0.9999f, 3.0e38f); // NaN query -> NaN -> the probes below fail -> general loop
+        }
+        if (slots <= KG_SLOTS && b2 > 0.f) {
+            float d[KG_SLOTS];
+            int id[KG_SLOTS];
+            int row = 0, a = __builtin_amdgcn_readlane(rs, 0), e = __builtin_amdgcn_readlane(re, 0);
+#pragma unroll
+            for (int sl = 0; sl < KG_SLOTS; ++sl) {
+                while (row < 9 && a >= e) {
+                    ++row;
+                    if (row < 9) { a = __builtin_amdgcn_readlane(rs, row); e = __builtin_amdgcn_readlane(re, row); }
+                }
+                d[sl] = INFINITY;
+                id[sl] = 0;
+                if (row < 9) {
+                    if (a + lane < e) {
+                        const float4 pr = rec[a + lane];
+                        d[sl] = sqdist3(qx, qy, qz, pr.x, pr.y, pr.z);
+                        id[sl] = __float_as_int(pr.w);
+                    }
+                    a += 64;
+                }
+            }
+            auto count_le = [&](float tau) {
+                int c = 0;
+#pragma unroll
+                for (int sl = 0; sl < KG_SLOTS; ++sl) c += __popcll(__ballot(d[sl] <= tau));
+                return c;
+            };
+            float tau = b2;
+            int c = count_le(tau);
+            bool found = c >= k && c <= 64;
+            if (c > 64) { // bisect between a threshold with too few and one with too many survivors
+                float lo_t = 0.f, hi_t = b2;
+                for (int it = 0; it < 12 && !found; ++it) {
+                    tau = 0.5f * (lo_t + hi_t);
+                    c = count_le(tau);
+                    if (c < k) lo_t = tau;
+                    else if (c > 64) hi_t = tau;
+                    else found = true;
+                }
+            }
+            if (found) {
+                int base = 0;
+#pragma unroll
+                for (int sl = 0; sl < KG_SLOTS; ++sl) {
+                    const bool sel = d[sl] <= tau;
+                    const unsigned long long m = __ballot(sel);
+                    const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+                    if (sel) { kg_sd[wave][pos] = d[sl]; kg_si[wave][pos] = id[sl]; }
+                    base += __popcll(m);
+                }
+                const float cd = lane < c ? kg_sd[wave][lane] : INFINITY;
+                const int ci = lane < c ? kg_si[wave][lane] : 0x7fffffff;
+                int rank = 0;
+                for (int jx = 0; jx < c; ++jx) {
+                    const float dj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cd), jx));
+                    const int ij = __builtin_amdgcn_readlane(ci, jx);
+                    rank += (dj < cd || (dj == cd && ij < ci)) ? 1 : 0;
+                }
+                if (lane < c && rank < k) {
+                    const size_t o = ((size_t)bi * nq + j) * k + rank;
+                    idx[o] = ci;
+                    dist2[o] = cd;
+                }
+                return;
+            }
+        }
+    }
+
     for (int r = 1;; ++r) {
         // rows (y, z) of the ring: r == 1 takes the whole 3x3x3 block (rings 0 and 1); r >= 2 only the shell
         const int side = 2 * r + 1, nrows = side * side;
