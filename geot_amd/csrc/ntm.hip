@@ -537,11 +537,24 @@ __global__ __launch_bounds__(256) void threed_loss_kernel(
 // neighbour lists in lanes, and every neighbour row it loads is applied to ALL of its points that list it
 // (membership = one ballot per point), so a row shared by 3 of the 4 points is fetched once, not 3 times.
 // The row gathers from L2 are what bounds this kernel; the arithmetic per (point, row) pair is unchanged.
-template <int CC, int G>
+// Graph arrays a forward pass can leave behind for its backward (see geot_ntm_threed_loss_fwd_graph):
+// fixed-capacity reverse adjacency (TLG_CAP in-edges per point, the rest in an overflow list).
+constexpr int TLG_CAP = 64;
+struct TlGraph {
+    float *S;     // [t]      per-point normaliser
+    float *wout;  // [t*k]    out-edge weights
+    int *cnt;     // [t]      in-degree (may exceed TLG_CAP; zero on entry)
+    int *rev;     // [t*CAP]  in-edge sources
+    float *revc;  // [t*CAP]  in-edge coefficients w / S_source
+    int *ovf_cnt; // [1]      entries in the overflow list (zero on entry)
+    int *ovf;     // [t*k*3]  (target, source, bits(coefficient))
+};
+
+template <int CC, int G, bool BUILD>
 __global__ __launch_bounds__(256) void threed_loss_shared_kernel(
     int total_pts, int n, int k, float inv2s2, const float *__restrict__ pos, const int *__restrict__ labels,
     const float *__restrict__ T, const int *__restrict__ nbr, const int *__restrict__ order,
-    float *__restrict__ per_point)
+    float *__restrict__ per_point, TlGraph gr)
 {
     constexpr int R = (CC + 63) / 64;
     const int lane = lane_id();
@@ -578,6 +591,27 @@ __global__ __launch_bounds__(256) void threed_loss_shared_kernel(
             for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
             S[g] = s + 0.001f;
             live[g] = __ballot(wl[g] != 0.f);
+            if (BUILD && i >= 0) {
+                // leave the graph behind: weights, normaliser, and this point entered as an in-neighbour of each
+                // of its live out-neighbours (the atomics overlap with the row gathers below)
+                if (lane == 0) gr.S[i] = S[g];
+                if (lane < k) {
+                    gr.wout[(size_t)i * k + lane] = wl[g];
+                    if (wl[g] != 0.f) {
+                        const int slot = atomicAdd(&gr.cnt[jl[g]], 1);
+                        const float cf = wl[g] / S[g];
+                        if (slot < TLG_CAP) {
+                            gr.rev[(size_t)jl[g] * TLG_CAP + slot] = i;
+                            gr.revc[(size_t)jl[g] * TLG_CAP + slot] = cf;
+                        } else {
+                            const int o = atomicAdd(gr.ovf_cnt, 1); // < t*k by construction: one entry per edge at most
+                            gr.ovf[3 * (size_t)o] = jl[g];
+                            gr.ovf[3 * (size_t)o + 1] = i;
+                            gr.ovf[3 * (size_t)o + 2] = __float_as_int(cf);
+                        }
+                    }
+                }
+            }
         }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -800,7 +834,9 @@ __global__ __launch_bounds__(256) void tl_grad_gather_kernel(
 // Gather backward, G consecutive points of the spatial order per wave, neighbour rows shared: a row is
 // loaded once and applied to every point of the wave that has it as an out- or an in-neighbour (most kNN
 // edges are mutual, so even a single point usually meets each neighbour twice).
-template <int CC, int G>
+// FIXED: the reverse lists are the fixed-capacity ones a forward pass left (off = in-degree counts, list of
+// point i at rev[i * TLG_CAP ..]); otherwise the CSR built by geot_ntm_threed_loss_grad_ws.
+template <int CC, int G, bool FIXED>
 __global__ __launch_bounds__(256) void tl_grad_gather_shared_kernel(
     int total_pts, int n, int k, float gscale, const float *__restrict__ T, const int *__restrict__ nbr,
     const float *__restrict__ wout, const float *__restrict__ S, const int *__restrict__ off,
@@ -831,8 +867,8 @@ __global__ __launch_bounds__(256) void tl_grad_gather_shared_kernel(
                 acc[g][r] = 0.f;
             }
             if (i >= 0) {
-                r0[g] = off[i];
-                nin[g] = off[i + 1] - r0[g];
+                if (FIXED) { r0[g] = i * TLG_CAP; nin[g] = min(off[i], TLG_CAP); }
+                else { r0[g] = off[i]; nin[g] = off[i + 1] - r0[g]; }
                 if (lane < k) {
                     jo[g] = (i / n) * n + nbr[(size_t)i * k + lane];
                     co[g] = two_g * (wout[(size_t)i * k + lane] / S[i]);
@@ -896,6 +932,22 @@ __global__ __launch_bounds__(256) void tl_grad_gather_shared_kernel(
                 if (e < CC) grad_T[(size_t)pi[g] * CC + e] += acc[g][r];
             }
         }
+    }
+}
+
+// in-edges that did not fit a point's TLG_CAP slots (hubs; rare): grad_T[tgt] += 2 g c (T_tgt - T_src)
+template <int CC>
+__global__ __launch_bounds__(256) void tl_overflow_kernel(int cap, float gscale, const float *__restrict__ T,
+                                                          const int *__restrict__ ovf_cnt, const int *__restrict__ ovf,
+                                                          float *__restrict__ grad_T)
+{
+    const int lane = lane_id();
+    const int cnt = min(*ovf_cnt, cap);
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < cnt; e += gridDim.x * 4) {
+        const int tgt = ovf[3 * (size_t)e], src = ovf[3 * (size_t)e + 1];
+        const float cf = 2.f * gscale * __int_as_float(ovf[3 * (size_t)e + 2]);
+        for (int el = lane; el < CC; el += 64)
+            atomicAdd(grad_T + (size_t)tgt * CC + el, cf * (T[(size_t)tgt * CC + el] - T[(size_t)src * CC + el]));
     }
 }
 
@@ -1081,8 +1133,9 @@ GEOT_EXPORT int geot_ntm_threed_loss_ord(int b, int n, int c, int k, float sigma
         int blocks = (b * n + 4 * G - 1) / (4 * G);                                                                 \
         if (blocks > 16384) blocks = 16384;                                                                         \
         blocks = (blocks + 7) & ~7;                                                                                 \
-        hipLaunchKernelGGL((threed_loss_shared_kernel<CC, G>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,     \
-                           b * n, n, k, 1.f / (2.f * sigma * sigma), positions, labels, ins_T, nbr, order, per_point); \
+        hipLaunchKernelGGL((threed_loss_shared_kernel<CC, G, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, \
+                           b * n, n, k, 1.f / (2.f * sigma * sigma), positions, labels, ins_T, nbr, order, per_point, \
+                           TlGraph{});                                                                              \
     }
     if (Gsel == 2) GEOT_TL_FWD(2) else if (Gsel == 3) GEOT_TL_FWD(3) else if (Gsel == 6) GEOT_TL_FWD(6) else GEOT_TL_FWD(4)
 #undef GEOT_TL_FWD
@@ -1143,11 +1196,78 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float s
         int blocks = (t + 4 * G - 1) / (4 * G);                                                                     \
         if (blocks > 16384) blocks = 16384;                                                                         \
         blocks = (blocks + 7) & ~7;                                                                                 \
-        hipLaunchKernelGGL((tl_grad_gather_shared_kernel<CC, G>), dim3(blocks), dim3(256), 0, s, t, n, k, grad_scale, \
+        hipLaunchKernelGGL((tl_grad_gather_shared_kernel<CC, G, false>), dim3(blocks), dim3(256), 0, s, t, n, k, grad_scale, \
                            ins_T, nbr, wout, S, off, rev, revc, order, grad_ins_T);                                 \
     }
     if (Gsel == 2) GEOT_TL_BWD(2) else if (Gsel == 3) GEOT_TL_BWD(3) else if (Gsel == 6) GEOT_TL_BWD(6) else GEOT_TL_BWD(4)
 #undef GEOT_TL_BWD
+    return hipGetLastError();
+}
+
+static TlGraph tl_graph_views(void *workspace, long long t, int k)
+{
+    TlGraph g;
+    g.S = (float *)workspace;
+    g.wout = g.S + t;
+    g.cnt = (int *)(g.wout + t * k);
+    g.ovf_cnt = g.cnt + t; // adjacent to cnt: one memset clears both
+    g.rev = g.ovf_cnt + 4;
+    g.revc = (float *)(g.rev + t * TLG_CAP);
+    g.ovf = (int *)(g.revc + t * TLG_CAP);
+    return g;
+}
+
+GEOT_EXPORT long long geot_ntm_threed_graph_bytes(int b, int n, int k)
+{
+    if (b < 0 || n < 0 || k < 0) return -1;
+    const long long t = (long long)b * n;
+    return 4 * (t + t * k + t + 4 + 2 * t * TLG_CAP + 3 * t * k) + 64;
+}
+
+// Forward of threeD_space_loss that also leaves the kNN graph's reverse adjacency, edge weights and
+// normalisers in `graph` (geot_ntm_threed_graph_bytes(b, n, k) bytes) for geot_ntm_threed_loss_grad_graph:
+// the backward is then the gather alone, no graph building.  `order` may be NULL.
+GEOT_EXPORT int geot_ntm_threed_loss_fwd_graph(int b, int n, int c, int k, float sigma, const float *positions,
+                                               const int *labels, const float *ins_T, const int *nbr,
+                                               const int *order, float *per_point, void *graph,
+                                               long long graph_bytes, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    if (!graph || graph_bytes < geot_ntm_threed_graph_bytes(b, n, k) || (long long)b * n * TLG_CAP > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
+    constexpr int G = 4;
+    const long long t = (long long)b * n;
+    TlGraph g = tl_graph_views(graph, t, k);
+    hipError_t e = hipMemsetAsync(g.cnt, 0, (size_t)(t + 4) * sizeof(int), (hipStream_t)stream);
+    if (e != hipSuccess) return e;
+    int blocks = (int)((t + 4 * G - 1) / (4 * G));
+    if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7;
+    hipLaunchKernelGGL((threed_loss_shared_kernel<CC, G, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, b * n,
+                       n, k, 1.f / (2.f * sigma * sigma), positions, labels, ins_T, nbr, order, per_point, g);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_threed_loss_grad_graph(int b, int n, int c, int k, float grad_scale, const float *ins_T,
+                                                const int *nbr, const int *order, const void *graph,
+                                                long long graph_bytes, float *grad_ins_T, void *stream)
+{
+    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64) return hipErrorInvalidValue;
+    if ((long long)b * n == 0) return hipSuccess;
+    if (!graph || graph_bytes < geot_ntm_threed_graph_bytes(b, n, k)) return hipErrorInvalidValue;
+    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
+    constexpr int G = 4;
+    const long long t = (long long)b * n;
+    const TlGraph g = tl_graph_views(const_cast<void *>(graph), t, k);
+    int blocks = (int)((t + 4 * G - 1) / (4 * G));
+    if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7;
+    hipLaunchKernelGGL((tl_grad_gather_shared_kernel<CC, G, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (int)t, n, k, grad_scale, ins_T, nbr, g.wout, g.S, g.cnt, g.rev, g.revc, order, grad_ins_T);
+    hipLaunchKernelGGL((tl_overflow_kernel<CC>), dim3(64), dim3(256), 0, (hipStream_t)stream, (int)(t * k), grad_scale,
+                       ins_T, g.ovf_cnt, g.ovf, grad_ins_T);
     return hipGetLastError();
 }
 

@@ -187,23 +187,36 @@ class _ThreeDLossFn(Function):
              "threeD_space_loss shape mismatch")
         per_point = torch.empty(b * n, dtype=torch.float32, device=dev)
         order = spatial_order(positions)      # processing order only: neighbour rows then hit L2
-        call("geot_ntm_threed_loss_ord", dev, b, n, c, k, float(sigma), ptr(positions), ptr(labels), ptr(ins_T),
-             ptr(nbr), ptr(order), ptr(per_point))
-        ctx.save_for_backward(positions, labels, ins_T, nbr, order)
+        mode = os.environ.get("GEOT_NTM_GRAD", "graph")   # graph | gather | atomic (A/B tests)
+        graph = None
+        if ctx.needs_input_grad[2] and mode == "graph":
+            # the forward pass leaves the reverse adjacency behind: the backward is then the gather alone
+            gbytes = int(_lib.load().geot_ntm_threed_graph_bytes(b, n, k))
+            graph = torch.empty(gbytes, dtype=torch.uint8, device=dev)
+            call("geot_ntm_threed_loss_fwd_graph", dev, b, n, c, k, float(sigma), ptr(positions), ptr(labels),
+                 ptr(ins_T), ptr(nbr), ptr(order), ptr(per_point), ptr(graph), gbytes)
+        else:
+            call("geot_ntm_threed_loss_ord", dev, b, n, c, k, float(sigma), ptr(positions), ptr(labels), ptr(ins_T),
+                 ptr(nbr), ptr(order), ptr(per_point))
+        ctx.save_for_backward(positions, labels, ins_T, nbr, order, graph)
         ctx.sigma = float(sigma)
+        ctx.mode = mode
         return per_point.mean()
 
     @staticmethod
     def backward(ctx, grad_out):
-        positions, labels, ins_T, nbr, order = ctx.saved_tensors
+        positions, labels, ins_T, nbr, order, graph = ctx.saved_tensors
         b, n, _ = positions.shape
         c, k = ins_T.shape[1], nbr.shape[2]
         g = torch.zeros_like(ins_T)
         scale = float(grad_out.item()) / (b * n) if grad_out.numel() == 1 else 1.0 / (b * n)
-        if os.environ.get("GEOT_NTM_GRAD", "gather") == "atomic":   # the scatter form (A/B tests)
+        if graph is not None:
+            call("geot_ntm_threed_loss_grad_graph", positions.device, b, n, c, k, scale, ptr(ins_T), ptr(nbr),
+                 ptr(order), ptr(graph), graph.numel(), ptr(g))
+        elif ctx.mode == "atomic":   # the scatter form
             call("geot_ntm_threed_loss_grad", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
                  ptr(labels), ptr(ins_T), ptr(nbr), ptr(g))
-        else:
+        else:                        # graph rebuilt here (callers that did not keep the forward's)
             nbytes = int(_lib.load().geot_ntm_threed_loss_ws_bytes(b, n, k))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=positions.device)
             call("geot_ntm_threed_loss_grad_ws", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),

@@ -116,15 +116,42 @@ def test_threed_space_loss_forward_backward(B, N, k, nlab, oracle):
     from geot_amd.ntm import spatial_order
     od = spatial_order(pos).cpu().numpy()
     assert np.array_equal(np.sort(od), np.arange(B * N)) and np.all(od // N == np.repeat(np.arange(B), N))
-    # the scatter (atomic) form of the backward gives the same gradient
+    # the other two backward forms (graph rebuilt in the backward; scatter with atomics) give the same gradient
     import os
-    os.environ["GEOT_NTM_GRAD"] = "atomic"
-    try:
-        t2 = T(insT).requires_grad_(True)
-        crit(pos, T(labels, torch.int64), t2).backward()
-    finally:
-        del os.environ["GEOT_NTM_GRAD"]
-    np.testing.assert_allclose(t2.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
+    for mode in ("gather", "atomic"):
+        os.environ["GEOT_NTM_GRAD"] = mode
+        try:
+            t2 = T(insT).requires_grad_(True)
+            l2 = crit(pos, T(labels, torch.int64), t2)
+            l2.backward()
+        finally:
+            del os.environ["GEOT_NTM_GRAD"]
+        assert abs(l2.item() - want) <= 2e-5 * abs(want) + 1e-9
+        np.testing.assert_allclose(t2.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
+
+
+def test_threed_space_loss_hubs_overflow_the_fixed_lists(oracle):
+    """Hundreds of points all listing the same few neighbours (exact duplicates): in-degrees far above the 64
+    slots a point has in the forward-built graph, so the overflow list carries most edges."""
+    from geot_amd.ntm import threeD_space_loss
+    rng = np.random.default_rng(9)
+    B, N, k = 1, 900, 8
+    xyz = rng.standard_normal((B, N, 3)).astype(np.float32) * 0.3
+    xyz[:, 100:700] = xyz[:, 5:6]                       # 600 copies of point 5
+    labels = np.zeros((B, N), np.int64)
+    insT = np_ntm.l1_normalize(rng.random((B * N, C, C)) + 0.01, 2).astype(np.float32)
+    crit = threeD_space_loss(k=k, sigma=1.0, num_classes=C)
+    pos, tT = T(xyz), T(insT).requires_grad_(True)
+    nbr = crit.neighbours(pos)
+    widx, _ = oracle.knn_sorted(xyz, xyz, k + 1)
+    assert np.array_equal(nbr.cpu().numpy(), widx[:, :, 1:])
+    indeg = np.bincount(widx[0, :, 1:].ravel(), minlength=N)
+    assert indeg.max() > 64
+    loss = crit(pos, T(labels, torch.int64), tT)
+    want, wgrad, _ = np_ntm.threed_space_loss(xyz, labels, insT, widx[:, :, 1:], 1.0)
+    assert abs(loss.item() - want) <= 2e-5 * abs(want) + 1e-9
+    loss.backward()
+    np.testing.assert_allclose(tT.grad.cpu().numpy(), wgrad, rtol=1e-3, atol=2e-4 * np.abs(wgrad).max())
 
 
 @pytest.mark.parametrize("B,N,k,nlab", [(2, 300, 7, 3), (1, 1500, 16, 17)])
