@@ -237,6 +237,8 @@ def main():
                      "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                      "traffic": pmc_traffic("fps_pruned_kernel") if workload == "sa" and B == 1 else None,
                      "avg_launch_ms": fps_ms,
+                     # one cloud = one workgroup = one CU: the share of the chip a launch can reach is B / 256
+                     "cus_used": B, "frac_of_cus_used": achieved / (FP32_VECTOR_PEAK_TFLOPS * min(B, 256) / 256.0),
                      "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic "
                              "flop = clouds*N*(m-1) updates * 10 (what the reference executes); the pruned kernel "
                              "skips most of them exactly; one workgroup (one CU of 256) per cloud"},
