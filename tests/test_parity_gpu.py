@@ -150,6 +150,36 @@ def test_fps_full_size_vs_oracle_and_properties(ext, oracle, fps_impl):
         assert mind[sel[j + 1]] >= mind.max() * (1 - 1e-6)
 
 
+@pytest.mark.parametrize("shape", ["lattice", "line", "clusters", "dups50", "outlier", "plane_ties"])
+def test_fps_adversarial_geometry(ext, oracle, fps_impl, shape):
+    """Geometries that stress the pruned / multi-commit kernels: exact distance ties between waves (lattices),
+    degenerate bounding boxes (line, plane), most cells empty (outlier), half the cloud duplicated, tight
+    clusters.  Indices AND the final min-distance buffer must equal the oracle's, for both tie rules."""
+    rng = np.random.default_rng(17)
+    n, m = 12000, 700
+    if shape == "lattice":
+        g = np.stack(np.meshgrid(np.arange(23), np.arange(23), np.arange(23)), -1).reshape(-1, 3)[:n]
+        x = (g / 32.0).astype(np.float32)
+    elif shape == "line":
+        x = np.zeros((n, 3), np.float32); x[:, 0] = (np.arange(n) % 4000) / 4000.0
+    elif shape == "clusters":
+        x = (rng.integers(0, 6, (n, 1)) * 0.15 + rng.standard_normal((n, 3)) * 1e-3).astype(np.float32)
+    elif shape == "dups50":
+        x = (rng.random((n, 3)) * 0.9).astype(np.float32); x[n // 2:] = x[rng.integers(0, n // 2, n - n // 2)]
+    elif shape == "outlier":
+        x = (rng.random((n, 3)) * 0.01).astype(np.float32); x[77] = (0.9, -0.9, 0.5)
+    else:
+        side = 110
+        gx, gy = np.meshgrid(np.arange(side, dtype=np.float32), np.arange(side, dtype=np.float32))
+        x = np.stack([gx.ravel()[:n] / 128, gy.ravel()[:n] / 128, np.full(n, 0.25, np.float32)], 1)
+    x = np.ascontiguousarray(x[None])
+    got, temp = fps_k1p(ext, x, m, return_temp=True)
+    want, wtemp = oracle.fps_dense(x, m, 1024, False, return_temp=True)
+    assert np.array_equal(got, want)
+    assert np.array_equal(temp, wtemp)
+    assert np.array_equal(fps_k1(ext, x, m), oracle.fps_dense(x, m, 512, True))
+
+
 def test_fps_streaming_path_large_cloud(ext, oracle, fps_impl):
     xyz, _ = make_batch(1, 30000, start_index=4)  # > 24576 points: not register-resident
     assert np.array_equal(fps_k1p(ext, xyz, 300), oracle.fps_dense(xyz, 300, 1024, False))
