@@ -770,67 +770,6 @@ __global__ __launch_bounds__(256) void tl_fill_kernel(int total_pts, int n, int 
     revc[slot] = w / S[i];
 }
 
-template <int CC>
-__global__ __launch_bounds__(256) void tl_grad_gather_kernel(
-    int total_pts, int n, int k, float gscale, const float *__restrict__ T, const int *__restrict__ nbr,
-    const float *__restrict__ wout, const float *__restrict__ S, const int *__restrict__ off,
-    const int *__restrict__ rev, const float *__restrict__ revc, const int *__restrict__ order,
-    float *__restrict__ grad_T)
-{
-    constexpr int R = (CC + 63) / 64;
-    const int lane = lane_id();
-    // XCD-aware walk of the (spatially sorted) point order: workgroups are dealt round-robin to the 8 XCDs,
-    // so XCD x takes the x-th eighth of the order and its private L2 caches one region of the cloud instead of
-    // all eight L2s caching the same rows.  (Placement is a performance assumption only; any mapping is correct.)
-    const int xcd_chunk = (((total_pts + 7) >> 3) + 3) & ~3;
-    for (int t = blockIdx.x >> 3; ; t += gridDim.x >> 3) {
-        const int within = t * 4 + (threadIdx.x >> 6);
-        if (within >= xcd_chunk) break;
-        const int ii = (blockIdx.x & 7) * xcd_chunk + within;
-        if (ii >= total_pts) break;
-        const int i = order ? order[ii] : ii;
-        const int b = i / n;
-        const float *Ti = T + (size_t)i * CC;
-        float ti[R], acc[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) { ti[r] = (lane + 64 * r < CC) ? Ti[lane + 64 * r] : 0.f; acc[r] = 0.f; }
-        const float two_g = 2.f * gscale, inv_si = 1.f / S[i];
-        const int r0 = off[i], nin = off[i + 1] - r0;
-        // edge list = the k out-neighbours (first pass), then the in-neighbours, 64 per pass
-        for (int e0 = -64; e0 < nin; e0 += 64) {
-            int j = 0;
-            float coef = 0.f;
-            if (e0 < 0) {
-                if (lane < k) {
-                    j = b * n + nbr[(size_t)i * k + lane];
-                    coef = two_g * (wout[(size_t)i * k + lane] * inv_si);
-                }
-            } else if (e0 + lane < nin) {
-                j = rev[r0 + e0 + lane];
-                coef = two_g * revc[r0 + e0 + lane];
-            }
-            unsigned long long live = __ballot(coef != 0.f);
-            while (live) {
-                const int l = __builtin_ctzll(live);
-                live &= live - 1;
-                const int jj = __builtin_amdgcn_readlane(j, l);
-                const float cf = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(coef), l));
-                const float *Tj = T + (size_t)jj * CC;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int e = lane + 64 * r;
-                    if (e < CC) acc[r] = fmaf(cf, ti[r] - Tj[e], acc[r]);
-                }
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int e = lane + 64 * r;
-            if (e < CC) grad_T[(size_t)i * CC + e] += acc[r];
-        }
-    }
-}
-
 // Gather backward, G consecutive points of the spatial order per wave, neighbour rows shared: a row is
 // loaded once and applied to every point of the wave that has it as an out- or an in-neighbour (most kNN
 // edges are mutual, so even a single point usually meets each neighbour twice).
