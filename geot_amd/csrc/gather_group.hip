@@ -17,6 +17,7 @@
 // cloud is 96 KB).
 #include "geot_common.h"
 #include "geot_hip.h"
+#include <cstdlib>
 
 namespace geot {
 
@@ -377,6 +378,108 @@ __global__ __launch_bounds__(GG_THREADS) void graph_feature_grad_q_kernel(
     grad_xq[((size_t)bi * c + l) * nq + i] += acc;
 }
 
+// ---- table-in-LDS gathers ------------------------------------------------------------------------
+// out[b,c,e] = sum_t w[e,t] * table[b,c,idx[e,t]]  (three_interpolate: NT = 3; group / gather: NT = 1, w = 1).
+// In the (B,C,N) layout each lane of a gather hits a different 4-byte word of a
+// channel row: the vector-memory address path handles a few lanes per clock, which caps the kernels above
+// at 0.4-1 TB/s.  A channel row is small (m floats), so a workgroup keeps `ch` whole rows of the table in
+// LDS (up to 144 KB), where 64 random 4-byte reads are one ds_read_b32, and streams its slice of e with
+// coalesced index loads and coalesced stores.  (The transposed scatter with LDS float atomics was measured
+// too and loses to the channels-last workspace scatter below: 0.20 vs 0.13 ms for the prop0 gradient.)
+constexpr int TLDS_THREADS = 512;
+constexpr int TLDS_FLOATS = 36 * 1024; // LDS budget for the table rows (144 KB of the CU's 160 KB)
+
+template <int NT, bool WEIGHTED>
+__global__ __launch_bounds__(TLDS_THREADS) void table_gather_lds_kernel(
+    int c, int m, int L, int ch, const float *__restrict__ table, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ out)
+{
+    extern __shared__ float tlds_rows[]; // [ch][m]
+    const int bi = blockIdx.z, c0 = blockIdx.y * ch, nch = min(ch, c - c0);
+    const float *src = table + ((size_t)bi * c + c0) * m; // nch rows, contiguous
+    for (int e = threadIdx.x; e < nch * m; e += TLDS_THREADS) tlds_rows[e] = src[e];
+    __syncthreads();
+    const int per = (L + gridDim.x - 1) / gridDim.x;
+    const int e0 = blockIdx.x * per, e1 = min(L, e0 + per);
+    // U elements per thread and pass: U x 2 NT independent index / weight loads in flight (one workgroup per
+    // CU -- the rows fill its LDS -- so memory-level parallelism has to come from within the thread)
+    constexpr int U = 4;
+    for (int eb = e0 + threadIdx.x; eb < e1; eb += U * TLDS_THREADS) {
+        int ii[U][NT];
+        float w[U][NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = eb + u * TLDS_THREADS;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                ii[u][t] = e < e1 ? idx[((size_t)bi * L + e) * NT + t] : 0;
+                w[u][t] = (WEIGHTED && e < e1) ? weight[((size_t)bi * L + e) * NT + t] : 1.f;
+            }
+        }
+        for (int l = 0; l < nch; ++l) {
+            const float *R = tlds_rows + l * m;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = eb + u * TLDS_THREADS;
+                float v;
+                if (WEIGHTED) {
+                    v = R[ii[u][0]] * w[u][0];
+#pragma unroll
+                    for (int t = 1; t < NT; ++t) v = v + R[ii[u][t]] * w[u][t]; // ((p0*w0 + p1*w1) + p2*w2), un-contracted
+                } else {
+                    v = R[ii[u][0]];
+                }
+                if (e < e1) out[((size_t)bi * c + c0 + l) * L + e] = v;
+            }
+        }
+    }
+}
+
+// launch geometry: (slices of e, channel chunks, batch); 0 rows -> the table does not fit, use the plain kernels
+struct TldsPlan {
+    int ch, slices;
+    size_t lds;
+};
+static TldsPlan tlds_plan(int b, int c, int m, long long L, int min_ch)
+{
+    TldsPlan p{0, 1, 0};
+    const char *env = getenv("GEOT_GATHER_IMPL"); // "plain" = the register-gather kernels (A/B tests)
+    if ((env && env[0] == 'p') || m < 1 || m > TLDS_FLOATS || L * c < (1 << 16)) return p;
+    int ch = TLDS_FLOATS / m;
+    if (ch < min_ch) return p; // long rows: one or two channels per workgroup do not pay for loading them
+    if (ch > 16) ch = 16;
+    if (ch > c) ch = c;
+    const int chunks = (c + ch - 1) / ch;
+    // enough workgroups for 256 CUs (one per CU: the rows fill its LDS), but slices of >= 4096 elements so that
+    // loading / flushing the rows stays a small part of a workgroup's work; the scatter prefers one owner per row
+    long long want = (512 + (long long)chunks * b - 1) / ((long long)chunks * b);
+    long long maxs = L / 4096;
+    long long sl = want < 1 ? 1 : want;
+    if (sl > maxs) sl = maxs < 1 ? 1 : maxs;
+    if (sl > 64) sl = 64;
+    p.ch = ch;
+    p.slices = (int)sl;
+    p.lds = (size_t)ch * m * sizeof(float);
+    return p;
+}
+
+template <typename K>
+static hipError_t tlds_set_lds(K kernel, size_t lds)
+{
+    if (lds <= 64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <int NT, bool WEIGHTED>
+static hipError_t tlds_gather(const TldsPlan &p, int b, int c, int m, int L, const float *table, const int *idx,
+                              const float *weight, float *out, hipStream_t s)
+{
+    hipError_t e = tlds_set_lds(table_gather_lds_kernel<NT, WEIGHTED>, p.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((table_gather_lds_kernel<NT, WEIGHTED>), dim3(p.slices, (c + p.ch - 1) / p.ch, b),
+                       dim3(TLDS_THREADS), p.lds, s, c, m, L, p.ch, table, idx, weight, out);
+    return hipGetLastError();
+}
 static inline dim3 grid3(long long inner, int c, int b)
 {
     return dim3((unsigned)((inner + GG_THREADS - 1) / GG_THREADS), (unsigned)((c + GG_CCHUNK - 1) / GG_CCHUNK),
@@ -403,6 +506,8 @@ GEOT_EXPORT int geot_gather_points(int b, int c, int n, int m, const float *poin
     if (b < 0 || c < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
     if (b == 0 || c == 0 || m == 0) return hipSuccess;
     GEOT_CHECK_DIMS3(b, c);
+    const TldsPlan tp = tlds_plan(b, c, n, m, 4);
+    if (tp.ch) return tlds_gather<1, false>(tp, b, c, n, m, points, idx, nullptr, out, (hipStream_t)stream);
     hipLaunchKernelGGL(gather_points_kernel, grid3(m, c, b), dim3(GG_THREADS), 0, (hipStream_t)stream, c,
                        n, m, points, idx, out);
     return hipGetLastError();
@@ -427,6 +532,8 @@ GEOT_EXPORT int geot_group_points(int b, int c, int n, int npoints, int nsample,
     if (b == 0 || c == 0 || npns == 0) return hipSuccess;
     if (npns > 0x7fffffffLL) return hipErrorInvalidValue;
     GEOT_CHECK_DIMS3(b, c);
+    const TldsPlan tp = tlds_plan(b, c, n, npns, 4);
+    if (tp.ch) return tlds_gather<1, false>(tp, b, c, n, (int)npns, points, idx, nullptr, out, (hipStream_t)stream);
     hipLaunchKernelGGL(group_points_kernel, grid3(npns, c, b), dim3(GG_THREADS), 0, (hipStream_t)stream,
                        c, n, (int)npns, points, idx, out);
     return hipGetLastError();
@@ -452,6 +559,8 @@ GEOT_EXPORT int geot_three_interpolate(int b, int c, int m, int n, const float *
     if (b < 0 || c < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
     if (b == 0 || c == 0 || n == 0) return hipSuccess;
     GEOT_CHECK_DIMS3(b, c);
+    const TldsPlan tp = tlds_plan(b, c, m, n, 1);
+    if (tp.ch) return tlds_gather<3, true>(tp, b, c, m, n, points, idx, weight, out, (hipStream_t)stream);
     hipLaunchKernelGGL(three_interpolate_kernel, grid3(n, c, b), dim3(GG_THREADS), 0,
                        (hipStream_t)stream, c, m, n, points, idx, weight, out);
     return hipGetLastError();
