@@ -386,7 +386,7 @@ __global__ __launch_bounds__(GG_THREADS) void graph_feature_grad_q_kernel(
 // LDS (up to 144 KB), where 64 random 4-byte reads are one ds_read_b32, and streams its slice of e with
 // coalesced index loads and coalesced stores.  (The transposed scatter with LDS float atomics was measured
 // too and loses to the channels-last workspace scatter below: 0.20 vs 0.13 ms for the prop0 gradient.)
-constexpr int TLDS_THREADS = 512;
+constexpr int TLDS_THREADS = 1024;
 constexpr int TLDS_FLOATS = 36 * 1024; // LDS budget for the table rows (144 KB of the CU's 160 KB)
 
 template <int NT, bool WEIGHTED>
@@ -506,7 +506,7 @@ GEOT_EXPORT int geot_gather_points(int b, int c, int n, int m, const float *poin
     if (b < 0 || c < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
     if (b == 0 || c == 0 || m == 0) return hipSuccess;
     GEOT_CHECK_DIMS3(b, c);
-    const TldsPlan tp = tlds_plan(b, c, n, m, 4);
+    const TldsPlan tp = tlds_plan(b, c, n, m, 1);
     if (tp.ch) return tlds_gather<1, false>(tp, b, c, n, m, points, idx, nullptr, out, (hipStream_t)stream);
     hipLaunchKernelGGL(gather_points_kernel, grid3(m, c, b), dim3(GG_THREADS), 0, (hipStream_t)stream, c,
                        n, m, points, idx, out);
@@ -532,7 +532,7 @@ GEOT_EXPORT int geot_group_points(int b, int c, int n, int npoints, int nsample,
     if (b == 0 || c == 0 || npns == 0) return hipSuccess;
     if (npns > 0x7fffffffLL) return hipErrorInvalidValue;
     GEOT_CHECK_DIMS3(b, c);
-    const TldsPlan tp = tlds_plan(b, c, n, npns, 4);
+    const TldsPlan tp = tlds_plan(b, c, n, npns, 1);
     if (tp.ch) return tlds_gather<1, false>(tp, b, c, n, (int)npns, points, idx, nullptr, out, (hipStream_t)stream);
     hipLaunchKernelGGL(group_points_kernel, grid3(npns, c, b), dim3(GG_THREADS), 0, (hipStream_t)stream,
                        c, n, (int)npns, points, idx, out);
