@@ -480,6 +480,136 @@ static hipError_t tlds_gather(const TldsPlan &p, int b, int c, int m, int L, con
                        dim3(TLDS_THREADS), p.lds, s, c, m, L, p.ch, table, idx, weight, out);
     return hipGetLastError();
 }
+// ---- gradients of the gathers as gathers: reverse index + source rows in LDS --------------------
+// grad_table[b,c,j] += sum over the (e,t) with idx[b,e,t] == j of w[b,e,t] * grad_out[b,c,e].
+// The pairs are grouped by target once per call (count with rank, exclusive scan, fill: three small
+// kernels, no atomics in the fill because the count pass already handed out the ranks); then a workgroup
+// keeps `ch` rows of grad_out (L floats each) in LDS and every thread sums one target's list from LDS:
+// no float atomics at all, and grad_out is read exactly once.  Needs L <= TLDS_FLOATS (the prop0/1/2
+// interpolations, the kNN graph features, the 512-group gather; not the 6000 x 32 SA grouping).
+__global__ __launch_bounds__(256) void rix_count_kernel(long long total, long long per_batch, int m,
+                                                        const int *__restrict__ idx, int *__restrict__ cnt,
+                                                        int *__restrict__ rank)
+{
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= total) return;
+    const int bi = (int)(x / per_batch);
+    rank[x] = atomicAdd(&cnt[(size_t)bi * m + idx[x]], 1);
+}
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void rix_fill_kernel(long long total, long long per_batch, int m, int nt,
+                                                       const int *__restrict__ idx, const float *__restrict__ weight,
+                                                       const int *__restrict__ off, const int *__restrict__ rank,
+                                                       int *__restrict__ rev, float *__restrict__ revw)
+{
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= total) return;
+    const int bi = (int)(x / per_batch);
+    const int pos = off[(size_t)bi * m + idx[x]] + rank[x];
+    rev[pos] = (int)((x - (long long)bi * per_batch) / nt); // source element within its batch
+    if (WEIGHTED) revw[pos] = weight[x];
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
+    int c, int m, int L, int ch, const float *__restrict__ grad_out, size_t src_bstride,
+    const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw,
+    float *__restrict__ grad_table)
+{
+    extern __shared__ float tlds_rows[]; // [ch][L] rows of grad_out
+    const int bi = blockIdx.z, c0 = blockIdx.y * ch, nch = min(ch, c - c0);
+    const float *src = grad_out + (size_t)bi * src_bstride + (size_t)c0 * L;
+    for (int e = threadIdx.x; e < nch * L; e += TLDS_THREADS) tlds_rows[e] = src[e];
+    __syncthreads();
+    const int per = (m + gridDim.x - 1) / gridDim.x;
+    const int j0 = blockIdx.x * per, j1 = min(m, j0 + per);
+    constexpr int CHMAX = 16, RU = 8, TP = 4;
+    // TP targets per thread and pass: their list bounds (and, below, RU entries of a list) are loaded together,
+    // so a pass exposes two global latencies instead of 2 x TP
+    for (int jb = j0 + threadIdx.x; jb < j1; jb += TP * TLDS_THREADS) {
+        int a[TP], z[TP];
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            const int j = jb + p * TLDS_THREADS;
+            a[p] = j < j1 ? off[(size_t)bi * m + j] : 0;
+            z[p] = j < j1 ? off[(size_t)bi * m + j + 1] : 0;
+        }
+#pragma unroll
+        for (int p = 0; p < TP; ++p) {
+            const int j = jb + p * TLDS_THREADS;
+            float acc[CHMAX];
+#pragma unroll
+            for (int l = 0; l < CHMAX; ++l) acc[l] = 0.f;
+            for (int q = a[p]; q < z[p]; q += RU) {
+                int e[RU];
+                float w[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const bool in = q + u < z[p];
+                    e[u] = in ? rev[q + u] : 0;
+                    w[u] = in ? (WEIGHTED ? revw[q + u] : 1.f) : 0.f;
+                }
+#pragma unroll
+                for (int l = 0; l < CHMAX; ++l) {
+                    if (l < nch) {
+#pragma unroll
+                        for (int u = 0; u < RU; ++u) acc[l] = fmaf(w[u], tlds_rows[l * L + e[u]], acc[l]);
+                    }
+                }
+            }
+            if (j < j1 && z[p] > a[p]) { // untouched targets keep what they had (the buffer is accumulated into)
+#pragma unroll
+                for (int l = 0; l < CHMAX; ++l)
+                    if (l < nch) grad_table[((size_t)bi * c + c0 + l) * m + j] += acc[l];
+            }
+        }
+    }
+}
+
+// ints needed in the workspace for the reverse index of (b, L, nt) pairs onto m targets per batch
+static inline long long rix_ws_ints(int b, int m, long long L, int nt)
+{
+    const long long t = (long long)b * m, pairs = (long long)b * L * nt;
+    return (t + 1) + scan_blocks(t) + 3 * pairs + 8;
+}
+
+// returns hipErrorNotSupported when this path does not apply (caller falls back)
+template <int NT, bool WEIGHTED>
+static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride, const float *grad_out,
+                                  const int *idx, const float *weight, float *grad_table, float *workspace,
+                                  long long ws_floats, hipStream_t s)
+{
+    const char *env = getenv("GEOT_GATHER_IMPL");
+    if ((env && env[0] == 'p') || L < 1 || L > TLDS_FLOATS || (long long)L * c < (1 << 16)) return hipErrorNotSupported;
+    if (ws_floats < rix_ws_ints(b, m, L, NT) || (long long)b * L * NT > 0x7fffffffLL) return hipErrorNotSupported;
+    int ch = TLDS_FLOATS / L;
+    if (ch > 16) ch = 16;
+    if (ch > c) ch = c;
+    const long long t = (long long)b * m, pairs = (long long)b * L * NT;
+    int *off = (int *)workspace;
+    int *bsum = off + t + 1;
+    int *rank = bsum + scan_blocks(t);
+    int *rev = rank + pairs;
+    float *revw = (float *)(rev + pairs);
+    hipError_t e = hipMemsetAsync(off, 0, (size_t)(t + 1) * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    const int pb = (int)((pairs + 255) / 256);
+    hipLaunchKernelGGL(rix_count_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, idx, off, rank);
+    exclusive_scan_i32((int)t, off, bsum, nullptr, s);
+    hipLaunchKernelGGL((rix_fill_kernel<WEIGHTED>), dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, idx,
+                       weight, off, rank, rev, revw);
+    const size_t lds = (size_t)ch * L * sizeof(float);
+    e = tlds_set_lds(table_gather_csr_lds_kernel<WEIGHTED>, lds);
+    if (e != hipSuccess) return e;
+    const int chunks = (c + ch - 1) / ch;
+    long long slices = (512 + (long long)chunks * b - 1) / ((long long)chunks * b);
+    if (slices > m / 1024) slices = m / 1024;
+    if (slices < 1) slices = 1;
+    hipLaunchKernelGGL((table_gather_csr_lds_kernel<WEIGHTED>), dim3((int)slices, chunks, b), dim3(TLDS_THREADS), lds, s,
+                       c, m, L, ch, grad_out, src_bstride, off, rev, revw, grad_table);
+    return hipGetLastError();
+}
+
 static inline dim3 grid3(long long inner, int c, int b)
 {
     return dim3((unsigned)((inner + GG_THREADS - 1) / GG_THREADS), (unsigned)((c + GG_CCHUNK - 1) / GG_CCHUNK),
@@ -585,6 +715,11 @@ GEOT_EXPORT int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const
     if (b < 0 || c < 0 || n < 0 || m < 0 || !workspace) return hipErrorInvalidValue;
     if (b == 0 || c == 0 || n == 0 || m == 0) return hipSuccess;
     if (b > 65535) return hipErrorInvalidValue;
+    {
+        hipError_t e = scatter_via_csr<3, true>(b, c, m, n, (size_t)c * n, grad_out, idx, weight, grad_points, workspace,
+                                                (long long)b * m * c, (hipStream_t)stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     dim3 g1((n + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
     hipLaunchKernelGGL((scatter_rows_cl_kernel<3, true>), g1, dim3(256), 0, (hipStream_t)stream, c, n, m,
                        grad_out, (size_t)c * n, idx, weight, workspace);
@@ -602,6 +737,11 @@ GEOT_EXPORT int geot_group_points_grad_ws(int b, int c, int n, int npoints, int 
     long long npns = (long long)npoints * nsample;
     if (b == 0 || c == 0 || npns == 0 || n == 0) return hipSuccess;
     if (npns > 0x7fffffffLL || b > 65535) return hipErrorInvalidValue;
+    {
+        hipError_t e = scatter_via_csr<1, false>(b, c, n, (int)npns, (size_t)c * npns, grad_out, idx, nullptr, grad_points, workspace,
+                                                 (long long)b * n * c, (hipStream_t)stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     dim3 g1((unsigned)((npns + SC_TILE - 1) / SC_TILE), (c + SC_TILE - 1) / SC_TILE, b);
     hipLaunchKernelGGL((scatter_rows_cl_kernel<1, false>), g1, dim3(256), 0, (hipStream_t)stream, c,
                        (int)npns, n, grad_out, (size_t)c * npns, idx, nullptr, workspace);
@@ -643,6 +783,11 @@ GEOT_EXPORT int geot_graph_feature_grad(int b, int c, int nq, int nk, int k, con
     else if (al && k == 16) hipLaunchKernelGGL(graph_feature_grad_q_kernel<4>, gq, dim3(GG_THREADS), 0, s, c, nq, k, grad_out, grad_xq);
     else hipLaunchKernelGGL(graph_feature_grad_q_kernel<0>, gq, dim3(GG_THREADS), 0, s, c, nq, k, grad_out, grad_xq);
     const int L = nq * k;
+    {
+        hipError_t e = scatter_via_csr<1, false>(b, c, nk, L, (size_t)2 * c * L, grad_out, idx, nullptr, grad_xk,
+                                                 workspace, (long long)b * nk * c, s);
+        if (e != hipErrorNotSupported) return e;
+    }
     dim3 g1((L + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
     hipLaunchKernelGGL((scatter_rows_cl_kernel<1, false>), g1, dim3(256), 0, s, c, L, nk, grad_out,
                        (size_t)2 * c * L, idx, nullptr, workspace);

@@ -115,4 +115,79 @@ __device__ __forceinline__ float wave_max_f32(float v) { return -wave_min_f32(-v
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
+
+// ---- exclusive scan of int counters, in place, on a stream (used to turn per-target counts into CSR
+// offsets): data[0..total] (total + 1 entries, the last one receives the grand total); `bsum` is scratch of
+// scan_blocks(total) ints; `also_zero` (nullable) gets its first `total` entries cleared on the way.
+// exclusive scan of deg[0..total] in three small kernels (block-local scan, scan of the block sums, add)
+constexpr int SCAN_CHUNK = 4096;
+static __global__ __launch_bounds__(1024) void scan_local_kernel(int total, int *__restrict__ deg, int *__restrict__ bsum)
+{
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.x * SCAN_CHUNK + tid * 4;
+    int v[4], s = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = base + e <= total ? deg[base + e] : 0; s += v[e]; }
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int o = __shfl_up(inc, d);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int run = woff + inc - s;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { if (base + e <= total) deg[base + e] = run; run += v[e]; }
+    if (tid == 1023) bsum[blockIdx.x] = run;
+}
+static __global__ __launch_bounds__(1024) void scan_top_kernel(int nblk, int *__restrict__ bsum)
+{
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblk; base += 1024) {
+        const int v = base + tid < nblk ? bsum[base + tid] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int woff = carry;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (base + tid < nblk) bsum[base + tid] = woff + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry = woff + inc;
+        __syncthreads();
+    }
+}
+static __global__ __launch_bounds__(1024) void scan_add_kernel(int total, int *__restrict__ deg, const int *__restrict__ bsum,
+                                                           int *__restrict__ cursor)
+{
+    const int add = bsum[blockIdx.x];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (base + e <= total) deg[base + e] += add;
+        if (cursor && base + e < total) cursor[base + e] = 0;
+    }
+}
+
+static inline int scan_blocks(long long total) { return (int)((total + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK); }
+static inline void exclusive_scan_i32(int total, int *data, int *bsum, int *also_zero, hipStream_t s)
+{
+    const int nblk = scan_blocks(total);
+    hipLaunchKernelGGL(scan_local_kernel, dim3(nblk), dim3(1024), 0, s, total, data, bsum);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, nblk, bsum);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(nblk), dim3(1024), 0, s, total, data, bsum, also_zero);
+}
+
 } // namespace geot

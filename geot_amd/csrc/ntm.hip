@@ -688,68 +688,6 @@ __global__ __launch_bounds__(256) void tl_prep_kernel(int total_pts, int n, int 
     if (i < total_pts && l == 0) S[i] = s + 0.001f;
 }
 
-// exclusive scan of deg[0..total] in three small kernels (block-local scan, scan of the block sums, add)
-constexpr int TL_SCAN_CHUNK = 4096;
-__global__ __launch_bounds__(1024) void tl_scan_local_kernel(int total, int *__restrict__ deg, int *__restrict__ bsum)
-{
-    __shared__ int wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int base = blockIdx.x * TL_SCAN_CHUNK + tid * 4;
-    int v[4], s = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { v[e] = base + e <= total ? deg[base + e] : 0; s += v[e]; }
-    int inc = s;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int o = __shfl_up(inc, d);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wsum[w];
-    int run = woff + inc - s;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { if (base + e <= total) deg[base + e] = run; run += v[e]; }
-    if (tid == 1023) bsum[blockIdx.x] = run;
-}
-__global__ __launch_bounds__(1024) void tl_scan_top_kernel(int nblk, int *__restrict__ bsum)
-{
-    __shared__ int wsum[16];
-    __shared__ int carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nblk; base += 1024) {
-        const int v = base + tid < nblk ? bsum[base + tid] : 0;
-        int inc = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            int o = __shfl_up(inc, d);
-            if (lane >= d) inc += o;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int woff = carry;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        if (base + tid < nblk) bsum[base + tid] = woff + inc - v;
-        __syncthreads();
-        if (tid == 1023) carry = woff + inc;
-        __syncthreads();
-    }
-}
-__global__ __launch_bounds__(1024) void tl_scan_add_kernel(int total, int *__restrict__ deg, const int *__restrict__ bsum,
-                                                           int *__restrict__ cursor)
-{
-    const int add = bsum[blockIdx.x];
-    const int base = blockIdx.x * TL_SCAN_CHUNK + threadIdx.x * 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        if (base + e <= total) deg[base + e] += add;
-        if (base + e < total) cursor[base + e] = 0;
-    }
-}
-
 // reverse adjacency: the in-edge (s -> i) is stored with its finished coefficient w_si / S_s
 __global__ __launch_bounds__(256) void tl_fill_kernel(int total_pts, int n, int k, int seg_shift,
                                                       const int *__restrict__ nbr, const float *__restrict__ wout,
@@ -1085,7 +1023,7 @@ GEOT_EXPORT long long geot_ntm_threed_loss_ws_bytes(int b, int n, int k)
 {
     if (b < 0 || n < 0 || k < 0) return -1;
     const long long t = (long long)b * n;
-    const long long nblk = (t + 1 + TL_SCAN_CHUNK - 1) / TL_SCAN_CHUNK;
+    const long long nblk = (t + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
     // S, offsets, cursor, block sums, then per edge: wout, rev, revc
     return 4 * (t + (t + 1) + t + nblk + 3 * t * k) + 64;
 }
@@ -1106,7 +1044,7 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float s
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     hipStream_t s = (hipStream_t)stream;
     const int t = b * n;
-    const int nblk = (t + 1 + TL_SCAN_CHUNK - 1) / TL_SCAN_CHUNK;
+    const int nblk = (t + 1 + SCAN_CHUNK - 1) / SCAN_CHUNK;
     float *S = (float *)workspace;
     int *off = (int *)(S + t);
     int *cursor = off + t + 1;
@@ -1123,9 +1061,7 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float s
     const int eb = (int)((lanes + 255) / 256);
     hipLaunchKernelGGL(tl_prep_kernel, dim3(eb), dim3(256), 0, s, t, n, k, seg_shift, inv2s2, positions, labels, nbr,
                        order, S, wout, off);
-    hipLaunchKernelGGL(tl_scan_local_kernel, dim3(nblk), dim3(1024), 0, s, t, off, bsum);
-    hipLaunchKernelGGL(tl_scan_top_kernel, dim3(1), dim3(1024), 0, s, nblk, bsum);
-    hipLaunchKernelGGL(tl_scan_add_kernel, dim3(nblk), dim3(1024), 0, s, t, off, bsum, cursor);
+    exclusive_scan_i32(t, off, bsum, cursor, s);
     hipLaunchKernelGGL(tl_fill_kernel, dim3(eb), dim3(256), 0, s, t, n, k, seg_shift, nbr, wout, S, off, order, cursor,
                        rev, revc);
     const char *ge = getenv("GEOT_NTM_G");
