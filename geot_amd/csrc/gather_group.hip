@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void transpose_add_kernel(int c, int M, const 
 // out[b, C + c, i, j] = x_q[b, c, i]
 // One pass instead of the reference's transpose + fancy-index gather + permute + expand + cat chain.
 // Lanes walk i (the contiguous dimension of x_q and, with j, of out); indices are loaded once per
-// lane and reused over GG_CCHUNK channels.  KMAX neighbours are held in registers.
+// lane and reused over GG_CCHUNK channels; for k = 4, 8, 16 the neighbour ids are held in registers (int4).
 
 typedef float gf_f4 __attribute__((ext_vector_type(4)));
 
