@@ -44,6 +44,7 @@ PROTOTYPES = {
 PROTOTYPES.update({
     "geot_group_points_grad_ws": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_three_interpolate_grad_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ball_query_ws": [_c_int, _c_int, _c_int, _c_float, _c_int, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_knn_sorted_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_three_nn_ws": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_graph_feature": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
@@ -77,6 +78,7 @@ PLAIN = {
     "geot_ntm_correct_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_threed_graph_bytes": ([_c_int, _c_int, _c_int], ctypes.c_longlong),
     "geot_knn_grid_eligible": ([_c_int, _c_int, _c_int, _c_int], _c_int),
+    "geot_ball_grid_eligible": ([_c_int, _c_int, _c_int, _c_float, _c_int], _c_int),
 }
 
 _lib = None

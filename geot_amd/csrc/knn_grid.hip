@@ -66,7 +66,8 @@ struct KgGrid {
 };
 
 // header words: 0-2 min (ordered), 3-5 max (ordered); grid parameters are recomputed from them by everyone
-__device__ __forceinline__ KgGrid kg_grid(const uint32_t *hdr, int gtarget)
+// min_h > 0 (ball query): as many cells per axis as keep the cell edge >= min_h, instead of `gtarget`
+__device__ __forceinline__ KgGrid kg_grid(const uint32_t *hdr, int gtarget, float min_h = 0.f)
 {
     KgGrid g;
     float ext[3], mx = 0.f;
@@ -78,6 +79,10 @@ __device__ __forceinline__ KgGrid kg_grid(const uint32_t *hdr, int gtarget)
         mx = fmaxf(mx, ext[a]);
     }
     const bool ok = mx > 0.f && mx < INFINITY;
+    if (min_h > 0.f) {
+        const float f = ok ? mx / min_h : 1.f;
+        gtarget = f >= (float)KG_GMAX ? KG_GMAX : (f >= 1.f ? (int)f : 1);
+    }
     g.h = ok ? mx / (float)gtarget : INFINITY;
     g.inv_h = ok ? (float)gtarget / mx : 0.f;
 #pragma unroll
@@ -151,11 +156,11 @@ __device__ __forceinline__ uint32_t kg_morton15(uint32_t x, uint32_t y, uint32_t
 
 // morton = 0: x-fastest linear cell ids (what the kNN query walks); 1: Morton ids (geot_spatial_order)
 __global__ __launch_bounds__(256) void kg_count_kernel(int nr, int gtarget, int morton, const float *__restrict__ ref,
-                                                       uint32_t *ws, size_t per_cloud, size_t off_tmp)
+                                                       uint32_t *ws, size_t per_cloud, size_t off_tmp, float min_h)
 {
     const float *R = ref + (size_t)blockIdx.y * nr * 3;
     uint32_t *W = ws + (size_t)blockIdx.y * per_cloud;
-    const KgGrid g = kg_grid(W, gtarget);
+    const KgGrid g = kg_grid(W, gtarget, min_h);
     uint32_t *cnt = W + KG_HDR;
     uint32_t *tmp = W + off_tmp;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nr; i += gridDim.x * 256) {
@@ -479,6 +484,137 @@ __global__ __launch_bounds__(256) void kg_order_kernel(int nr, const uint32_t *_
         order[(size_t)blockIdx.y * nr + i] = blockIdx.y * nr + __float_as_int(rec[i].w);
 }
 
+// ---- ball query over the grid -------------------------------------------------------------------
+// Same output as ball_query_kernel (neighbors.hip; pointnet2/_ext_src/src/ball_query_gpu.cu:12-47): the
+// first nsample points, in index order, with d2 < r^2, the tail filled with the first hit (0 if none).
+// "First nsample in index order" = the nsample SMALLEST indices among all hits, so the scan over half the
+// cloud becomes: cells of edge >= 1.0001 r, the 27 around the query hold every hit; their records go into
+// register slots; if there are more than 64 hits an integer bisection on the index finds a cut with
+// nsample <= #{hits with index <= cut} <= 64; the survivors are compacted through LDS and ranked by index.
+// Blocks too dense for the register slots are scanned row by row with an insertion list keyed by index.
+__global__ __launch_bounds__(KG_WAVES * 64) void ball_grid_kernel(
+    int nq, int nr, int nsample, float radius, float min_h, const float *__restrict__ query,
+    const uint32_t *__restrict__ ws, size_t per_cloud, size_t off_rec, int *__restrict__ idx)
+{
+    __shared__ int bg_si[KG_WAVES][64];
+    const int lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bi = blockIdx.y;
+    const int j = blockIdx.x * KG_WAVES + wave;
+    if (j >= nq) return;
+    const uint32_t *W = ws + (size_t)bi * per_cloud;
+    const KgGrid g = kg_grid(W, 1, min_h);
+    const int *start = reinterpret_cast<const int *>(W + KG_HDR);
+    const float4 *rec = reinterpret_cast<const float4 *>(W + off_rec);
+    const float *Q = query + ((size_t)bi * nq + j) * 3;
+    const float qx = Q[0], qy = Q[1], qz = Q[2], r2 = radius * radius;
+    const int cx = kg_cell1(qx, g.lo[0], g.inv_h, g.dim[0]);
+    const int cy = kg_cell1(qy, g.lo[1], g.inv_h, g.dim[1]);
+    const int cz = kg_cell1(qz, g.lo[2], g.inv_h, g.dim[2]);
+    const int dx = g.dim[0], dy = g.dim[1], dz = g.dim[2];
+    int *out = idx + ((size_t)bi * nq + j) * nsample;
+
+    int rs = 0, re = 0;
+    if (lane < 9) {
+        const int y = cy + lane % 3 - 1, z = cz + lane / 3 - 1;
+        if (y >= 0 && y < dy && z >= 0 && z < dz) {
+            const int base = (z * dy + y) * dx;
+            rs = start[base + max(cx - 1, 0)];
+            re = start[base + min(cx + 1, dx - 1) + 1];
+        }
+    }
+    int slots = (re - rs + 63) >> 6;
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) slots += __shfl_xor(slots, o, 16);
+    slots = __builtin_amdgcn_readfirstlane(slots);
+
+    if (slots <= KG_SLOTS) {
+        int id[KG_SLOTS]; // index of a hit, INT_MAX otherwise
+        int row = 0, a = __builtin_amdgcn_readlane(rs, 0), e = __builtin_amdgcn_readlane(re, 0), H = 0;
+#pragma unroll
+        for (int sl = 0; sl < KG_SLOTS; ++sl) {
+            while (row < 9 && a >= e) {
+                ++row;
+                if (row < 9) { a = __builtin_amdgcn_readlane(rs, row); e = __builtin_amdgcn_readlane(re, row); }
+            }
+            id[sl] = 0x7fffffff;
+            if (row < 9) {
+                if (a + lane < e) {
+                    const float4 pr = rec[a + lane];
+                    if (sqdist3(qx, qy, qz, pr.x, pr.y, pr.z) < r2) id[sl] = __float_as_int(pr.w);
+                }
+                a += 64;
+            }
+            H += __popcll(__ballot(id[sl] != 0x7fffffff));
+        }
+        int cut = 0x7ffffffe, c = H; // keep hits with index <= cut
+        bool ok = H <= 64;
+        if (!ok) {
+            int lo_i = -1, hi_i = nr - 1; // count(lo_i) < nsample <= ... ; count(hi_i) = H > 64
+            for (int it = 0; it < 32 && !ok; ++it) {
+                cut = lo_i + ((hi_i - lo_i) >> 1);
+                c = 0;
+#pragma unroll
+                for (int sl = 0; sl < KG_SLOTS; ++sl) c += __popcll(__ballot(id[sl] <= cut));
+                if (c < nsample) lo_i = cut;
+                else if (c > 64) hi_i = cut;
+                else ok = true;
+                if (hi_i - lo_i <= 1) break;
+            }
+        }
+        if (ok) {
+            int base = 0;
+#pragma unroll
+            for (int sl = 0; sl < KG_SLOTS; ++sl) {
+                const bool sel = id[sl] <= cut;
+                const unsigned long long mk = __ballot(sel);
+                const int pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0));
+                if (sel) bg_si[wave][pos] = id[sl];
+                base += __popcll(mk);
+            }
+            const int ci = lane < c ? bg_si[wave][lane] : 0x7fffffff;
+            int rank = 0;
+            for (int jx = 0; jx < c; ++jx) rank += __builtin_amdgcn_readlane(ci, jx) < ci ? 1 : 0;
+            // smallest index of all = the reference's "first hit" used as filler
+            int first = ci;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) first = min(first, __shfl_xor(first, o));
+            if (c == 0) first = 0;
+            if (lane < c && rank < nsample) out[rank] = ci;
+            const int have = min(c, nsample);
+            for (int l = have + lane; l < nsample; l += 64) out[l] = first;
+            return;
+        }
+    }
+    // dense block (or a pathological index distribution): rows one by one, list of the nsample smallest hit
+    // indices (lane i = i-th smallest) built by insertion
+    int li = 0x7fffffff, taui = 0x7fffffff;
+    for (int row = 0; row < 9; ++row) {
+        const int a0 = __builtin_amdgcn_readlane(rs, row), e0 = __builtin_amdgcn_readlane(re, row);
+        for (int c0 = a0; c0 < e0; c0 += 64) {
+            int cand = 0x7fffffff;
+            if (c0 + lane < e0) {
+                const float4 pr = rec[c0 + lane];
+                if (sqdist3(qx, qy, qz, pr.x, pr.y, pr.z) < r2) cand = __float_as_int(pr.w);
+            }
+            unsigned long long mk = __ballot(cand < taui);
+            while (mk) {
+                const int l = __builtin_ctzll(mk);
+                mk &= mk - 1;
+                const int ic = __builtin_amdgcn_readlane(cand, l);
+                if (!(ic < taui)) continue;
+                const int pos = __popcll(__ballot(li < ic));
+                const int sh = kg_shr1(li);
+                li = lane > pos ? sh : (lane == pos ? ic : li);
+                taui = __builtin_amdgcn_readlane(li, nsample - 1);
+            }
+        }
+    }
+    const int cnt = __popcll(__ballot(li != 0x7fffffff && lane < nsample));
+    const int first = cnt ? __builtin_amdgcn_readlane(li, 0) : 0;
+    if (lane < nsample) out[lane] = lane < cnt ? li : first;
+}
+
 static int kg_target(int nr, int k)
 {
     double g = std::sqrt(3.0 * (double)nr / (5.0 * (double)(k < 1 ? 1 : k)));
@@ -526,7 +662,7 @@ GEOT_EXPORT int geot_knn_sorted_ws(int b, int nq, int nr, int k, const float *qu
     const int pb = (nr + 255) / 256 < 96 ? (nr + 255) / 256 : 96;
     hipLaunchKernelGGL(kg_init_kernel, dim3((KG_CELLS + 1 + 255) / 256, b), dim3(256), 0, s, ws, L.per_cloud_words);
     hipLaunchKernelGGL(kg_bbox_kernel, dim3(pb, b), dim3(256), 0, s, nr, ref, ws, L.per_cloud_words);
-    hipLaunchKernelGGL(kg_count_kernel, dim3(pb, b), dim3(256), 0, s, nr, G, 0, ref, ws, L.per_cloud_words, L.off_tmp);
+    hipLaunchKernelGGL(kg_count_kernel, dim3(pb, b), dim3(256), 0, s, nr, G, 0, ref, ws, L.per_cloud_words, L.off_tmp, 0.f);
     hipLaunchKernelGGL(kg_scan_kernel, dim3(b), dim3(1024), 0, s, ws, L.per_cloud_words);
     hipLaunchKernelGGL(kg_scatter_kernel, dim3(pb, b), dim3(256), 0, s, nr, ref, ws, L.per_cloud_words, L.off_tmp,
                        L.off_rec);
@@ -562,10 +698,46 @@ GEOT_EXPORT int geot_spatial_order(int b, int n, const float *xyz, int *order, v
     hipLaunchKernelGGL(kg_init_kernel, dim3((KG_CELLS + 1 + 255) / 256, b), dim3(256), 0, s, ws, L.per_cloud_words);
     hipLaunchKernelGGL(kg_bbox_kernel, dim3(pb, b), dim3(256), 0, s, n, xyz, ws, L.per_cloud_words);
     hipLaunchKernelGGL(kg_count_kernel, dim3(pb, b), dim3(256), 0, s, n, KG_GMAX, 1, xyz, ws, L.per_cloud_words,
-                       L.off_tmp);
+                       L.off_tmp, 0.f);
     hipLaunchKernelGGL(kg_scan_kernel, dim3(b), dim3(1024), 0, s, ws, L.per_cloud_words);
     hipLaunchKernelGGL(kg_scatter_kernel, dim3(pb, b), dim3(256), 0, s, n, xyz, ws, L.per_cloud_words, L.off_tmp,
                        L.off_rec);
     hipLaunchKernelGGL(kg_order_kernel, dim3(pb, b), dim3(256), 0, s, n, ws, L.per_cloud_words, L.off_rec, order);
+    return hipGetLastError();
+}
+
+// 1 if geot_ball_query_ws would take the grid path
+GEOT_EXPORT int geot_ball_grid_eligible(int b, int n, int m, float radius, int nsample)
+{
+    const char *e = getenv("GEOT_NN_IMPL");
+    if (e && (e[0] == 'b' || e[0] == 'w')) return 0;
+    if (!(radius > 0.f) || nsample < 1 || nsample > 64 || n < 2048 || b < 1 || m < 1) return 0;
+    if (e && e[0] == 'g') return 1;
+    return (long long)b * m * n >= (1ll << 26) ? 1 : 0;
+}
+
+// geot_ball_query through the grid (identical output); workspace: geot_knn_grid_ws_bytes(b, n) bytes.
+GEOT_EXPORT int geot_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                                   const float *xyz, int *idx, void *workspace, long long ws_bytes, void *stream)
+{
+    if (b < 0 || n < 0 || m < 0 || nsample < 0) return hipErrorInvalidValue;
+    if (b == 0 || m == 0 || nsample == 0) return hipSuccess;
+    if (!workspace || !geot_ball_grid_eligible(b, n, m, radius, nsample) || ws_bytes < geot_knn_grid_ws_bytes(b, n) ||
+        b > 65535 || ((uintptr_t)workspace & 15) != 0)
+        return geot_ball_query(b, n, m, radius, nsample, new_xyz, xyz, idx, stream);
+    hipStream_t s = (hipStream_t)stream;
+    const KgLayout L = kg_layout(n);
+    uint32_t *ws = (uint32_t *)workspace;
+    const float min_h = radius * 1.0001f;
+    const int pb = (n + 255) / 256 < 96 ? (n + 255) / 256 : 96;
+    hipLaunchKernelGGL(kg_init_kernel, dim3((KG_CELLS + 1 + 255) / 256, b), dim3(256), 0, s, ws, L.per_cloud_words);
+    hipLaunchKernelGGL(kg_bbox_kernel, dim3(pb, b), dim3(256), 0, s, n, xyz, ws, L.per_cloud_words);
+    hipLaunchKernelGGL(kg_count_kernel, dim3(pb, b), dim3(256), 0, s, n, 1, 0, xyz, ws, L.per_cloud_words, L.off_tmp,
+                       min_h);
+    hipLaunchKernelGGL(kg_scan_kernel, dim3(b), dim3(1024), 0, s, ws, L.per_cloud_words);
+    hipLaunchKernelGGL(kg_scatter_kernel, dim3(pb, b), dim3(256), 0, s, n, xyz, ws, L.per_cloud_words, L.off_tmp,
+                       L.off_rec);
+    hipLaunchKernelGGL(ball_grid_kernel, dim3((m + KG_WAVES - 1) / KG_WAVES, b), dim3(KG_WAVES * 64), 0, s, m, n, nsample,
+                       radius, min_h, new_xyz, ws, L.per_cloud_words, L.off_rec, idx);
     return hipGetLastError();
 }

@@ -71,3 +71,13 @@ def knn_workspace(dev, b, nq, nr, k):
     nbytes = int(lib.geot_knn_grid_ws_bytes(int(b), int(nr)))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     return ws.data_ptr(), nbytes, ws
+
+
+def ball_workspace(dev, b, n, m, radius, nsample):
+    """(ptr, bytes, keep-alive tensor) of scratch for the grid ball query, or (None, 0, None)."""
+    lib = _lib.load()
+    if not lib.geot_ball_grid_eligible(int(b), int(n), int(m), float(radius), int(nsample)):
+        return None, 0, None
+    nbytes = int(lib.geot_knn_grid_ws_bytes(int(b), int(n)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return ws.data_ptr(), nbytes, ws

@@ -9,7 +9,7 @@ tensors and raises RuntimeError.  Outputs may be uninitialised
 """
 import torch
 
-from ._common import f32, i32, same_device, need, call, ptr, knn_workspace
+from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace
 
 
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
@@ -43,7 +43,8 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
     dev = same_device(new_xyz, xyz, idx)
     need(new_xyz.numel() == b * m * 3 and xyz.numel() == b * n * 3 and idx.numel() == b * m * nsample,
          "ball_query size mismatch")
-    call("geot_ball_query", dev, b, n, m, float(radius), int(nsample), ptr(new_xyz), ptr(xyz), ptr(idx))
+    wp, wb, _keep = ball_workspace(dev, b, n, m, radius, nsample)
+    call("geot_ball_query_ws", dev, b, n, m, float(radius), int(nsample), ptr(new_xyz), ptr(xyz), ptr(idx), wp, wb)
     return 1
 
 

@@ -8,7 +8,7 @@ ball_query.cpp:22-24; group_points.cpp:25-27,50-52; interpolate.cpp:26-31,58-60,
 """
 import torch
 
-from ._common import f32, i32, same_device, need, call, ptr, knn_workspace
+from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace
 
 
 def gather_points(points, idx):
@@ -90,7 +90,8 @@ def ball_query(new_xyz, xyz, radius, nsample):
     need(xyz.shape[0] == b and xyz.shape[2] == 3 and new_xyz.shape[2] == 3, "ball_query shape mismatch")
     n = xyz.shape[1]
     idx = torch.zeros((b, m, int(nsample)), dtype=torch.int32, device=dev)
-    call("geot_ball_query", dev, b, n, m, float(radius), int(nsample), ptr(new_xyz), ptr(xyz), ptr(idx))
+    wp, wb, _keep = ball_workspace(dev, b, n, m, radius, nsample)
+    call("geot_ball_query_ws", dev, b, n, m, float(radius), int(nsample), ptr(new_xyz), ptr(xyz), ptr(idx), wp, wb)
     return idx
 
 

@@ -99,6 +99,10 @@ int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad
  * when workspace is NULL / too small or geot_knn_grid_eligible(b, nq, nr, k) is 0 (small problems, k > 64,
  * or GEOT_NN_IMPL=basic|wave in the environment; GEOT_NN_IMPL=grid forces the grid where it is valid). */
 long long geot_knn_grid_ws_bytes(int b, int nr);
+/* geot_ball_query through the same grid (cells of edge >= 1.0001 radius; identical output). */
+int geot_ball_grid_eligible(int b, int n, int m, float radius, int nsample);
+int geot_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz, const float *xyz,
+                       int *idx, void *workspace, long long ws_bytes, void *stream);
 int geot_knn_grid_eligible(int b, int nq, int nr, int k);
 int geot_knn_sorted_ws(int b, int nq, int nr, int k, const float *query, const float *ref, int *idx,
                        float *dist2, void *workspace, long long ws_bytes, void *stream);

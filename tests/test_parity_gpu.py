@@ -534,3 +534,23 @@ def test_knn_grid_full_size_vs_oracle_and_three_nn(ext, oracle):
     finally:
         del os.environ["GEOT_NN_IMPL"]
     assert torch.equal(ig, ib) and torch.equal(torch.nan_to_num(dg, nan=-1.0), torch.nan_to_num(db, nan=-1.0))
+
+
+@pytest.mark.parametrize("radius,ns", [(0.1, 32), (0.05, 16), (0.3, 64), (0.02, 8), (2.5, 32)])
+def test_ball_query_grid_matches_bruteforce_bit_for_bit(ext, oracle, radius, ns, monkeypatch):
+    """Grid ball query == linear-scan kernel on adversarial reference sets (sparse, dense blocks that overflow
+    the register slots, lattices, duplicates, an outlier, queries outside the box); one case vs the oracle."""
+    rng = np.random.default_rng(int(radius * 1000) + ns)
+    n = 6000
+    clouds = _adversarial_clouds(rng, n)
+    names = list(clouds)
+    ref = np.stack([clouds[c] for c in names])
+    q_out = (rng.standard_normal((len(names), 150, 3)) * 3).astype(np.float32)
+    qry = np.ascontiguousarray(np.concatenate([ref[:, :1200], q_out, ref[:, -200:] + np.float32(1e-3)], 1))
+    monkeypatch.setenv("GEOT_NN_IMPL", "grid")
+    got = ext.p2.ball_query(dev(qry), dev(ref), radius, ns)
+    monkeypatch.setenv("GEOT_NN_IMPL", "wave")
+    want = ext.p2.ball_query(dev(qry), dev(ref), radius, ns)
+    for c, name in enumerate(names):
+        assert torch.equal(got[c], want[c]), name
+    assert np.array_equal(host(got[:2, :300]), oracle.ball_query(qry[:2, :300], ref[:2], radius, ns))
