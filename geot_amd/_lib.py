@@ -73,6 +73,7 @@ PROTOTYPES.update({
 PLAIN = {
     "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),
     "geot_knn_grid_ws_bytes": ([_c_int, _c_int], ctypes.c_longlong),
+    "geot_grad_ws_needs_zero": ([_c_int, _c_int, _c_int, ctypes.c_longlong, _c_int], _c_int),
     "geot_ntm_sig_t_mean_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_threed_loss_ws_bytes": ([_c_int, _c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_correct_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),

@@ -572,15 +572,20 @@ static inline long long rix_ws_ints(int b, int m, long long L, int nt)
     return (t + 1) + scan_blocks(t) + 3 * pairs + 8;
 }
 
+static bool csr_applies(int b, int c, int m, long long L, int nt, long long ws_floats)
+{
+    const char *env = getenv("GEOT_GATHER_IMPL");
+    if ((env && env[0] == 'p') || L < 1 || L > TLDS_FLOATS || L * c < (1 << 16)) return false;
+    return ws_floats >= rix_ws_ints(b, m, L, nt) && (long long)b * L * nt <= 0x7fffffffLL;
+}
+
 // returns hipErrorNotSupported when this path does not apply (caller falls back)
 template <int NT, bool WEIGHTED>
 static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride, const float *grad_out,
                                   const int *idx, const float *weight, float *grad_table, float *workspace,
                                   long long ws_floats, hipStream_t s)
 {
-    const char *env = getenv("GEOT_GATHER_IMPL");
-    if ((env && env[0] == 'p') || L < 1 || L > TLDS_FLOATS || (long long)L * c < (1 << 16)) return hipErrorNotSupported;
-    if (ws_floats < rix_ws_ints(b, m, L, NT) || (long long)b * L * NT > 0x7fffffffLL) return hipErrorNotSupported;
+    if (!csr_applies(b, c, m, L, NT, ws_floats)) return hipErrorNotSupported;
     int ch = TLDS_FLOATS / L;
     if (ch > 16) ch = 16;
     if (ch > c) ch = c;
@@ -705,6 +710,14 @@ GEOT_EXPORT int geot_three_interpolate_grad(int b, int c, int n, int m, const fl
     hipLaunchKernelGGL(three_interpolate_grad_kernel, grid3(n, c, b), dim3(GG_THREADS), 0,
                        (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
     return hipGetLastError();
+}
+
+// 1 if a *_grad_ws call with these sizes (targets m per batch, L source elements with nt slots each, c
+// channels, workspace of b*m*c floats) accumulates in the workspace and needs it zero-filled; 0 if it
+// only uses it as scratch (reverse-index path) and any contents will do.
+GEOT_EXPORT int geot_grad_ws_needs_zero(int b, int c, int m, long long L, int nt)
+{
+    return csr_applies(b, c, m, L, nt, (long long)b * m * c) ? 0 : 1;
 }
 
 GEOT_EXPORT int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out,

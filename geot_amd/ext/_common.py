@@ -81,3 +81,11 @@ def ball_workspace(dev, b, n, m, radius, nsample):
     nbytes = int(lib.geot_knn_grid_ws_bytes(int(b), int(n)))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     return ws.data_ptr(), nbytes, ws
+
+
+def grad_workspace(dev, b, c, m, n_sources, slots):
+    """(B, m, C) float scratch for the *_grad_ws entry points: zero-filled only when the kernel accumulates
+    in it (channels-last scatter); the reverse-index path just needs the room."""
+    need_zero = _lib.load().geot_grad_ws_needs_zero(int(b), int(c), int(m), int(n_sources), int(slots))
+    alloc = torch.zeros if need_zero else torch.empty
+    return alloc((int(b), int(m), int(c)), dtype=torch.float32, device=dev)

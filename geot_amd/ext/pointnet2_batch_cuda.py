@@ -9,7 +9,7 @@ tensors and raises RuntimeError.  Outputs may be uninitialised
 """
 import torch
 
-from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace
+from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace
 
 
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
@@ -65,7 +65,7 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     if c < 16:
         call("geot_group_points_grad", dev, b, c, n, npoints, nsample, ptr(grad_out), ptr(idx), ptr(grad_points))
         return 1
-    ws = torch.zeros((b, n, c), dtype=torch.float32, device=dev)       # channels-last accumulator
+    ws = grad_workspace(dev, b, c, n, npoints * nsample, 1)
     call("geot_group_points_grad_ws", dev, b, c, n, npoints, nsample, ptr(grad_out), ptr(idx), ptr(grad_points),
          ptr(ws))
     return 1
@@ -96,6 +96,6 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     if c < 16:
         call("geot_three_interpolate_grad", dev, b, c, n, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(grad_points))
         return
-    ws = torch.zeros((b, m, c), dtype=torch.float32, device=dev)       # channels-last accumulator
+    ws = grad_workspace(dev, b, c, m, n, 3)
     call("geot_three_interpolate_grad_ws", dev, b, c, n, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(grad_points),
          ptr(ws))

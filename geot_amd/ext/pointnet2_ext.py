@@ -8,7 +8,7 @@ ball_query.cpp:22-24; group_points.cpp:25-27,50-52; interpolate.cpp:26-31,58-60,
 """
 import torch
 
-from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace
+from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace
 
 
 def gather_points(points, idx):
@@ -77,7 +77,7 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     if c < 16:   # too few channels to fill a wave's 256-B atomic row: direct scatter
         call("geot_three_interpolate_grad", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out))
         return out
-    ws = torch.zeros((b, int(m), c), dtype=torch.float32, device=dev)   # channels-last accumulator
+    ws = grad_workspace(dev, b, c, int(m), n, 3)
     call("geot_three_interpolate_grad_ws", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out),
          ptr(ws))
     return out
@@ -115,7 +115,7 @@ def group_points_grad(grad_out, idx, n):
     if c < 16:
         call("geot_group_points_grad", dev, b, c, int(n), npoints, nsample, ptr(grad_out), ptr(idx), ptr(out))
         return out
-    ws = torch.zeros((b, int(n), c), dtype=torch.float32, device=dev)   # channels-last accumulator
+    ws = grad_workspace(dev, b, c, int(n), grad_out.shape[2] * grad_out.shape[3], 1)
     call("geot_group_points_grad_ws", dev, b, c, int(n), npoints, nsample, ptr(grad_out), ptr(idx), ptr(out),
          ptr(ws))
     return out

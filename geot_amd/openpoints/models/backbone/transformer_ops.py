@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from ....pointnet2 import pointnet2_utils as pt_utils
 from ....knn_cuda import KNN
-from ....ext._common import f32, i32, same_device, need, call, ptr
+from ....ext._common import f32, i32, same_device, need, call, ptr, grad_workspace
 
 
 def fps(data, number):
@@ -66,7 +66,7 @@ class _GraphFeatureFn(torch.autograd.Function):
         g = grad_out.contiguous()
         gq = torch.zeros((b, c, nq), dtype=torch.float32, device=g.device)
         gk = torch.zeros((b, c, nk), dtype=torch.float32, device=g.device)
-        ws = torch.zeros((b, nk, c), dtype=torch.float32, device=g.device)
+        ws = grad_workspace(g.device, b, c, nk, nq * k, 1)
         call("geot_graph_feature_grad", g.device, b, c, nq, nk, k, ptr(g), ptr(idx), ptr(gq), ptr(gk), ptr(ws))
         return gq, gk, None
 

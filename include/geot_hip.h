@@ -88,6 +88,9 @@ int geot_group_points_grad(int b, int c, int n, int npoints, int nsample, const 
  * (interpolate) floats, ZERO-FILLED by the caller. */
 int geot_group_points_grad_ws(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                               const int *idx, float *grad_points, float *workspace, void *stream);
+/* 0 when the *_grad_ws entry points only use their workspace as scratch for these sizes (gradient as a
+ * gather over a reverse index), 1 when they accumulate in it and it must arrive zero-filled. */
+int geot_grad_ws_needs_zero(int b, int c, int m_targets, long long n_sources, int slots_per_source);
 int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                    const float *weight, float *grad_points, float *workspace,
                                    void *stream);
