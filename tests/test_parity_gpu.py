@@ -554,3 +554,18 @@ def test_ball_query_grid_matches_bruteforce_bit_for_bit(ext, oracle, radius, ns,
     for c, name in enumerate(names):
         assert torch.equal(got[c], want[c]), name
     assert np.array_equal(host(got[:2, :300]), oracle.ball_query(qry[:2, :300], ref[:2], radius, ns))
+
+
+def test_fps_multi_commit_soak_against_unpruned_kernel(ext, monkeypatch):
+    """64 different clouds (sizes across all four launch geometries, with duplicates): the multi-commit pruned
+    kernel must agree with the unpruned one on every index and on the final min-distance buffer."""
+    rng = np.random.default_rng(2024)
+    for n, m, cnt in ((3000, 700, 16), (7000, 1500, 16), (14000, 2500, 16), (24000, 3000, 16)):
+        xyz = np.stack([make_cloud(n, 500 + n + i, dup_frac=0.02 * (i % 3))[0] for i in range(cnt)])
+        if n == 14000:
+            xyz[:, :, 2] *= 0.01                                  # nearly flat clouds
+        monkeypatch.setenv("GEOT_FPS_IMPL", "multi")
+        a, ta = fps_k1p(ext, xyz, m, return_temp=True)
+        monkeypatch.setenv("GEOT_FPS_IMPL", "basic")
+        b_, tb = fps_k1p(ext, xyz, m, return_temp=True)
+        assert np.array_equal(a, b_) and np.array_equal(ta, tb), (n, m)
