@@ -806,7 +806,12 @@ __global__ __launch_bounds__(256) void tl_grad_gather_shared_kernel(
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int e = lane + 64 * r;
-                if (e < CC) grad_T[(size_t)pi[g] * CC + e] += acc[g][r];
+                if (e < CC) {
+                    // FIXED (graph from the forward): every row is produced exactly once -> plain store, the
+                    // buffer need not be zeroed; CSR entry point: accumulate into the caller's buffer (its contract)
+                    if (FIXED) grad_T[(size_t)pi[g] * CC + e] = acc[g][r];
+                    else grad_T[(size_t)pi[g] * CC + e] += acc[g][r];
+                }
             }
         }
     }

@@ -208,9 +208,9 @@ class _ThreeDLossFn(Function):
         positions, labels, ins_T, nbr, order, graph = ctx.saved_tensors
         b, n, _ = positions.shape
         c, k = ins_T.shape[1], nbr.shape[2]
-        g = torch.zeros_like(ins_T)
+        g = torch.empty_like(ins_T) if graph is not None else torch.zeros_like(ins_T)
         scale = float(grad_out.item()) / (b * n) if grad_out.numel() == 1 else 1.0 / (b * n)
-        if graph is not None:
+        if graph is not None:   # writes g in full
             call("geot_ntm_threed_loss_grad_graph", positions.device, b, n, c, k, scale, ptr(ins_T), ptr(nbr),
                  ptr(order), ptr(graph), graph.numel(), ptr(g))
         elif ctx.mode == "atomic":   # the scatter form

@@ -250,7 +250,8 @@ int geot_ntm_threed_loss_ord(int b, int n, int c, int k, float sigma, const floa
                              float *per_point, void *stream);
 /* Forward that leaves the graph (reverse adjacency with fixed 64-slot lists + overflow list, edge weights,
  * normalisers) in `graph` (geot_ntm_threed_graph_bytes(b, n, k) bytes), and the backward that consumes it:
- * the backward is then the gather alone.  Same results as the entry points above. */
+ * the backward is then the gather alone.  Same results as the entry points above, except that
+ * _grad_graph WRITES grad_ins_T in full (it need not be zero-filled). */
 long long geot_ntm_threed_graph_bytes(int b, int n, int k);
 int geot_ntm_threed_loss_fwd_graph(int b, int n, int c, int k, float sigma, const float *positions,
                                    const int *labels, const float *ins_T, const int *nbr, const int *order,
