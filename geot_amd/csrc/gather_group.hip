@@ -388,6 +388,37 @@ __global__ __launch_bounds__(GG_THREADS) void graph_feature_grad_q_kernel(
 constexpr int TLDS_THREADS = 1024;
 constexpr int TLDS_FLOATS = 36 * 1024; // LDS budget for the table rows (144 KB of the CU's 160 KB)
 
+// global -> LDS copy of `count` contiguous floats by the whole workgroup: 16-byte vectors when the source is
+// aligned, four independent loads in flight per thread before the first LDS store (a plain loop makes every
+// iteration wait for its own load: 24 serialised latencies for a 96 KB row)
+__device__ __forceinline__ void tlds_load_rows(float *__restrict__ dst, const float *__restrict__ src, int count)
+{
+    const int tid = threadIdx.x;
+    if ((((uintptr_t)src) & 15) == 0) {
+        const int vec = count >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(src);
+        float4 *d4 = reinterpret_cast<float4 *>(dst);
+        for (int e = tid; e < vec; e += 4 * TLDS_THREADS) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = e + u * TLDS_THREADS < vec ? s4[e + u * TLDS_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u * TLDS_THREADS < vec) d4[e + u * TLDS_THREADS] = v[u];
+        }
+        for (int e = (vec << 2) + tid; e < count; e += TLDS_THREADS) dst[e] = src[e];
+    } else {
+        for (int e = tid; e < count; e += 4 * TLDS_THREADS) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = e + u * TLDS_THREADS < count ? src[e + u * TLDS_THREADS] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u * TLDS_THREADS < count) dst[e + u * TLDS_THREADS] = v[u];
+        }
+    }
+}
+
 template <int NT, bool WEIGHTED>
 __global__ __launch_bounds__(TLDS_THREADS) void table_gather_lds_kernel(
     int c, int m, int L, int ch, const float *__restrict__ table, const int *__restrict__ idx,
@@ -396,7 +427,7 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_lds_kernel(
     extern __shared__ float tlds_rows[]; // [ch][m]
     const int bi = blockIdx.z, c0 = blockIdx.y * ch, nch = min(ch, c - c0);
     const float *src = table + ((size_t)bi * c + c0) * m; // nch rows, contiguous
-    for (int e = threadIdx.x; e < nch * m; e += TLDS_THREADS) tlds_rows[e] = src[e];
+    tlds_load_rows(tlds_rows, src, nch * m);
     __syncthreads();
     const int per = (L + gridDim.x - 1) / gridDim.x;
     const int e0 = blockIdx.x * per, e1 = min(L, e0 + per);
@@ -509,57 +540,65 @@ __global__ __launch_bounds__(256) void rix_fill_kernel(long long total, long lon
     if (WEIGHTED) revw[pos] = weight[x];
 }
 
-template <bool WEIGHTED>
+template <bool WEIGHTED, int CH>
 __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
-    int c, int m, int L, int ch, const float *__restrict__ grad_out, size_t src_bstride,
+    int c, int m, int L, const float *__restrict__ grad_out, size_t src_bstride,
     const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw,
     float *__restrict__ grad_table)
 {
-    extern __shared__ float tlds_rows[]; // [ch][L] rows of grad_out
-    const int bi = blockIdx.z, c0 = blockIdx.y * ch, nch = min(ch, c - c0);
+    extern __shared__ float tlds_rows[]; // [CH][L] rows of grad_out
+    const int bi = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, c - c0);
     const float *src = grad_out + (size_t)bi * src_bstride + (size_t)c0 * L;
-    for (int e = threadIdx.x; e < nch * L; e += TLDS_THREADS) tlds_rows[e] = src[e];
+    tlds_load_rows(tlds_rows, src, nch * L);
     __syncthreads();
     const int per = (m + gridDim.x - 1) / gridDim.x;
     const int j0 = blockIdx.x * per, j1 = min(m, j0 + per);
-    constexpr int CHMAX = 16, RU = 8, TP = 4;
-    // TP targets per thread and pass: their list bounds (and, below, RU entries of a list) are loaded together,
-    // so a pass exposes two global latencies instead of 2 x TP
+    // TP targets per thread, their lists walked in lock step RU entries at a time: TP x RU x 2 independent
+    // loads in flight per thread (one workgroup per CU, so the memory-level parallelism must come from here)
+    constexpr int RU = 4, TP = 4;
     for (int jb = j0 + threadIdx.x; jb < j1; jb += TP * TLDS_THREADS) {
         int a[TP], z[TP];
+        float acc[TP][CH];
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
             const int j = jb + p * TLDS_THREADS;
             a[p] = j < j1 ? off[(size_t)bi * m + j] : 0;
             z[p] = j < j1 ? off[(size_t)bi * m + j + 1] : 0;
+#pragma unroll
+            for (int l = 0; l < CH; ++l) acc[p][l] = 0.f;
+        }
+        int longest = 0;
+#pragma unroll
+        for (int p = 0; p < TP; ++p) longest = max(longest, z[p] - a[p]);
+        for (int it = 0; it < longest; it += RU) {
+            int e[TP][RU];
+            float w[TP][RU];
+#pragma unroll
+            for (int p = 0; p < TP; ++p)
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int q = a[p] + it + u;
+                    const bool in = q < z[p];
+                    e[p][u] = in ? rev[q] : 0;
+                    w[p][u] = in ? (WEIGHTED ? revw[q] : 1.f) : 0.f;
+                }
+#pragma unroll
+            for (int p = 0; p < TP; ++p)
+#pragma unroll
+                for (int l = 0; l < CH; ++l) {
+                    if (l < nch) {
+#pragma unroll
+                        for (int u = 0; u < RU; ++u) acc[p][l] = fmaf(w[p][u], tlds_rows[l * L + e[p][u]], acc[p][l]);
+                    }
+                }
         }
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
             const int j = jb + p * TLDS_THREADS;
-            float acc[CHMAX];
-#pragma unroll
-            for (int l = 0; l < CHMAX; ++l) acc[l] = 0.f;
-            for (int q = a[p]; q < z[p]; q += RU) {
-                int e[RU];
-                float w[RU];
-#pragma unroll
-                for (int u = 0; u < RU; ++u) {
-                    const bool in = q + u < z[p];
-                    e[u] = in ? rev[q + u] : 0;
-                    w[u] = in ? (WEIGHTED ? revw[q + u] : 1.f) : 0.f;
-                }
-#pragma unroll
-                for (int l = 0; l < CHMAX; ++l) {
-                    if (l < nch) {
-#pragma unroll
-                        for (int u = 0; u < RU; ++u) acc[l] = fmaf(w[u], tlds_rows[l * L + e[u]], acc[l]);
-                    }
-                }
-            }
             if (j < j1 && z[p] > a[p]) { // untouched targets keep what they had (the buffer is accumulated into)
 #pragma unroll
-                for (int l = 0; l < CHMAX; ++l)
-                    if (l < nch) grad_table[((size_t)bi * c + c0 + l) * m + j] += acc[l];
+                for (int l = 0; l < CH; ++l)
+                    if (l < nch) grad_table[((size_t)bi * c + c0 + l) * m + j] += acc[p][l];
             }
         }
     }
@@ -587,8 +626,8 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
 {
     if (!csr_applies(b, c, m, L, NT, ws_floats)) return hipErrorNotSupported;
     int ch = TLDS_FLOATS / L;
-    if (ch > 16) ch = 16;
-    if (ch > c) ch = c;
+    ch = ch >= 8 ? 8 : (ch >= 4 ? 4 : (ch >= 2 ? 2 : 1)); // template instantiations
+    while (ch > 1 && ch > c) ch >>= 1;
     const long long t = (long long)b * m, pairs = (long long)b * L * NT;
     int *off = (int *)workspace;
     int *bsum = off + t + 1;
@@ -603,14 +642,20 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     hipLaunchKernelGGL((rix_fill_kernel<WEIGHTED>), dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, idx,
                        weight, off, rank, rev, revw);
     const size_t lds = (size_t)ch * L * sizeof(float);
-    e = tlds_set_lds(table_gather_csr_lds_kernel<WEIGHTED>, lds);
-    if (e != hipSuccess) return e;
     const int chunks = (c + ch - 1) / ch;
     long long slices = (512 + (long long)chunks * b - 1) / ((long long)chunks * b);
     if (slices > m / 1024) slices = m / 1024;
     if (slices < 1) slices = 1;
-    hipLaunchKernelGGL((table_gather_csr_lds_kernel<WEIGHTED>), dim3((int)slices, chunks, b), dim3(TLDS_THREADS), lds, s,
-                       c, m, L, ch, grad_out, src_bstride, off, rev, revw, grad_table);
+    const dim3 grid((int)slices, chunks, b);
+#define GEOT_CSR_LAUNCH(CHV)                                                                                     \
+    {                                                                                                            \
+        e = tlds_set_lds(table_gather_csr_lds_kernel<WEIGHTED, CHV>, lds);                                       \
+        if (e != hipSuccess) return e;                                                                           \
+        hipLaunchKernelGGL((table_gather_csr_lds_kernel<WEIGHTED, CHV>), grid, dim3(TLDS_THREADS), lds, s, c, m, L, \
+                           grad_out, src_bstride, off, rev, revw, grad_table);                                   \
+    }
+    if (ch == 8) GEOT_CSR_LAUNCH(8) else if (ch == 4) GEOT_CSR_LAUNCH(4) else if (ch == 2) GEOT_CSR_LAUNCH(2) else GEOT_CSR_LAUNCH(1)
+#undef GEOT_CSR_LAUNCH
     return hipGetLastError();
 }
 
