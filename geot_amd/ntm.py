@@ -113,9 +113,14 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999):
     the last axis, i.e. divides column j by row-sum j)."""
     B, C, N = eta.shape
     eta = eta.detach()
-    flat = eta.permute(1, 0, 2).reshape(C, B * N)
-    best = torch.argmax(flat, dim=1)                                      # first maximum per class
-    class_T = eta.permute(0, 2, 1).reshape(B * N, C)[best]                # (C, C): row cc = eta[b*, :, n*]
+    # first maximum of class cc over the flattened (b, n) order, without materialising the two (C, B*N) /
+    # (B*N, C) transposes the reference builds: arg-max over n per (b, cc), then the first b that attains it
+    n_best = torch.argmax(eta, dim=2)                                     # (B, C), first maximum along n
+    v_best = torch.gather(eta, 2, n_best.unsqueeze(2)).squeeze(2)         # (B, C)
+    b_star = torch.argmax(v_best, dim=0)                                  # (C,), first b with the maximum
+    n_star = torch.gather(n_best, 0, b_star.unsqueeze(0)).squeeze(0)      # (C,)
+    cols = torch.arange(C, device=eta.device)
+    class_T = eta[b_star.unsqueeze(1), cols.unsqueeze(0), n_star.unsqueeze(1)]   # (C, C): row cc = eta[b*, :, n*]
     proj = torch.tensor(LABEL_PROJ[:C], dtype=eta.dtype, device=eta.device)
     prior_T = gaussian(proj.unsqueeze(0), proj.unsqueeze(1), sigma.unsqueeze(1))   # [cc][k]
     row0 = torch.zeros(C, dtype=eta.dtype, device=eta.device)
