@@ -95,3 +95,36 @@ def test_reference_wrapper_files_import_against_our_modules(built):
             "print('DROPIN_OK')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert "DROPIN_OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_host_only_planning_entry_points(monkeypatch):
+    """Entry points that only plan (sizes, path selection) run without a GPU: sanity of their contracts."""
+    from geot_amd import _lib
+    lib = _lib.load()
+    monkeypatch.delenv("GEOT_NN_IMPL", raising=False)
+    # grid kNN: big or long-list problems qualify, small ones and k > 64 do not; env overrides both ways
+    assert lib.geot_knn_grid_eligible(1, 24000, 24000, 33) == 1
+    assert lib.geot_knn_grid_eligible(8, 8192, 8192, 4) == 1
+    assert lib.geot_knn_grid_eligible(1, 512, 24000, 32) == 1
+    assert lib.geot_knn_grid_eligible(1, 1000, 1000, 8) == 0
+    assert lib.geot_knn_grid_eligible(1, 24000, 24000, 65) == 0
+    monkeypatch.setenv("GEOT_NN_IMPL", "wave")
+    assert lib.geot_knn_grid_eligible(1, 24000, 24000, 33) == 0
+    monkeypatch.setenv("GEOT_NN_IMPL", "grid")
+    assert lib.geot_knn_grid_eligible(1, 3000, 3000, 8) == 1
+    monkeypatch.delenv("GEOT_NN_IMPL")
+    assert lib.geot_ball_grid_eligible(1, 24000, 6000, 0.1, 32) == 1
+    assert lib.geot_ball_grid_eligible(1, 24000, 6000, 0.1, 65) == 0
+    assert lib.geot_ball_grid_eligible(1, 24000, 6000, -1.0, 32) == 0
+    # workspace sizes: monotone, 16-byte multiples, linear in the batch
+    w1, w8 = lib.geot_knn_grid_ws_bytes(1, 24000), lib.geot_knn_grid_ws_bytes(8, 24000)
+    assert w1 > 24000 * 24 and w1 % 16 == 0 and w8 == 8 * w1
+    assert lib.geot_knn_grid_ws_bytes(-1, 5) == -1
+    assert lib.geot_ntm_threed_graph_bytes(2, 1000, 32) > 4 * (2 * 1000 * (2 * 64 + 4 * 32))
+    assert lib.geot_ntm_threed_loss_ws_bytes(2, 1000, 32) > 0 and lib.geot_ntm_sig_t_mean_ws_floats(8, 24000) > 0
+    assert lib.geot_ntm_correct_ws_floats(8, 24000) % 289 == 0
+    # gradients: reverse-index path when the source rows fit LDS and the workspace is big enough
+    assert lib.geot_grad_ws_needs_zero(8, 384, 8192, 24000, 3) == 0
+    assert lib.geot_grad_ws_needs_zero(8, 64, 24000, 6000 * 32, 1) == 1      # 768 KB rows: channels-last scatter
+    assert lib.geot_grad_ws_needs_zero(1, 16, 8192, 24000, 3) == 1           # workspace too small for the index
+    assert lib.geot_sa_param_floats(3, 3, (__import__("ctypes").c_int * 3)(64, 64, 128)) == 6 * 64 + 64 + 64 * 64 + 64 + 64 * 128 + 128
