@@ -5,18 +5,19 @@
 //   openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:101-260 (dense, block<=1024)
 //   pointops/src/sampling/sampling_cuda_kernel.cu:15-171, 175-349 (offset-batched, weighted)
 //
-// Design (MI355X-first, see DESIGN.md "FPS"):
-//   * one 1024-thread workgroup (16 wave64s, 4 per SIMD) per cloud; the cloud's
-//     xyz and running min-distance live in VGPRs for the whole kernel (<=24
-//     points per lane => n <= 24576), so a round touches no memory except the
-//     16-entry LDS exchange and one scalar load of the winner's coordinates;
-//   * the reference's block-size-dependent tie rule is reproduced with an
-//     explicit key  bitreverse(k mod bs) : (k div bs)  instead of inheriting
-//     whatever order our own reduction has, which frees the
-//     launch geometry from the reference's;
-//   * arg-max = wave DPP max of the fp32 bit pattern (non-negative floats order
-//     like unsigned ints) + DPP min of the key among the maxima, then one
-//     LDS hop + one barrier per round (double-buffered slots).
+// Design (MI355X-first):
+//   * the reference's block-size-dependent tie rule is reproduced with an explicit key
+//     bitreverse(k mod bs) : (k div bs)  instead of inheriting whatever order our own reduction
+//     has, which frees the launch geometry from the reference's;
+//   * three kernels, bit-identical outputs (tests run all three on every case):
+//       fps_kernel                 unpruned: one 1024-thread workgroup per cloud, <= 24 points per
+//                                  lane in VGPRs, DPP arg-max + one LDS hop + one barrier per round;
+//                                  weighted FPS, n < 1024, n > 24576 (streaming variant);
+//       fps_pruned_kernel<.., 1>   exact bucket pruning (Morton counting sort, per-slot boxes, cached
+//                                  wave candidates), one sample per round   (GEOT_FPS_IMPL=single);
+//       fps_pruned_kernel<.., 8>   the same with multi-commit rounds: up to 8 provably independent
+//                                  samples per round, the certain first one applied while wave 0
+//                                  ranks the candidates                     (default).
 #include "geot_common.h"
 #include "geot_hip.h"
 #include <cmath>
