@@ -569,3 +569,30 @@ def test_fps_multi_commit_soak_against_unpruned_kernel(ext, monkeypatch):
         monkeypatch.setenv("GEOT_FPS_IMPL", "basic")
         b_, tb = fps_k1p(ext, xyz, m, return_temp=True)
         assert np.array_equal(a, b_) and np.array_equal(ta, tb), (n, m)
+
+
+@pytest.mark.parametrize("b,c,m,L", [(3, 19, 777, 4001), (1, 384, 8192, 24000), (2, 70, 36864, 1500), (2, 33, 5, 3000),
+                                     (1, 16, 9000, 4100)])
+def test_lds_table_paths_match_plain_kernels(ext, b, c, m, L, monkeypatch):
+    """table-in-LDS gather (forward) and reverse-index gather (backward) against the register-gather / atomic
+    kernels on odd shapes: forward bit for bit, backward to summation order."""
+    rng = np.random.default_rng(b * 1000 + c)
+    feat = dev(rng.standard_normal((b, c, m)).astype(np.float32))
+    idx3 = dev(rng.integers(0, m, (b, L, 3)).astype(np.int32))
+    w3 = dev(rng.random((b, L, 3)).astype(np.float32))
+    g = dev(rng.standard_normal((b, c, L)).astype(np.float32))
+    ns = 4
+    idxg = dev(rng.integers(0, m, (b, L // ns, ns)).astype(np.int32))
+    gg = dev(rng.standard_normal((b, c, L // ns, ns)).astype(np.float32))
+    idx1 = dev(rng.integers(0, m, (b, L)).astype(np.int32))
+
+    def run():
+        return (ext.p2.three_interpolate(feat, idx3, w3), ext.p2.group_points(feat, idxg), ext.p2.gather_points(feat, idx1),
+                ext.p2.three_interpolate_grad(g, idx3, w3, m), ext.p2.group_points_grad(gg, idxg, m))
+    fast = run()
+    monkeypatch.setenv("GEOT_GATHER_IMPL", "plain")
+    plain = run()
+    for k in range(3):
+        assert torch.equal(fast[k], plain[k]), k
+    for k in (3, 4):
+        np.testing.assert_allclose(host(fast[k]), host(plain[k]), rtol=1e-4, atol=1e-4 * float(plain[k].abs().max()))
