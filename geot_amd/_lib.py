@@ -62,8 +62,8 @@ PROTOTYPES.update({
     "geot_ntm_threed_loss_ord": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_threed_loss_fwd_graph": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _P,
                                        ctypes.c_longlong, _c_void_p],
-    "geot_ntm_threed_loss_grad_graph": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, ctypes.c_longlong, _P,
-                                        _c_void_p],
+    "geot_ntm_threed_loss_grad_graph": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, ctypes.c_longlong,
+                                        _P, _c_void_p],
     "geot_spatial_order": [_c_int, _c_int, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_ntm_feature_loss": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_feature_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P,

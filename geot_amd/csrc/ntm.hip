@@ -718,11 +718,12 @@ __global__ __launch_bounds__(256) void tl_grad_gather_shared_kernel(
     int total_pts, int n, int k, float gscale, const float *__restrict__ T, const int *__restrict__ nbr,
     const float *__restrict__ wout, const float *__restrict__ S, const int *__restrict__ off,
     const int *__restrict__ rev, const float *__restrict__ revc, const int *__restrict__ order,
-    float *__restrict__ grad_T)
+    const float *__restrict__ upstream, float *__restrict__ grad_T)
 {
     constexpr int R = (CC + 63) / 64;
     const int lane = lane_id();
-    const float two_g = 2.f * gscale;
+    // upstream: optional device scalar (d loss_total / d this loss), so the host never has to read it back
+    const float two_g = 2.f * gscale * (upstream ? upstream[0] : 1.f);
     const int xcd_chunk = (((total_pts + 7) >> 3) + 4 * G - 1) / (4 * G) * (4 * G);
     for (int t = blockIdx.x >> 3;; t += gridDim.x >> 3) {
         const int within = (t * 4 + (threadIdx.x >> 6)) * G;
@@ -821,10 +822,11 @@ __global__ __launch_bounds__(256) void tl_grad_gather_shared_kernel(
 template <int CC>
 __global__ __launch_bounds__(256) void tl_overflow_kernel(int cap, float gscale, const float *__restrict__ T,
                                                           const int *__restrict__ ovf_cnt, const int *__restrict__ ovf,
-                                                          float *__restrict__ grad_T)
+                                                          const float *__restrict__ upstream, float *__restrict__ grad_T)
 {
     const int lane = lane_id();
     const int cnt = min(*ovf_cnt, cap);
+    gscale *= upstream ? upstream[0] : 1.f;
     for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < cnt; e += gridDim.x * 4) {
         const int tgt = ovf[3 * (size_t)e], src = ovf[3 * (size_t)e + 1];
         const float cf = 2.f * gscale * __int_as_float(ovf[3 * (size_t)e + 2]);
@@ -1077,7 +1079,7 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float s
         if (blocks > 16384) blocks = 16384;                                                                         \
         blocks = (blocks + 7) & ~7;                                                                                 \
         hipLaunchKernelGGL((tl_grad_gather_shared_kernel<CC, G, false>), dim3(blocks), dim3(256), 0, s, t, n, k, grad_scale, \
-                           ins_T, nbr, wout, S, off, rev, revc, order, grad_ins_T);                                 \
+                           ins_T, nbr, wout, S, off, rev, revc, order, nullptr, grad_ins_T);                        \
     }
     if (Gsel == 2) GEOT_TL_BWD(2) else if (Gsel == 3) GEOT_TL_BWD(3) else if (Gsel == 6) GEOT_TL_BWD(6) else GEOT_TL_BWD(4)
 #undef GEOT_TL_BWD
@@ -1130,9 +1132,10 @@ GEOT_EXPORT int geot_ntm_threed_loss_fwd_graph(int b, int n, int c, int k, float
     return hipGetLastError();
 }
 
-GEOT_EXPORT int geot_ntm_threed_loss_grad_graph(int b, int n, int c, int k, float grad_scale, const float *ins_T,
-                                                const int *nbr, const int *order, const void *graph,
-                                                long long graph_bytes, float *grad_ins_T, void *stream)
+GEOT_EXPORT int geot_ntm_threed_loss_grad_graph(int b, int n, int c, int k, float grad_scale,
+                                                const float *upstream, const float *ins_T, const int *nbr,
+                                                const int *order, const void *graph, long long graph_bytes,
+                                                float *grad_ins_T, void *stream)
 {
     if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
@@ -1145,9 +1148,10 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_graph(int b, int n, int c, int k, floa
     if (blocks > 16384) blocks = 16384;
     blocks = (blocks + 7) & ~7;
     hipLaunchKernelGGL((tl_grad_gather_shared_kernel<CC, G, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (int)t, n, k, grad_scale, ins_T, nbr, g.wout, g.S, g.cnt, g.rev, g.revc, order, grad_ins_T);
+                       (int)t, n, k, grad_scale, ins_T, nbr, g.wout, g.S, g.cnt, g.rev, g.revc, order, upstream,
+                       grad_ins_T);
     hipLaunchKernelGGL((tl_overflow_kernel<CC>), dim3(64), dim3(256), 0, (hipStream_t)stream, (int)(t * k), grad_scale,
-                       ins_T, g.ovf_cnt, g.ovf, grad_ins_T);
+                       ins_T, g.ovf_cnt, g.ovf, upstream, grad_ins_T);
     return hipGetLastError();
 }
 

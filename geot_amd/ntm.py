@@ -213,12 +213,15 @@ class _ThreeDLossFn(Function):
         positions, labels, ins_T, nbr, order, graph = ctx.saved_tensors
         b, n, _ = positions.shape
         c, k = ins_T.shape[1], nbr.shape[2]
-        g = torch.empty_like(ins_T) if graph is not None else torch.zeros_like(ins_T)
+        if graph is not None:   # writes g in full; the upstream gradient stays on the device (no host sync)
+            g = torch.empty_like(ins_T)
+            up = grad_out.reshape(1).float().contiguous()
+            call("geot_ntm_threed_loss_grad_graph", positions.device, b, n, c, k, 1.0 / (b * n), ptr(up), ptr(ins_T),
+                 ptr(nbr), ptr(order), ptr(graph), graph.numel(), ptr(g))
+            return None, None, g, None, None
+        g = torch.zeros_like(ins_T)
         scale = float(grad_out.item()) / (b * n) if grad_out.numel() == 1 else 1.0 / (b * n)
-        if graph is not None:   # writes g in full
-            call("geot_ntm_threed_loss_grad_graph", positions.device, b, n, c, k, scale, ptr(ins_T), ptr(nbr),
-                 ptr(order), ptr(graph), graph.numel(), ptr(g))
-        elif ctx.mode == "atomic":   # the scatter form
+        if ctx.mode == "atomic":     # the scatter form
             call("geot_ntm_threed_loss_grad", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
                  ptr(labels), ptr(ins_T), ptr(nbr), ptr(g))
         else:                        # graph rebuilt here (callers that did not keep the forward's)

@@ -256,9 +256,11 @@ long long geot_ntm_threed_graph_bytes(int b, int n, int k);
 int geot_ntm_threed_loss_fwd_graph(int b, int n, int c, int k, float sigma, const float *positions,
                                    const int *labels, const float *ins_T, const int *nbr, const int *order,
                                    float *per_point, void *graph, long long graph_bytes, void *stream);
-int geot_ntm_threed_loss_grad_graph(int b, int n, int c, int k, float grad_scale, const float *ins_T,
-                                    const int *nbr, const int *order, const void *graph, long long graph_bytes,
-                                    float *grad_ins_T, void *stream);
+int geot_ntm_threed_loss_grad_graph(int b, int n, int c, int k, float grad_scale, const float *upstream,
+                                    const float *ins_T, const int *nbr, const int *order, const void *graph,
+                                    long long graph_bytes, float *grad_ins_T, void *stream);
+/* upstream: optional DEVICE scalar multiplied into grad_scale (autograd's incoming gradient), so the host
+ * does not have to read it back; NULL = 1. */
 int geot_spatial_order(int b, int n, const float *xyz, int *order, void *workspace, long long ws_bytes,
                        void *stream); /* workspace: geot_knn_grid_ws_bytes(b, n) bytes, 16-byte aligned */
 /* feature_space_loss (utils/insT_loss.py:9-58; disabled in the shipped cfg, use_feat_loss): same graph
