@@ -25,7 +25,7 @@ namespace geot {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int SA_WAVES = 4;
+constexpr int SA_WAVES = 8;   // at most; the launcher uses 4 when 8 activation tiles do not fit the LDS
 constexpr int SA_MAX_LAYERS = 4;
 
 struct SaDesc {
@@ -36,7 +36,7 @@ struct SaDesc {
     int boff[SA_MAX_LAYERS]; // float offset of bias [cp]
     int relu_mask;           // bit l = ReLU after layer l
     int total;               // floats in the parameter block
-    int act_stride;          // floats per activation row (max width + 1, odd)
+    int act_stride;          // floats per activation row (widest STORED activation + 1, odd; the last layer is pooled from registers)
 };
 
 template <int NCT>
@@ -134,7 +134,8 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_group_mlp_max_kernel(
     const int cp_last = d.cp[d.nlayers - 1];
     float *act = sa_lds + d.total + wave * (32 * d.act_stride + 4 * cp_last);
     float *pool = act + 32 * d.act_stride;
-    for (int i = threadIdx.x; i < d.total; i += SA_WAVES * 64) P[i] = params[i];
+    const int nwaves = blockDim.x >> 6;
+    for (int i = threadIdx.x; i < d.total; i += blockDim.x) P[i] = params[i];
     __syncthreads();
 
     const int gpt = nsample >= 32 ? 1 : 32 / nsample;  // groups per 32-row tile
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_group_mlp_max_kernel(
     const long long ngroups = (long long)b * npoint;
     const long long nunits = (ngroups + gpt - 1) / gpt;
     const int k_in = 3 + c_feat;
-    for (long long u = (long long)blockIdx.x * SA_WAVES + wave; u < nunits; u += (long long)gridDim.x * SA_WAVES) {
+    for (long long u = (long long)blockIdx.x * nwaves + wave; u < nunits; u += (long long)gridDim.x * nwaves) {
         for (int i = lane; i < gpt * cp_last; i += 64) pool[i] = -INFINITY;
         for (int t = 0; t < tpg; ++t) {
             // ---- layer-0 input: row r of the tile <- (xyz[idx]-centre)*scale, features[:, idx]
@@ -227,12 +228,19 @@ GEOT_EXPORT int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int
         if (widths[l] < 1 || widths[l] > 256) return hipErrorInvalidValue;
         int cp = pad_cols(widths[l]);
         d.kp[l] = kp; d.cp[l] = cp; d.woff[l] = off; off += kp * cp; d.boff[l] = off; off += cp;
-        if (cp > maxw) maxw = cp;
+        if (l + 1 < nlayers && cp > maxw) maxw = cp; // the last layer's output never goes to the activation tile
         kp = cp;
     }
     d.total = off;
     d.act_stride = maxw + 1;
-    size_t lds = ((size_t)d.total + (size_t)SA_WAVES * (32 * d.act_stride + 4 * d.cp[nlayers - 1])) * sizeof(float);
+    // two waves per SIMD (8 per workgroup) when their activation tiles fit next to the weights: one wave's LDS
+    // round trips and accumulator hand-offs between layers then overlap with the other's MFMA chain
+    int waves = SA_WAVES;
+    size_t lds = ((size_t)d.total + (size_t)waves * (32 * d.act_stride + 4 * d.cp[nlayers - 1])) * sizeof(float);
+    if (lds > 160 * 1024) {
+        waves = 4;
+        lds = ((size_t)d.total + (size_t)waves * (32 * d.act_stride + 4 * d.cp[nlayers - 1])) * sizeof(float);
+    }
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
@@ -243,9 +251,9 @@ GEOT_EXPORT int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int
     }
     int gpt = nsample >= 32 ? 1 : 32 / nsample;
     long long nunits = ((long long)b * npoint + gpt - 1) / gpt;
-    long long blocks = (nunits + SA_WAVES - 1) / SA_WAVES;
+    long long blocks = (nunits + waves - 1) / waves;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sa_group_mlp_max_kernel, dim3((unsigned)blocks), dim3(SA_WAVES * 64), lds,
+    hipLaunchKernelGGL(sa_group_mlp_max_kernel, dim3((unsigned)blocks), dim3(waves * 64), lds,
                        (hipStream_t)stream, d, b, n, npoint, nsample, c_feat, widths[nlayers - 1], xyz,
                        new_xyz, features, idx, xyz_scale, params, out);
     return hipGetLastError();

@@ -52,7 +52,7 @@ def fused_sa_available(mlp):
     floats = _lib.load().geot_sa_param_floats(c_feat, len(widths), arr)
     if floats < 0:
         return False
-    maxw = max([(3 + c_feat + 1) & ~1] + [_pad_cols(w) for w in widths])
+    maxw = max([(3 + c_feat + 1) & ~1] + [_pad_cols(w) for w in widths[:-1]])   # the last layer is pooled from registers
     lds = 4 * (floats + 4 * (32 * (maxw + 1) + 4 * _pad_cols(widths[-1])))
     return lds <= 160 * 1024
 
