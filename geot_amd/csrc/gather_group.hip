@@ -517,39 +517,48 @@ static hipError_t tlds_gather(const TldsPlan &p, int b, int c, int m, int L, con
 // keeps `ch` rows of grad_out (L floats each) in LDS and every thread sums one target's list from LDS:
 // no float atomics at all, and grad_out is read exactly once.  Needs L <= TLDS_FLOATS (the prop0/1/2
 // interpolations, the kNN graph features, the 512-group gather; not the 6000 x 32 SA grouping).
-__global__ __launch_bounds__(256) void rix_count_kernel(long long total, long long per_batch, int m,
-                                                        const int *__restrict__ idx, int *__restrict__ cnt,
-                                                        int *__restrict__ rank)
+// The L sources of a batch are cut into Q parts of `partlen` (Q = 1: one part); pairs are grouped by
+// (batch, part, target), so that a workgroup holding the rows of ONE part in LDS finds exactly its entries.
+__global__ __launch_bounds__(256) void rix_count_kernel(long long total, long long per_batch, int m, int nt, int Q,
+                                                        int partlen, const int *__restrict__ idx,
+                                                        int *__restrict__ cnt, int *__restrict__ rank)
 {
     const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
     if (x >= total) return;
     const int bi = (int)(x / per_batch);
-    rank[x] = atomicAdd(&cnt[(size_t)bi * m + idx[x]], 1);
+    const int e = (int)((x - (long long)bi * per_batch) / nt), part = e / partlen;
+    rank[x] = atomicAdd(&cnt[((size_t)bi * Q + part) * m + idx[x]], 1);
 }
 template <bool WEIGHTED>
-__global__ __launch_bounds__(256) void rix_fill_kernel(long long total, long long per_batch, int m, int nt,
-                                                       const int *__restrict__ idx, const float *__restrict__ weight,
-                                                       const int *__restrict__ off, const int *__restrict__ rank,
-                                                       int *__restrict__ rev, float *__restrict__ revw)
+__global__ __launch_bounds__(256) void rix_fill_kernel(long long total, long long per_batch, int m, int nt, int Q,
+                                                       int partlen, const int *__restrict__ idx,
+                                                       const float *__restrict__ weight, const int *__restrict__ off,
+                                                       const int *__restrict__ rank, int *__restrict__ rev,
+                                                       float *__restrict__ revw)
 {
     const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
     if (x >= total) return;
     const int bi = (int)(x / per_batch);
-    const int pos = off[(size_t)bi * m + idx[x]] + rank[x];
-    rev[pos] = (int)((x - (long long)bi * per_batch) / nt); // source element within its batch
+    const int e = (int)((x - (long long)bi * per_batch) / nt), part = e / partlen;
+    const int pos = off[((size_t)bi * Q + part) * m + idx[x]] + rank[x];
+    rev[pos] = e - part * partlen; // source element within its part
     if (WEIGHTED) revw[pos] = weight[x];
 }
 
 template <bool WEIGHTED, int CH>
 __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
-    int c, int m, int L, const float *__restrict__ grad_out, size_t src_bstride,
+    int c, int m, int L, int Q, int partlen, const float *__restrict__ grad_out, size_t src_bstride,
     const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw,
     float *__restrict__ grad_table)
 {
-    extern __shared__ float tlds_rows[]; // [CH][L] rows of grad_out
-    const int bi = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, c - c0);
-    const float *src = grad_out + (size_t)bi * src_bstride + (size_t)c0 * L;
-    tlds_load_rows(tlds_rows, src, nch * L);
+    extern __shared__ float tlds_rows[]; // [CH][plen] this part of CH rows of grad_out
+    const int bq = blockIdx.z, bi = bq / Q, part = bq - bi * Q;
+    const int c0 = blockIdx.y * CH, nch = min(CH, c - c0);
+    const int p0 = part * partlen, plen = min(partlen, L - p0);
+    const float *src = grad_out + (size_t)bi * src_bstride + (size_t)c0 * L + p0;
+    if (Q == 1) tlds_load_rows(tlds_rows, src, nch * L); // whole rows are contiguous
+    else
+        for (int l = 0; l < nch; ++l) tlds_load_rows(tlds_rows + l * plen, src + (size_t)l * L, plen);
     __syncthreads();
     const int per = (m + gridDim.x - 1) / gridDim.x;
     const int j0 = blockIdx.x * per, j1 = min(m, j0 + per);
@@ -562,8 +571,8 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
             const int j = jb + p * TLDS_THREADS;
-            a[p] = j < j1 ? off[(size_t)bi * m + j] : 0;
-            z[p] = j < j1 ? off[(size_t)bi * m + j + 1] : 0;
+            a[p] = j < j1 ? off[(size_t)bq * m + j] : 0;
+            z[p] = j < j1 ? off[(size_t)bq * m + j + 1] : 0;
 #pragma unroll
             for (int l = 0; l < CH; ++l) acc[p][l] = 0.f;
         }
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
                 for (int l = 0; l < CH; ++l) {
                     if (l < nch) {
 #pragma unroll
-                        for (int u = 0; u < RU; ++u) acc[p][l] = fmaf(w[p][u], tlds_rows[l * L + e[p][u]], acc[p][l]);
+                        for (int u = 0; u < RU; ++u) acc[p][l] = fmaf(w[p][u], tlds_rows[l * plen + e[p][u]], acc[p][l]);
                     }
                 }
         }
@@ -597,17 +606,42 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
             const int j = jb + p * TLDS_THREADS;
             if (j < j1 && z[p] > a[p]) { // untouched targets keep what they had (the buffer is accumulated into)
 #pragma unroll
-                for (int l = 0; l < CH; ++l)
-                    if (l < nch) grad_table[((size_t)bi * c + c0 + l) * m + j] += acc[p][l];
+                for (int l = 0; l < CH; ++l) {
+                    if (l < nch) {
+                        float *dst = grad_table + ((size_t)bi * c + c0 + l) * m + j;
+                        if (Q == 1) *dst += acc[p][l];   // sole writer of this element
+                        else atomicAdd(dst, acc[p][l]);  // one contribution per part; lanes = consecutive targets
+                    }
+                }
             }
         }
     }
 }
 
 // ints needed in the workspace for the reverse index of (b, L, nt) pairs onto m targets per batch
-static inline long long rix_ws_ints(int b, int m, long long L, int nt)
+// Parts: with whole rows in LDS only TLDS_FLOATS / L channels share a workgroup, and each of them re-reads the
+// whole index (8 bytes per pair): at L = 24 000 that is one channel per workgroup and 4.4x more index than
+// payload traffic.  Cutting the source range into Q parts lets >= 4 channels share one part's entries.
+struct RixPlan {
+    int Q, partlen, ch;
+};
+static RixPlan rix_plan(int c, long long L)
 {
-    const long long t = (long long)b * m, pairs = (long long)b * L * nt;
+    RixPlan p{1, (int)L, 1};
+    int ch = (int)(TLDS_FLOATS / L);
+    if (ch < 4 && c >= 4) {
+        p.Q = (int)((4 * L + TLDS_FLOATS - 1) / TLDS_FLOATS);
+        p.partlen = (int)(((L + p.Q - 1) / p.Q + 3) & ~3LL); // 16-byte aligned parts
+        p.Q = (int)((L + p.partlen - 1) / p.partlen);
+        ch = TLDS_FLOATS / p.partlen;
+    }
+    p.ch = ch >= 8 ? 8 : (ch >= 4 ? 4 : (ch >= 2 ? 2 : 1)); // template instantiations
+    while (p.ch > 1 && p.ch > c) p.ch >>= 1;
+    return p;
+}
+static inline long long rix_ws_ints(int b, int c, int m, long long L, int nt)
+{
+    const long long t = (long long)b * rix_plan(c, L).Q * m, pairs = (long long)b * L * nt;
     return (t + 1) + scan_blocks(t) + 3 * pairs + 8;
 }
 
@@ -615,7 +649,8 @@ static bool csr_applies(int b, int c, int m, long long L, int nt, long long ws_f
 {
     const char *env = getenv("GEOT_GATHER_IMPL");
     if ((env && env[0] == 'p') || L < 1 || L > TLDS_FLOATS || L * c < (1 << 16)) return false;
-    return ws_floats >= rix_ws_ints(b, m, L, nt) && (long long)b * L * nt <= 0x7fffffffLL;
+    return ws_floats >= rix_ws_ints(b, c, m, L, nt) && (long long)b * L * nt <= 0x7fffffffLL &&
+           (long long)b * rix_plan(c, L).Q * m <= 0x7ffffff0LL;
 }
 
 // returns hipErrorNotSupported when this path does not apply (caller falls back)
@@ -625,10 +660,9 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
                                   long long ws_floats, hipStream_t s)
 {
     if (!csr_applies(b, c, m, L, NT, ws_floats)) return hipErrorNotSupported;
-    int ch = TLDS_FLOATS / L;
-    ch = ch >= 8 ? 8 : (ch >= 4 ? 4 : (ch >= 2 ? 2 : 1)); // template instantiations
-    while (ch > 1 && ch > c) ch >>= 1;
-    const long long t = (long long)b * m, pairs = (long long)b * L * NT;
+    const RixPlan rp = rix_plan(c, L);
+    const int ch = rp.ch, Q = rp.Q;
+    const long long t = (long long)b * Q * m, pairs = (long long)b * L * NT;
     int *off = (int *)workspace;
     int *bsum = off + t + 1;
     int *rank = bsum + scan_blocks(t);
@@ -637,22 +671,24 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     hipError_t e = hipMemsetAsync(off, 0, (size_t)(t + 1) * sizeof(int), s);
     if (e != hipSuccess) return e;
     const int pb = (int)((pairs + 255) / 256);
-    hipLaunchKernelGGL(rix_count_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, idx, off, rank);
+    hipLaunchKernelGGL(rix_count_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, Q, rp.partlen, idx,
+                       off, rank);
     exclusive_scan_i32((int)t, off, bsum, nullptr, s);
-    hipLaunchKernelGGL((rix_fill_kernel<WEIGHTED>), dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, idx,
-                       weight, off, rank, rev, revw);
-    const size_t lds = (size_t)ch * L * sizeof(float);
+    hipLaunchKernelGGL((rix_fill_kernel<WEIGHTED>), dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, Q,
+                       rp.partlen, idx, weight, off, rank, rev, revw);
+    const size_t lds = (size_t)ch * rp.partlen * sizeof(float);
     const int chunks = (c + ch - 1) / ch;
-    long long slices = (512 + (long long)chunks * b - 1) / ((long long)chunks * b);
+    long long slices = (512 + (long long)chunks * b * Q - 1) / ((long long)chunks * b * Q);
     if (slices > m / 1024) slices = m / 1024;
     if (slices < 1) slices = 1;
-    const dim3 grid((int)slices, chunks, b);
+    if ((long long)b * Q > 65535) return hipErrorNotSupported;
+    const dim3 grid((int)slices, chunks, b * Q);
 #define GEOT_CSR_LAUNCH(CHV)                                                                                     \
     {                                                                                                            \
         e = tlds_set_lds(table_gather_csr_lds_kernel<WEIGHTED, CHV>, lds);                                       \
         if (e != hipSuccess) return e;                                                                           \
         hipLaunchKernelGGL((table_gather_csr_lds_kernel<WEIGHTED, CHV>), grid, dim3(TLDS_THREADS), lds, s, c, m, L, \
-                           grad_out, src_bstride, off, rev, revw, grad_table);                                   \
+                           Q, rp.partlen, grad_out, src_bstride, off, rev, revw, grad_table);                    \
     }
     if (ch == 8) GEOT_CSR_LAUNCH(8) else if (ch == 4) GEOT_CSR_LAUNCH(4) else if (ch == 2) GEOT_CSR_LAUNCH(2) else GEOT_CSR_LAUNCH(1)
 #undef GEOT_CSR_LAUNCH
