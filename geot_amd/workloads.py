@@ -27,18 +27,40 @@ def _fp(unknown, known, feats):
 
 
 class BackboneHotPath(torch.nn.Module):
-    def __init__(self):
+    def __init__(self, overlap=True):
         super().__init__()
         self.group = Group(GROUPS, GROUP_SIZE)
         self.knn4 = KNN(k=4, transpose_mode=False)
+        self.overlap = overlap
+        self._side = {}
+
+    def _side_stream(self, device):
+        key = str(device)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
 
     def forward(self, pts, tokens):
         """pts (B,N,3); tokens (B,384,512) stands for the transformer output at the 512 group centres.
         Returns the (B,384,N) propagated features (sum of the interpolation outputs feeds backward)."""
         B, N, _ = pts.shape
-        neighborhood, center, _ = self.group(pts)                                  # FPS 512 + kNN 32 + gather
+        # FPS keeps one CU per cloud busy for milliseconds and leaves the other ~250 idle: the patch-embedding
+        # front end (FPS 512 + kNN 32 + gather), which does not depend on the 8192-point FPS, runs beside it on
+        # a second HIP stream (the C ABI launches on torch's current stream, so `with torch.cuda.stream` is
+        # all it takes); the main stream waits for it before the first consumer.
+        side = self._side_stream(pts.device) if self.overlap else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(pts.device))
+            with torch.cuda.stream(side):
+                neighborhood, center, _ = self.group(pts)                          # FPS 512 + kNN 32 + gather
+        else:
+            neighborhood, center, _ = self.group(pts)
         c8192, c4096 = pointops.fps(pts, 8192), pointops.fps(pts, 4096)            # one FPS run (prefix reuse)
         pointops.fps(pts, 2048)                                                    # computed, unused (reference)
+        if side is not None:
+            torch.cuda.current_stream(pts.device).wait_stream(side)
+            neighborhood.record_stream(torch.cuda.current_stream(pts.device))
+            center.record_stream(torch.cuda.current_stream(pts.device))
         f_l2 = _fp(c4096, center, tokens)                                          # propogation_2: 512 -> 4096
         f_l1 = _fp(c8192, center, tokens)                                          # propogation_1: 512 -> 8192
         ct, c4t, c8t = (center.transpose(1, 2).contiguous(), c4096.transpose(1, 2).contiguous(),
