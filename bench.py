@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--workload", choices=["sa", "backbone_ops", "ntm"], default="sa")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the steps are dealt to round-robin (default 1 = strictly one after the other; "
+                         "2 lets step i+1's FPS, which occupies one CU per cloud, run beside step i's ball query + MLP)")
     return ap.parse_args()
 
 
@@ -201,8 +204,14 @@ def main():
     dist_utils.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    if args.streams > 1:
+        pool = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
+        for i in range(args.steps):
+            with torch.cuda.stream(pool[i % args.streams]):
+                out = step()
+    else:
+        for _ in range(args.steps):
+            out = step()
     torch.cuda.synchronize()
     dist_utils.barrier()
     torch.cuda.synchronize()
@@ -231,7 +240,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": desc, "clouds_per_gpu": B, "points": N_POINTS,
-                   "parallelism": "independent clouds per rank, no collective"},
+                   "parallelism": "independent clouds per rank, no collective" +
+                                  ("" if args.streams == 1 else "; consecutive steps overlap on %d HIP streams" % args.streams)},
         "roofline": {"kernel": "fps_pruned_kernel", "bound": "valu",
                      "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
