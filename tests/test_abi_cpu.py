@@ -128,3 +128,23 @@ def test_host_only_planning_entry_points(monkeypatch):
     assert lib.geot_grad_ws_needs_zero(8, 64, 24000, 6000 * 32, 1) == 1      # 768 KB rows: channels-last scatter
     assert lib.geot_grad_ws_needs_zero(1, 16, 8192, 24000, 3) == 1           # workspace too small for the index
     assert lib.geot_sa_param_floats(3, 3, (__import__("ctypes").c_int * 3)(64, 64, 128)) == 6 * 64 + 64 + 64 * 64 + 64 + 64 * 128 + 128
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/geot_hip.h must be consumable from C (no C++ / torch types) and every declared entry point must
+    resolve at link time against the shared library -- what a maintainer's cgo / JNI / C++ forwarder would do."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "geot_hip.h")).read()
+    names = sorted(set(re.findall(r"\b(geot_[a-z0-9_]+)\s*\(", hdr)))
+    src = tmp_path / "link_all.c"
+    body = "\n".join("    p[%d] = (fn)%s;" % (i, n) for i, n in enumerate(names))
+    src.write_text('#include "geot_hip.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n    fn p[%d];\n%s\n'
+                   '    printf("%%d %%d\\n", geot_abi_version(), p[0] != 0);\n    return 0;\n}\n' % (len(names), body))
+    lib_dir = os.path.join(root, "geot_amd")
+    exe = tmp_path / "link_all"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+           "-L", lib_dir, "-lgeot_hip", "-Wl,-rpath," + lib_dir, "-Wl,--unresolved-symbols=ignore-in-shared-libs"]
+    subprocess.check_call(cmd)
+    assert len(names) >= 50
