@@ -45,6 +45,7 @@ PROTOTYPES.update({
     "geot_group_points_grad_ws": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_three_interpolate_grad_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ball_query_ws": [_c_int, _c_int, _c_int, _c_float, _c_int, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
+    "geot_knnquery_heap_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_knn_sorted_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_three_nn_ws": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_graph_feature": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
@@ -73,6 +74,7 @@ PROTOTYPES.update({
 PLAIN = {
     "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),
     "geot_knn_grid_ws_bytes": ([_c_int, _c_int], ctypes.c_longlong),
+    "geot_knnquery_heap_ws_bytes": ([_c_int, _c_int, _c_int, _c_int], ctypes.c_longlong),
     "geot_grad_ws_needs_zero": ([_c_int, _c_int, _c_int, ctypes.c_longlong, _c_int], _c_int),
     "geot_ntm_sig_t_mean_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_threed_loss_ws_bytes": ([_c_int, _c_int, _c_int], ctypes.c_longlong),

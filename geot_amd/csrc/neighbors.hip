@@ -176,15 +176,17 @@ __device__ __forceinline__ void heap_sift(LdsList h, int k)
     }
 }
 
+// qlist / qcount (nullable): process only the listed queries (the ones the fast path could not certify)
 __global__ __launch_bounds__(KNN_THREADS) void knnquery_heap_kernel(
     int b, int m, int nsample, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
-    const int *__restrict__ offset, const int *__restrict__ new_offset, int *__restrict__ idx,
-    float *__restrict__ dist2)
+    const int *__restrict__ offset, const int *__restrict__ new_offset, const int *__restrict__ qlist,
+    const int *__restrict__ qcount, int *__restrict__ idx, float *__restrict__ dist2)
 {
     extern __shared__ float knn_lds[];
     LdsList h{knn_lds + threadIdx.x, (int *)(knn_lds + nsample * KNN_THREADS) + threadIdx.x};
-    const int p = blockIdx.x * KNN_THREADS + threadIdx.x;
-    if (p >= m) return;
+    const int t = blockIdx.x * KNN_THREADS + threadIdx.x;
+    if (t >= (qcount ? min(*qcount, m) : m)) return;
+    const int p = qlist ? qlist[t] : t;
     int bt = segment_of(p, new_offset, b);
     int start = bt ? offset[bt - 1] : 0, end = offset[bt];
     float qx = new_xyz[p * 3], qy = new_xyz[p * 3 + 1], qz = new_xyz[p * 3 + 2];
@@ -381,7 +383,77 @@ GEOT_EXPORT int geot_knnquery_heap(int b, int m, int nsample, const float *xyz, 
     size_t lds = (size_t)nsample * KNN_THREADS * 8;
     hipLaunchKernelGGL(knnquery_heap_kernel, dim3((m + KNN_THREADS - 1) / KNN_THREADS),
                        dim3(KNN_THREADS), lds, (hipStream_t)stream, b, m, nsample, xyz, new_xyz, offset,
-                       new_offset, idx, dist2);
+                       new_offset, nullptr, nullptr, idx, dist2);
+    return hipGetLastError();
+}
+
+// ---- pointops kNN, fast path for uniform batches ------------------------------------------------
+// The reference's max-heap + heap-sort (knnquery_cuda_kernel.cu:21-108) returns the k nearest in ascending
+// order; only the order among EQUAL distances depends on the heap mechanics.  So: sorted (k+1)-NN from the
+// exact grid search; a query whose first k+1 distances are strictly increasing has a unique answer, which
+// is copied; the others (duplicates, lattice ties, fewer than k+1 candidates) are listed and go through the
+// literal heap kernel.  Identical output to geot_knnquery_heap.
+__global__ __launch_bounds__(256) void knn_heap_certify_kernel(int m_total, int m_per, int n_per, int k,
+                                                               const int *__restrict__ tidx, const float *__restrict__ td2,
+                                                               int *__restrict__ idx, float *__restrict__ dist2,
+                                                               int *__restrict__ qlist, int *__restrict__ qcount)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= m_total) return;
+    const float *d = td2 + (size_t)p * (k + 1);
+    bool strict = d[k] < 1e10f; // the heap never takes distances >= its 1e10 initial root
+    for (int s = 0; s < k; ++s) strict = strict && d[s] < d[s + 1];
+    if (strict) {
+        const int base = (p / m_per) * n_per; // global index of the batch's first support point
+        for (int s = 0; s < k; ++s) {
+            idx[(size_t)p * k + s] = base + tidx[(size_t)p * (k + 1) + s];
+            dist2[(size_t)p * k + s] = d[s];
+        }
+    } else {
+        qlist[atomicAdd(qcount, 1)] = p;
+    }
+}
+
+extern "C" long long geot_knn_grid_ws_bytes(int b, int nr);
+extern "C" int geot_knn_grid_eligible(int b, int nq, int nr, int k);
+extern "C" int geot_knn_sorted_ws(int b, int nq, int nr, int k, const float *query, const float *ref, int *idx,
+                                  float *dist2, void *workspace, long long ws_bytes, void *stream);
+
+GEOT_EXPORT long long geot_knnquery_heap_ws_bytes(int b, int n_per, int m_per, int nsample)
+{
+    if (b < 0 || n_per < 0 || m_per < 0 || nsample < 0) return -1;
+    const long long mt = (long long)b * m_per;
+    long long bytes = geot_knn_grid_ws_bytes(b, n_per);
+    bytes += 4 * (2 * mt * (nsample + 1) + mt + 4);
+    return (bytes + 15) & ~15LL;
+}
+
+GEOT_EXPORT int geot_knnquery_heap_ws(int b, int n_per, int m_per, int nsample, const float *xyz,
+                                      const float *new_xyz, const int *offset, const int *new_offset, int *idx,
+                                      float *dist2, void *workspace, long long ws_bytes, void *stream)
+{
+    if (b < 0 || n_per < 0 || m_per < 0 || nsample < 0 || nsample > 256) return hipErrorInvalidValue;
+    const long long mt = (long long)b * m_per;
+    if (b == 0 || mt == 0 || nsample == 0) return hipSuccess;
+    if (mt > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (!workspace || nsample > 63 || !geot_knn_grid_eligible(b, m_per, n_per, nsample + 1) ||
+        ws_bytes < geot_knnquery_heap_ws_bytes(b, n_per, m_per, nsample) || ((uintptr_t)workspace & 15) != 0)
+        return geot_knnquery_heap(b, (int)mt, nsample, xyz, new_xyz, offset, new_offset, idx, dist2, stream);
+    hipStream_t s = (hipStream_t)stream;
+    const long long gbytes = geot_knn_grid_ws_bytes(b, n_per);
+    int *tidx = (int *)((char *)workspace + gbytes);
+    float *td2 = (float *)(tidx + mt * (nsample + 1));
+    int *qlist = (int *)(td2 + mt * (nsample + 1));
+    int *qcount = qlist + mt;
+    hipError_t e = hipMemsetAsync(qcount, 0, sizeof(int), s);
+    if (e != hipSuccess) return e;
+    int rc = geot_knn_sorted_ws(b, m_per, n_per, nsample + 1, new_xyz, xyz, tidx, td2, workspace, gbytes, stream);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(knn_heap_certify_kernel, dim3((int)((mt + 255) / 256)), dim3(256), 0, s, (int)mt, m_per, n_per,
+                       nsample, tidx, td2, idx, dist2, qlist, qcount);
+    size_t lds = (size_t)nsample * KNN_THREADS * 8;
+    hipLaunchKernelGGL(knnquery_heap_kernel, dim3((int)((mt + KNN_THREADS - 1) / KNN_THREADS)), dim3(KNN_THREADS), lds, s, b,
+                       (int)mt, nsample, xyz, new_xyz, offset, new_offset, qlist, qcount, idx, dist2);
     return hipGetLastError();
 }
 

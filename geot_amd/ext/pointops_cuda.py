@@ -29,6 +29,23 @@ def knnquery_cuda(m, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
          ptr(idx), ptr(dist2))
 
 
+def knnquery_uniform(b, n_per, m_per, nsample, xyz, new_xyz, offset, new_offset, idx, dist2):
+    """knnquery_cuda for batches of equal segments (b x n_per support, b x m_per queries): same output through
+    the grid search + tie certification (not part of the reference module; used by pointops.knn)."""
+    f32(xyz, "xyz", 2); f32(new_xyz, "new_xyz", 2); i32(offset, "offset", 1); i32(new_offset, "new_offset", 1)
+    i32(idx, "idx"); f32(dist2, "dist2")
+    dev = same_device(xyz, new_xyz, offset, new_offset, idx, dist2)
+    need(xyz.shape[0] == b * n_per and new_xyz.shape[0] == b * m_per and idx.numel() == b * m_per * nsample
+         and dist2.numel() == b * m_per * nsample and offset.shape[0] == b and new_offset.shape[0] == b,
+         "knnquery_uniform size mismatch")
+    import torch
+    from .. import _lib
+    nbytes = int(_lib.load().geot_knnquery_heap_ws_bytes(int(b), int(n_per), int(m_per), int(nsample)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    call("geot_knnquery_heap_ws", dev, int(b), int(n_per), int(m_per), int(nsample), ptr(xyz), ptr(new_xyz),
+         ptr(offset), ptr(new_offset), ptr(idx), ptr(dist2), ptr(ws), nbytes)
+
+
 def furthestsampling_cuda(b, n_max, xyz, offset, new_offset, tmp, idx):
     f32(xyz, "xyz", 2); i32(offset, "offset", 1); i32(new_offset, "new_offset", 1); f32(tmp, "tmp"); i32(idx, "idx")
     dev = same_device(xyz, offset, new_offset, tmp, idx)

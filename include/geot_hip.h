@@ -140,6 +140,14 @@ int geot_three_interpolate_grad(int b, int c, int n, int m, const float *grad_ou
 int geot_knnquery_heap(int b, int m, int nsample, const float *xyz, const float *new_xyz,
                        const int *offset, const int *new_offset, int *idx, float *dist2,
                        void *stream);
+/* geot_knnquery_heap for uniform batches (every segment n_per support points, m_per queries, as
+ * pointops.knn builds them): sorted (nsample+1)-NN from the grid search; queries whose first nsample+1
+ * distances are strictly increasing have a unique answer and are copied, the rest (ties, too few
+ * candidates) go through the literal heap.  Identical output.  workspace: geot_knnquery_heap_ws_bytes. */
+long long geot_knnquery_heap_ws_bytes(int b, int n_per, int m_per, int nsample);
+int geot_knnquery_heap_ws(int b, int n_per, int m_per, int nsample, const float *xyz, const float *new_xyz,
+                          const int *offset, const int *new_offset, int *idx, float *dist2, void *workspace,
+                          long long ws_bytes, void *stream);
 /* Sorted brute-force kNN: the contract of the un-vendored knn_cuda.KNN
  * (openpoints/models/backbone/transformer.py:280,293,313,353) and of
  * knn_point = cdist + topk (openpoints/models/layers/knn.py:7-20).

@@ -596,3 +596,26 @@ def test_lds_table_paths_match_plain_kernels(ext, b, c, m, L, monkeypatch):
         assert torch.equal(fast[k], plain[k]), k
     for k in (3, 4):
         np.testing.assert_allclose(host(fast[k]), host(plain[k]), rtol=1e-4, atol=1e-4 * float(plain[k].abs().max()))
+
+
+@pytest.mark.parametrize("k", [2, 6, 17])
+def test_pointops_knn_fast_path_equals_literal_heap(ext, k):
+    """pointops.knn on equal segments (grid search + tie certification + heap for the tied queries) must equal
+    the literal max-heap kernel element for element, duplicates and lattice ties included."""
+    from geot_amd.pointops.functions import pointops
+    from geot_amd import _lib
+    rng = np.random.default_rng(31 + k)
+    B, N = 2, 6000
+    xyz, _ = make_batch(B, N, start_index=60, dup_frac=0.05)
+    xyz[1] = (xyz[1] * 48).round() / 48                                  # quantised: many exact distance ties
+    x = dev(xyz)
+    assert _lib.load().geot_knn_grid_eligible(B, N, N, k + 1) == 1
+    idx, dist = pointops.knn(x, x, k)
+    flat = x.reshape(-1, 3).contiguous()
+    off = dev(np.array([N, 2 * N]), torch.int32)
+    widx = torch.zeros((B * N, k), dtype=torch.int32, device=DEV)
+    wd2 = torch.zeros((B * N, k), dtype=torch.float32, device=DEV)
+    ext.pops.knnquery_cuda(B * N, k, flat, flat, off, off, widx, wd2)
+    want_local = widx.view(B, N, k).long() - (torch.arange(B, device=DEV) * N)[:, None, None]
+    assert torch.equal(idx, want_local)
+    assert torch.equal(dist, torch.sqrt(wd2).view(B, N, k))
