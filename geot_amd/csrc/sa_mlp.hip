@@ -252,7 +252,16 @@ GEOT_EXPORT int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int
     int gpt = nsample >= 32 ? 1 : 32 / nsample;
     long long nunits = ((long long)b * npoint + gpt - 1) / gpt;
     long long blocks = (nunits + waves - 1) / waves;
-    if (blocks > 4096) blocks = 4096;
+    // persistent workgroups: one per CU (the weights + activation tiles fill its LDS), each looping over its
+    // share of the tiles, so the 52 KB of weights are staged once per CU and not once per 8 tiles
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        n_cus = cus;
+    }
+    if (blocks > n_cus) blocks = n_cus;
     hipLaunchKernelGGL(sa_group_mlp_max_kernel, dim3((unsigned)blocks), dim3(waves * 64), lds,
                        (hipStream_t)stream, d, b, n, npoint, nsample, c_feat, widths[nlayers - 1], xyz,
                        new_xyz, features, idx, xyz_scale, params, out);
