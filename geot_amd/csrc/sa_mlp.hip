@@ -25,7 +25,7 @@ namespace geot {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int SA_WAVES = 8;   // at most; the launcher uses 4 when 8 activation tiles do not fit the LDS
+constexpr int SA_WAVES = 12;  // at most (3 per SIMD); the launcher uses 8 or 4 when the activation tiles do not fit the LDS
 constexpr int SA_MAX_LAYERS = 4;
 
 struct SaDesc {
@@ -122,7 +122,10 @@ __device__ __forceinline__ void sa_run_layer(const SaDesc &d, int l, const float
     else sa_pool<NCT>(acc, pool, d.cp[l], gpt);
 }
 
-__global__ __launch_bounds__(SA_WAVES * 64) void sa_group_mlp_max_kernel(
+// MAXW = widest layer / 32 the variant supports: the 8-tile (256-wide) accumulators cost 128 VGPRs, which caps
+// the occupancy at 2 waves per SIMD; networks up to 128 wide use the lean variant and run 3.
+template <int MAXW>
+__global__ __launch_bounds__(MAXW >= 8 ? 512 : SA_WAVES * 64) void sa_group_mlp_max_kernel(
     SaDesc d, int b, int n, int npoint, int nsample, int c_feat, int c_out,
     const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const float *__restrict__ features, const int *__restrict__ idx, float xyz_scale,
@@ -132,13 +135,13 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_group_mlp_max_kernel(
     float *P = sa_lds;
     const int wave = threadIdx.x >> 6, lane = lane_id();
     const int cp_last = d.cp[d.nlayers - 1];
-    float *act = sa_lds + d.total + wave * (32 * d.act_stride + 4 * cp_last);
+    const int gpt = nsample >= 32 ? 1 : 32 / nsample;  // groups per 32-row tile
+    float *act = sa_lds + d.total + wave * (32 * d.act_stride + gpt * cp_last);
     float *pool = act + 32 * d.act_stride;
     const int nwaves = blockDim.x >> 6;
     for (int i = threadIdx.x; i < d.total; i += blockDim.x) P[i] = params[i];
     __syncthreads();
 
-    const int gpt = nsample >= 32 ? 1 : 32 / nsample;  // groups per 32-row tile
     const int tpg = nsample >= 32 ? nsample / 32 : 1;  // tiles per group
     const long long ngroups = (long long)b * npoint;
     const long long nunits = (ngroups + gpt - 1) / gpt;
@@ -169,12 +172,11 @@ __global__ __launch_bounds__(SA_WAVES * 64) void sa_group_mlp_max_kernel(
                 }
             }
             for (int l = 0; l < d.nlayers; ++l) {
-                switch (d.cp[l] >> 5) {
-                case 1: sa_run_layer<1>(d, l, P, act, pool, gpt); break;
-                case 2: sa_run_layer<2>(d, l, P, act, pool, gpt); break;
-                case 4: sa_run_layer<4>(d, l, P, act, pool, gpt); break;
-                default: sa_run_layer<8>(d, l, P, act, pool, gpt); break;
-                }
+                const int w32 = d.cp[l] >> 5;
+                if (w32 == 1) sa_run_layer<1>(d, l, P, act, pool, gpt);
+                else if (w32 == 2) sa_run_layer<2>(d, l, P, act, pool, gpt);
+                else if (MAXW >= 8 && w32 == 8) sa_run_layer<(MAXW >= 8 ? 8 : 4)>(d, l, P, act, pool, gpt);
+                else sa_run_layer<4>(d, l, P, act, pool, gpt);
             }
         }
         // ---- pooled result -> out[b, col, group]
@@ -233,23 +235,27 @@ GEOT_EXPORT int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int
     }
     d.total = off;
     d.act_stride = maxw + 1;
-    // two waves per SIMD (8 per workgroup) when their activation tiles fit next to the weights: one wave's LDS
-    // round trips and accumulator hand-offs between layers then overlap with the other's MFMA chain
-    int waves = SA_WAVES;
-    size_t lds = ((size_t)d.total + (size_t)waves * (32 * d.act_stride + 4 * d.cp[nlayers - 1])) * sizeof(float);
-    if (lds > 160 * 1024) {
-        waves = 4;
-        lds = ((size_t)d.total + (size_t)waves * (32 * d.act_stride + 4 * d.cp[nlayers - 1])) * sizeof(float);
-    }
+    // As many waves per workgroup (= per CU: the weights + activation tiles fill its LDS) as fit next to the
+    // weights, up to 3 per SIMD: one wave's gather, LDS round trips and accumulator hand-offs between layers
+    // then overlap with the others' MFMA chains.
+    int gpt = nsample >= 32 ? 1 : 32 / nsample;
+    bool wide = false;
+    for (int l = 0; l < nlayers; ++l) wide = wide || d.cp[l] > 128;
+    const size_t per_wave = 32 * (size_t)d.act_stride + (size_t)gpt * d.cp[nlayers - 1];
+    int waves = wide ? 8 : SA_WAVES;
+    while (waves > 4 && ((size_t)d.total + waves * per_wave) * sizeof(float) > 160 * 1024) waves -= 4;
+    const size_t lds = ((size_t)d.total + waves * per_wave) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)sa_group_mlp_max_kernel,
+        hipError_t e = hipFuncSetAttribute((const void *)sa_group_mlp_max_kernel<4>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)sa_group_mlp_max_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    int gpt = nsample >= 32 ? 1 : 32 / nsample;
     long long nunits = ((long long)b * npoint + gpt - 1) / gpt;
     long long blocks = (nunits + waves - 1) / waves;
     // persistent workgroups: one per CU (the weights + activation tiles fill its LDS), each looping over its
@@ -262,8 +268,13 @@ GEOT_EXPORT int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int
         n_cus = cus;
     }
     if (blocks > n_cus) blocks = n_cus;
-    hipLaunchKernelGGL(sa_group_mlp_max_kernel, dim3((unsigned)blocks), dim3(waves * 64), lds,
-                       (hipStream_t)stream, d, b, n, npoint, nsample, c_feat, widths[nlayers - 1], xyz,
-                       new_xyz, features, idx, xyz_scale, params, out);
+    if (wide)
+        hipLaunchKernelGGL(sa_group_mlp_max_kernel<8>, dim3((unsigned)blocks), dim3(waves * 64), lds, (hipStream_t)stream,
+                           d, b, n, npoint, nsample, c_feat, widths[nlayers - 1], xyz, new_xyz, features, idx, xyz_scale,
+                           params, out);
+    else
+        hipLaunchKernelGGL(sa_group_mlp_max_kernel<4>, dim3((unsigned)blocks), dim3(waves * 64), lds, (hipStream_t)stream,
+                           d, b, n, npoint, nsample, c_feat, widths[nlayers - 1], xyz, new_xyz, features, idx, xyz_scale,
+                           params, out);
     return hipGetLastError();
 }

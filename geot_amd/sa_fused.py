@@ -53,7 +53,7 @@ def fused_sa_available(mlp):
     if floats < 0:
         return False
     maxw = max([(3 + c_feat + 1) & ~1] + [_pad_cols(w) for w in widths[:-1]])   # the last layer is pooled from registers
-    lds = 4 * (floats + 4 * (32 * (maxw + 1) + 4 * _pad_cols(widths[-1])))
+    lds = 4 * (floats + 4 * (32 * (maxw + 1) + 4 * _pad_cols(widths[-1])))   # the smallest launch: 4 waves, 4 groups per tile
     return lds <= 160 * 1024
 
 
