@@ -46,6 +46,7 @@ PROTOTYPES.update({
     "geot_three_interpolate_grad_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ball_query_ws": [_c_int, _c_int, _c_int, _c_float, _c_int, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_knnquery_heap_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
+    "geot_knn_sorted_nd": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_knn_sorted_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_three_nn_ws": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_graph_feature": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],

@@ -322,6 +322,73 @@ __global__ __launch_bounds__(KW_WAVES * 64) void knn_wave_kernel(
     }
 }
 
+// ---- sorted kNN in D dimensions (feature space: feature_space_loss searches its neighbours among the
+// 17-dimensional soft-max vectors, utils/insT_loss.py:19) ------------------------------------------------
+// Same wave-cooperative scheme as knn_wave_kernel: 64 lanes = 64 reference points per step, KW_QW queries per
+// wave with their coordinates in registers, best-k list one entry per lane, ties by smaller index.
+// d2 = sum_j (q_j - r_j)^2 accumulated in index order, un-contracted.  D <= KN_DMAX.
+constexpr int KN_DMAX = 32;
+
+template <int DPAD>
+__global__ __launch_bounds__(KW_WAVES * 64) void knn_wave_nd_kernel(
+    int nq, int nr, int d, int k, const float *__restrict__ query, const float *__restrict__ ref,
+    int *__restrict__ idx, float *__restrict__ dist2)
+{
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int bi = blockIdx.y;
+    const int q0 = (blockIdx.x * KW_WAVES + wave) * KW_QW;
+    if (q0 >= nq) return;
+    const float *Q = query + (size_t)bi * nq * d;
+    const float *R = ref + (size_t)bi * nr * d;
+    float qv[KW_QW][DPAD], ld[KW_QW], tau[KW_QW];
+    int li[KW_QW];
+#pragma unroll
+    for (int q = 0; q < KW_QW; ++q) {
+        const int j = min(q0 + q, nq - 1);
+#pragma unroll
+        for (int t = 0; t < DPAD; ++t) qv[q][t] = t < d ? Q[(size_t)j * d + t] : 0.f;
+        ld[q] = INFINITY; li[q] = 0; tau[q] = INFINITY;
+    }
+    for (int c0 = 0; c0 < nr; c0 += 64) {
+        const int r = c0 + lane;
+        const bool in = r < nr;
+        float rv[DPAD];
+#pragma unroll
+        for (int t = 0; t < DPAD; ++t) rv[t] = (in && t < d) ? R[(size_t)r * d + t] : 0.f;
+#pragma unroll
+        for (int q = 0; q < KW_QW; ++q) {
+            float dd = 0.f;
+#pragma unroll
+            for (int t = 0; t < DPAD; ++t) {
+                const float df = qv[q][t] - rv[t]; // padded dimensions contribute exactly 0
+                dd = dd + df * df;
+            }
+            unsigned long long mask = __ballot(in && dd < tau[q]);
+            while (mask) {
+                const int l = __builtin_ctzll(mask);
+                mask &= mask - 1;
+                const float dc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(dd), l));
+                if (!(dc < tau[q])) continue;
+                const int pos = __popcll(__ballot(ld[q] <= dc));
+                const float sd = dpp_wave_shr1(ld[q], ld[q]);
+                const int si = dpp_wave_shr1(li[q], li[q]);
+                ld[q] = lane > pos ? sd : (lane == pos ? dc : ld[q]);
+                li[q] = lane > pos ? si : (lane == pos ? c0 + l : li[q]);
+                tau[q] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(ld[q]), k - 1));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KW_QW; ++q) {
+        const int j = q0 + q;
+        if (j < nq && lane < k) {
+            const size_t o = ((size_t)bi * nq + j) * k + lane;
+            idx[o] = li[q];
+            dist2[o] = ld[q];
+        }
+    }
+}
+
 static inline int grid_cap(long long want, int cap) { return (int)(want < cap ? (want < 1 ? 1 : want) : cap); }
 
 } // namespace geot
@@ -473,5 +540,25 @@ GEOT_EXPORT int geot_knn_sorted(int b, int nq, int nr, int k, const float *query
     size_t lds = (size_t)k * KNN_THREADS * 8;
     hipLaunchKernelGGL(knn_sorted_kernel, dim3((nq + KNN_THREADS - 1) / KNN_THREADS, b),
                        dim3(KNN_THREADS), lds, (hipStream_t)stream, nq, nr, k, query, ref, idx, dist2);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_knn_sorted_nd(int b, int nq, int nr, int d, int k, const float *query, const float *ref,
+                                   int *idx, float *dist2, void *stream)
+{
+    if (b < 0 || nq < 0 || nr < 0 || d < 1 || d > KN_DMAX || k < 1 || k > 64) return hipErrorInvalidValue;
+    if (b == 0 || nq == 0) return hipSuccess;
+    if (b > 65535) return hipErrorInvalidValue;
+    const int per_block = KW_WAVES * KW_QW;
+    const dim3 grid((nq + per_block - 1) / per_block, b);
+    if (d <= 8)
+        hipLaunchKernelGGL(knn_wave_nd_kernel<8>, grid, dim3(KW_WAVES * 64), 0, (hipStream_t)stream, nq, nr, d, k, query, ref,
+                           idx, dist2);
+    else if (d <= 20)
+        hipLaunchKernelGGL(knn_wave_nd_kernel<20>, grid, dim3(KW_WAVES * 64), 0, (hipStream_t)stream, nq, nr, d, k, query,
+                           ref, idx, dist2);
+    else
+        hipLaunchKernelGGL(knn_wave_nd_kernel<32>, grid, dim3(KW_WAVES * 64), 0, (hipStream_t)stream, nq, nr, d, k, query,
+                           ref, idx, dist2);
     return hipGetLastError();
 }

@@ -17,7 +17,18 @@ def _knn(query, support, k):
 
 def _knn_nd(query, support, k, chunk=2048):
     """Feature-space neighbours (D != 3; only feature_space_loss, disabled in the shipped cfg, asks for
-    them): the reference's own cdist + topk, in query chunks so the (M, N) matrix is never whole."""
+    them).  D <= 32, k <= 64: the HIP wave kernel (direct-form distances, ties by index); otherwise the
+    reference's own cdist + topk, in query chunks so the (M, N) matrix is never whole."""
+    d = query.shape[-1]
+    if d <= 32 and k <= 64 and query.is_cuda:
+        from ....ext._common import f32, same_device, call, ptr
+        q, s = f32(query.contiguous().float(), "query", 3), f32(support.contiguous().float(), "support", 3)
+        dev = same_device(q, s)
+        b, nq, nr = q.shape[0], q.shape[1], s.shape[1]
+        idx = torch.empty((b, nq, k), dtype=torch.int32, device=dev)
+        d2 = torch.empty((b, nq, k), dtype=torch.float32, device=dev)
+        call("geot_knn_sorted_nd", dev, b, nq, nr, d, int(k), ptr(q), ptr(s), ptr(idx), ptr(d2))
+        return torch.sqrt(d2), idx
     dist, idx = [], []
     for s in range(0, query.shape[1], chunk):
         top = torch.cdist(query[:, s:s + chunk], support).topk(k=k, dim=-1, largest=False, sorted=True)

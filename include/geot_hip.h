@@ -140,6 +140,11 @@ int geot_three_interpolate_grad(int b, int c, int n, int m, const float *grad_ou
 int geot_knnquery_heap(int b, int m, int nsample, const float *xyz, const float *new_xyz,
                        const int *offset, const int *new_offset, int *idx, float *dist2,
                        void *stream);
+/* Sorted kNN in d <= 32 dimensions (feature_space_loss's neighbours among the 17-dim soft-max vectors,
+ * utils/insT_loss.py:19: knn_point = cdist + topk there): query (b,nq,d), ref (b,nr,d), k <= 64; ascending
+ * (d2, index); d2 accumulated over the dimensions in order, un-contracted. */
+int geot_knn_sorted_nd(int b, int nq, int nr, int d, int k, const float *query, const float *ref, int *idx,
+                       float *dist2, void *stream);
 /* geot_knnquery_heap for uniform batches (every segment n_per support points, m_per queries, as
  * pointops.knn builds them): sorted (nsample+1)-NN from the grid search; queries whose first nsample+1
  * distances are strictly increasing have a unique answer and are copied, the rest (ties, too few

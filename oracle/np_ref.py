@@ -167,6 +167,26 @@ def knn_sorted(query, ref, k):
     return idx, dist2
 
 
+def knn_sorted_nd(query, ref, k):
+    """Sorted kNN in D dimensions, (d2, index) order; d2 accumulated over the dimensions in index order in
+    fp32, one rounding per multiply and per add (the HIP kernel's un-contracted loop)."""
+    query = np.asarray(query, dtype=F32)
+    ref = np.asarray(ref, dtype=F32)
+    b, nq, d = query.shape
+    nr = ref.shape[1]
+    idx = np.zeros((b, nq, k), dtype=np.int32)
+    dist2 = np.full((b, nq, k), np.inf, dtype=F32)
+    for i in range(b):
+        d2 = np.zeros((nq, nr), dtype=F32)
+        for t in range(d):
+            df = (query[i][:, None, t] - ref[i][None, :, t]).astype(F32)
+            d2 = (d2 + (df * df).astype(F32)).astype(F32)
+        o, v = _lex_topk(d2, k)
+        idx[i, :, :min(k, nr)] = o
+        dist2[i, :, :min(k, nr)] = v
+    return idx, dist2
+
+
 def knnquery_heap_literal(nsample, xyz, new_xyz, offset, new_offset):
     """Pure-python transcription of the heap procedure (small inputs only)."""
     xyz = np.asarray(xyz, dtype=F32)

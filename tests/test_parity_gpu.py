@@ -619,3 +619,20 @@ def test_pointops_knn_fast_path_equals_literal_heap(ext, k):
     want_local = widx.view(B, N, k).long() - (torch.arange(B, device=DEV) * N)[:, None, None]
     assert torch.equal(idx, want_local)
     assert torch.equal(dist, torch.sqrt(wd2).view(B, N, k))
+
+
+@pytest.mark.parametrize("d,k", [(17, 8), (5, 3), (32, 33), (20, 64)])
+def test_knn_sorted_nd_matches_numpy_restatement(ext, d, k):
+    """Feature-space kNN (feature_space_loss's neighbours): ids and squared distances bit-exact against the
+    numpy restatement, duplicates (exact ties) included."""
+    from oracle import np_ref
+    from geot_amd.openpoints.models.layers.knn import knn_point
+    rng = np.random.default_rng(d * 100 + k)
+    b, nq, nr = 2, 300, 900
+    ref = rng.random((b, nr, d)).astype(np.float32)
+    ref[:, 500:600] = ref[:, 100:200]                                    # duplicates: ties broken by index
+    qry = np.concatenate([ref[:, :200], rng.random((b, nq - 200, d)).astype(np.float32)], 1)
+    dist, idx = knn_point(k, dev(qry), dev(ref))
+    wi, wd = np_ref.knn_sorted_nd(qry, ref, k)
+    assert idx.dtype == torch.int64 and np.array_equal(host(idx), wi)
+    np.testing.assert_array_equal(host(dist), np.sqrt(wd))
