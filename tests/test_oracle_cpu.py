@@ -249,3 +249,14 @@ def test_channels_last_ops(oracle):
     assert abs(lhs - rhs) < 1e-3 * max(1, abs(lhs))
     g1, g2 = oracle.subtraction_cl_grad(idx, np.ones((n, ns, c), dtype=np.float32))
     assert np.allclose(g1, ns) and np.isclose(g2.sum(), -n * ns * c)
+
+
+def test_nd_knn_restatement_reduces_to_the_3d_one():
+    from oracle import np_ref
+    rng = np.random.default_rng(12)
+    ref = rng.random((2, 400, 3)).astype(np.float32)
+    ref[:, 300:330] = ref[:, 10:40]
+    qry = np.concatenate([ref[:, :50], rng.random((2, 70, 3)).astype(np.float32)], 1)
+    i3, d3 = np_ref.knn_sorted(qry, ref, 9)
+    i_n, d_n = np_ref.knn_sorted_nd(qry, ref, 9)
+    assert np.array_equal(i3, i_n) and np.array_equal(d3, d_n)
