@@ -104,6 +104,20 @@ def gaussian(x, mu, s):
     return (1 / (s * math.sqrt(2 * math.pi))) * torch.exp(-((x - mu) ** 2) / (2 * s ** 2))
 
 
+_TRANSITION_CONSTANTS = {}
+
+
+def _transition_constants(C, dtype, device):
+    """(tooth-adjacency projection of the labels (train.py:48), e_0, 1 - e_0) on `device`, built once."""
+    key = (C, dtype, str(device))
+    if key not in _TRANSITION_CONSTANTS:
+        proj = torch.tensor(LABEL_PROJ[:C], dtype=dtype, device=device)
+        row0 = torch.zeros(C, dtype=dtype, device=device)
+        row0[0] = 1
+        _TRANSITION_CONSTANTS[key] = (proj, row0, 1 - row0)
+    return _TRANSITION_CONSTANTS[key]
+
+
 def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999):
     """The class-level transition estimate of train.py:505-545 + EMA update :556-557.
 
@@ -121,12 +135,8 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999):
     n_star = torch.gather(n_best, 0, b_star.unsqueeze(0)).squeeze(0)      # (C,)
     cols = torch.arange(C, device=eta.device)
     class_T = eta[b_star.unsqueeze(1), cols.unsqueeze(0), n_star.unsqueeze(1)]   # (C, C): row cc = eta[b*, :, n*]
-    proj = torch.tensor(LABEL_PROJ[:C], dtype=eta.dtype, device=eta.device)
+    proj, row0, keep = _transition_constants(C, eta.dtype, eta.device)   # cached: no host->device copy per step
     prior_T = gaussian(proj.unsqueeze(0), proj.unsqueeze(1), sigma.unsqueeze(1))   # [cc][k]
-    row0 = torch.zeros(C, dtype=eta.dtype, device=eta.device)
-    row0[0] = 1
-    keep = torch.ones(C, dtype=eta.dtype, device=eta.device)
-    keep[0] = 0
     prior_T = torch.cat([row0.unsqueeze(0), prior_T[1:] * keep.unsqueeze(0)], dim=0)  # [:,0]=0; [0,0]=1
     prior_T = prior_T / torch.sum(prior_T, 1)
     new_T = geo_lambda * class_T + (1 - geo_lambda) * prior_T
