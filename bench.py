@@ -169,7 +169,7 @@ def main():
         from geot_amd.pointops.functions import pointops as pops
         hot = wl.BackboneHotPath().to(dev)
         tokens = torch.randn(B, wl.TRANS_DIM, wl.GROUPS, device=dev)
-        patch_owner, patch_name = pops, "furthestsampling"
+        patch_owner, patch_name = pops, "furthestsampling_uniform"
         fps_rounds, desc = 8191, ("configs[2] hot-path ops only: PointTransformer_seg_T sampling/grouping/interpolation "
                                   "fwd+bwd (FPS 512+8192, kNN 32/4, three_nn+interpolate x3), dense layers excluded")
 

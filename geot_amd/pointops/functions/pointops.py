@@ -53,10 +53,19 @@ def fps_indices(x, k):
     c = _FPS_CACHE
     if c["x"] is x and c["version"] == x._version and c["idx"] is not None and c["idx"].shape[1] >= k:
         return c["idx"][:, :k]
-    flat = x.reshape(-1, 3)
-    idx = furthestsampling(flat, _uniform_offsets(b, n, x.device), _uniform_offsets(b, k, x.device)).long()
-    idx = idx.view(b, k)
+    idx = furthestsampling_uniform(x.reshape(-1, 3), b, n, k).long().view(b, k)
     c["x"], c["version"], c["idx"] = x, x._version, idx
+    return idx
+
+
+def furthestsampling_uniform(flat, b, n, k):
+    """FurthestSampling for b equal segments of n points, k samples each, without the reference's host
+    round trips: the wrapper reads the segment lengths back from the device offsets (pointops.py:69-72; ours
+    needs one .tolist()), but here they are known on the host.  -> (b*k,) int32 global indices."""
+    off, noff = _uniform_offsets(b, n, flat.device), _uniform_offsets(b, k, flat.device)
+    idx = torch.zeros(b * k, dtype=torch.int32, device=flat.device)
+    tmp = torch.full((b * n,), 1e10, dtype=torch.float32, device=flat.device)
+    pointops_cuda.furthestsampling_cuda(b, n, flat, off, noff, tmp, idx)
     return idx
 
 
