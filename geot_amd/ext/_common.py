@@ -50,11 +50,17 @@ def stream_of(dev):
 
 
 def call(name, dev, *args):
-    """Launch C-ABI entry `name` on torch's current stream of `dev`."""
+    """Launch C-ABI entry `name` on torch's current stream of `dev` (under a device guard when `dev` is not
+    the current device; the composite steps are launch-bound at one cloud, so the common case stays lean)."""
     lib = _lib.load()
-    with torch.cuda.device(dev):
-        err = getattr(lib, name)(*args, stream_of(dev))
-    _lib.check(err, name)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx == torch.cuda.current_device():
+        err = getattr(lib, name)(*args, torch.cuda.current_stream(idx).cuda_stream)
+    else:
+        with torch.cuda.device(idx):
+            err = getattr(lib, name)(*args, torch.cuda.current_stream(idx).cuda_stream)
+    if err:
+        _lib.check(err, name)
 
 
 def ptr(t):
