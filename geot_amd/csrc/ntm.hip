@@ -835,6 +835,87 @@ __global__ __launch_bounds__(256) void tl_overflow_kernel(int cap, float gscale,
     }
 }
 
+// ---- class-level transition block (train.py:505-557 after the anchor rows are known) -----------
+//   P0[r][k] = gauss(proj[k]; mu = proj[r], s = sigma[r]);  A = P0 with row 0 := e_0 and column 0 := 0 below it
+//   B = A / rowsum(A)[k]        (the reference's `X / X.sum(1)`: column k is divided by ROW-sum k)
+//   N = geo*class_T + (1-geo)*B, row 0 := class_T[0];   M = N / rowsum(N)[k]
+//   E = dec*ema_t + (1-dec)*M;  ema_corr = E / rowsum(E)[k];   ema_next = likewise from class_T alone
+// One workgroup, one thread per matrix entry: ~40 tiny torch kernels forward and as many backward become one
+// launch each.  Backward (only sigma is learnable) uses forward-mode derivatives, one sigma component at a
+// time: d/d sigma[c0] touches a single row of P0, the three quirky normalisations carry it everywhere.
+constexpr int CT_MAXC = 32;
+
+__device__ __forceinline__ float ct_rowsum(float v, int r, int k, int C, float *buf)
+{
+    // returns sum_j X[k][j] to thread (r, k): every thread deposits its entry, then reads across row k
+    __syncthreads();
+    buf[r * CT_MAXC + k] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int j = 0; j < C; ++j) s += buf[k * CT_MAXC + j];
+    return s;
+}
+
+template <bool BACKWARD>
+__global__ __launch_bounds__(CT_MAXC * CT_MAXC) void class_transition_kernel(
+    int C, float geo, float dec, const float *__restrict__ class_T, const float *__restrict__ sigma,
+    const float *__restrict__ ema_t, const float *__restrict__ proj, float *__restrict__ ema_corr,
+    float *__restrict__ ema_next, float *__restrict__ prior, float *__restrict__ ema_keep,
+    const float *__restrict__ g_corr, const float *__restrict__ g_prior, float *__restrict__ g_sigma)
+{
+    __shared__ float buf[CT_MAXC * CT_MAXC];
+    __shared__ float red[CT_MAXC * CT_MAXC / 64];
+    const int tid = threadIdx.x, r = tid / CT_MAXC, k = tid % CT_MAXC;
+    const bool in = r < C && k < C;
+    const float cT = in ? class_T[r * C + k] : 0.f, eT = in ? ema_t[r * C + k] : 0.f;
+    const float sg = in ? sigma[r] : 1.f, delta = in ? proj[k] - proj[r] : 0.f;
+    const float P0 = in ? (1.f / (sg * 2.5066282746310002f)) * expf(-(delta * delta) / (2.f * sg * sg)) : 0.f;
+    const float A = !in ? 0.f : (r == 0 ? (k == 0 ? 1.f : 0.f) : (k == 0 ? 0.f : P0));
+    const float RA = ct_rowsum(A, r, k, C, buf);
+    const float Bv = in ? A / RA : 0.f;
+    const float N = !in ? 0.f : (r == 0 ? cT : geo * cT + (1.f - geo) * Bv);
+    const float SN = ct_rowsum(N, r, k, C, buf);
+    const float M = in ? N / SN : 0.f;
+    const float E = in ? dec * eT + (1.f - dec) * M : 0.f;
+    const float UE = ct_rowsum(E, r, k, C, buf);
+    if (!BACKWARD) {
+        const float X = in ? dec * eT + (1.f - dec) * cT : 0.f;
+        const float UX = ct_rowsum(X, r, k, C, buf);
+        if (in) {
+            ema_corr[r * C + k] = E / UE;
+            ema_next[r * C + k] = X / UX;
+            prior[r * C + k] = Bv;
+            if (ema_keep) ema_keep[r * C + k] = eT;
+        }
+        return;
+    }
+    const float gc = (in && g_corr) ? g_corr[r * C + k] : 0.f, gp = (in && g_prior) ? g_prior[r * C + k] : 0.f;
+    for (int c0 = 0; c0 < C; ++c0) {
+        // derivative fields w.r.t. sigma[c0]
+        const float dP0 = (in && r == c0) ? P0 * (-1.f / sg + delta * delta / (sg * sg * sg)) : 0.f;
+        const float dA = (r >= 1 && k >= 1) ? dP0 : 0.f;
+        const float dRA = ct_rowsum(dA, r, k, C, buf);
+        const float dB = in ? dA / RA - A * dRA / (RA * RA) : 0.f;
+        const float dN = (in && r >= 1) ? (1.f - geo) * dB : 0.f;
+        const float dSN = ct_rowsum(dN, r, k, C, buf);
+        const float dM = in ? dN / SN - N * dSN / (SN * SN) : 0.f;
+        const float dE = (1.f - dec) * dM;
+        const float dUE = ct_rowsum(dE, r, k, C, buf);
+        const float dF = in ? dE / UE - E * dUE / (UE * UE) : 0.f;
+        float contrib = gc * dF + gp * dB;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = contrib;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < CT_MAXC * CT_MAXC / 64; ++w) t += red[w];
+            g_sigma[c0] += t;
+        }
+    }
+}
+
 // out[e] += sum over blocks of partial[blk][e]; grid.y slices the blocks 32 at a time
 __global__ __launch_bounds__(256) void ntm_partial_reduce_kernel(int nblk, int len, const float *__restrict__ partial,
                                                                  float *__restrict__ out)
@@ -954,6 +1035,29 @@ GEOT_EXPORT int geot_ntm_correct_grad(int b, int n, int c, float lam, const floa
     hipLaunchKernelGGL((ntm_correct_kernel<C, true>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
                        (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, grad_out, nullptr,
                        grad_logits, grad_ins_T, grad_ema_t, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_class_transition(int c, float geo_lambda, float ema_decay, const float *class_T,
+                                          const float *sigma, const float *ema_t, const float *proj, float *ema_t_corr,
+                                          float *ema_t_next, float *prior_T, float *ema_t_keep, void *stream)
+{
+    if (c < 1 || c > CT_MAXC) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((class_transition_kernel<false>), dim3(1), dim3(CT_MAXC * CT_MAXC), 0, (hipStream_t)stream, c,
+                       geo_lambda, ema_decay, class_T, sigma, ema_t, proj, ema_t_corr, ema_t_next, prior_T, ema_t_keep,
+                       nullptr, nullptr, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_class_transition_grad(int c, float geo_lambda, float ema_decay, const float *class_T,
+                                               const float *sigma, const float *ema_t, const float *proj,
+                                               const float *grad_ema_t_corr, const float *grad_prior_T,
+                                               float *grad_sigma, void *stream)
+{
+    if (c < 1 || c > CT_MAXC || !grad_sigma) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((class_transition_kernel<true>), dim3(1), dim3(CT_MAXC * CT_MAXC), 0, (hipStream_t)stream, c,
+                       geo_lambda, ema_decay, class_T, sigma, ema_t, proj, nullptr, nullptr, nullptr, nullptr,
+                       grad_ema_t_corr, grad_prior_T, grad_sigma);
     return hipGetLastError();
 }
 

@@ -104,6 +104,37 @@ def gaussian(x, mu, s):
     return (1 / (s * math.sqrt(2 * math.pi))) * torch.exp(-((x - mu) ** 2) / (2 * s ** 2))
 
 
+class _ClassTransitionFn(Function):
+    """The 17 x 17 arithmetic of the class-transition block in one launch (and one for d/d sigma) instead of
+    ~40 tiny torch kernels each way; the op-by-op torch version below stays as the reference (GEOT_NTM_CT=torch)."""
+
+    @staticmethod
+    def forward(ctx, class_T, sigma, ema_t, proj, geo_lambda, ema_decay):
+        class_T, ema_t = f32(class_T.contiguous(), "class_T", 2), f32(ema_t.contiguous(), "ema_t", 2)
+        sigma_c, proj = f32(sigma.detach().contiguous(), "sigma", 1), f32(proj.contiguous(), "proj", 1)
+        dev = same_device(class_T, sigma_c, ema_t, proj)
+        c = class_T.shape[0]
+        corr, nxt, prior, keep = torch.empty((4, c, c), dtype=torch.float32, device=dev).unbind(0)
+        call("geot_ntm_class_transition", dev, c, geo_lambda, ema_decay, ptr(class_T), ptr(sigma_c), ptr(ema_t), ptr(proj),
+             ptr(corr), ptr(nxt), ptr(prior), ptr(keep))
+        # `keep` = ema_t as it was: a loop holding ema_t in one buffer overwrites it (train.py:556-557) before backward
+        ctx.save_for_backward(class_T, sigma_c, keep, proj)
+        ctx.consts = (geo_lambda, ema_decay)
+        ctx.mark_non_differentiable(nxt)
+        return corr, nxt, prior
+
+    @staticmethod
+    def backward(ctx, g_corr, g_next, g_prior):
+        class_T, sigma_c, ema_t, proj = ctx.saved_tensors
+        geo_lambda, ema_decay = ctx.consts
+        gs = torch.zeros_like(sigma_c)
+        gc = g_corr.contiguous() if g_corr is not None else None
+        gp = g_prior.contiguous() if g_prior is not None else None
+        call("geot_ntm_class_transition_grad", class_T.device, class_T.shape[0], geo_lambda, ema_decay, ptr(class_T),
+             ptr(sigma_c), ptr(ema_t), ptr(proj), ptr(gc), ptr(gp), ptr(gs))
+        return None, gs, None, None, None, None
+
+
 _TRANSITION_CONSTANTS = {}
 
 
@@ -136,6 +167,10 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999):
     cols = torch.arange(C, device=eta.device)
     class_T = eta[b_star.unsqueeze(1), cols.unsqueeze(0), n_star.unsqueeze(1)]   # (C, C): row cc = eta[b*, :, n*]
     proj, row0, keep = _transition_constants(C, eta.dtype, eta.device)   # cached: no host->device copy per step
+    if eta.is_cuda and C <= 32 and eta.dtype == torch.float32 and os.environ.get("GEOT_NTM_CT", "fused") == "fused":
+        ema_t_corr, ema_next, prior_T = _ClassTransitionFn.apply(class_T.contiguous(), sigma, ema_t, proj,
+                                                                 float(geo_lambda), float(ema_decay))
+        return ema_t_corr, ema_next, class_T, prior_T
     prior_T = gaussian(proj.unsqueeze(0), proj.unsqueeze(1), sigma.unsqueeze(1))   # [cc][k]
     prior_T = torch.cat([row0.unsqueeze(0), prior_T[1:] * keep.unsqueeze(0)], dim=0)  # [:,0]=0; [0,0]=1
     prior_T = prior_T / torch.sum(prior_T, 1)

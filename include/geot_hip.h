@@ -230,6 +230,19 @@ int geot_ntm_correct(int b, int n, int c, float lam, const float *logits, const 
 int geot_ntm_correct_grad(int b, int n, int c, float lam, const float *logits, const float *ins_T,
                           const float *ema_t, const float *grad_out, float *grad_logits,
                           float *grad_ins_T, float *grad_ema_t, void *stream);
+/* Class-level transition block, train.py:505-557 once the anchor rows class_T (c,c) are gathered: Gaussian
+ * tooth-adjacency prior from sigma (c) over the label projection proj (c) (train.py:48), blend, the three
+ * `X / X.sum(1)` normalisations exactly as written there (column k divided by row-sum k), EMA.  c <= 32.
+ * Writes ema_t_corr, ema_t_next, prior_T (c,c) and, when ema_t_keep is not NULL, a copy of ema_t there (a caller
+ * that keeps ema_t in one persistent buffer overwrites it with ema_t_next, train.py:556-557, before backward).  _grad accumulates d/d sigma (c) given d/d ema_t_corr and
+ * d/d prior_T (either may be NULL); sigma is the only learnable input. */
+int geot_ntm_class_transition(int c, float geo_lambda, float ema_decay, const float *class_T, const float *sigma,
+                              const float *ema_t, const float *proj, float *ema_t_corr, float *ema_t_next,
+                              float *prior_T, float *ema_t_keep, void *stream);
+int geot_ntm_class_transition_grad(int c, float geo_lambda, float ema_decay, const float *class_T,
+                                   const float *sigma, const float *ema_t, const float *proj,
+                                   const float *grad_ema_t_corr, const float *grad_prior_T, float *grad_sigma,
+                                   void *stream);
 /* _grad_ws: as _grad, with grad_ema_t reduced through geot_ntm_correct_ws_floats(b, n) floats of scratch. */
 long long geot_ntm_correct_ws_floats(int b, int n);
 int geot_ntm_correct_grad_ws(int b, int n, int c, float lam, const float *logits, const float *ins_T,

@@ -73,6 +73,33 @@ def test_class_transition_matches_oracle():
     assert torch.isfinite(sg.grad).all() and sg.grad.abs().sum() > 0
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_class_transition_fused_kernel(seed, monkeypatch):
+    """fp32 single-launch kernel (+ its d/d sigma) against the oracle and against fp64 torch autograd of the
+    op-by-op version; both upstream gradients (ema_t_corr and prior_T) random."""
+    from geot_amd.ntm import class_transition
+    rng = np.random.default_rng(seed)
+    eta = _softmax(rng.standard_normal((2, C, 2000)) * 3, 1)
+    sigma = 0.3 + 1.5 * rng.random(C)
+    ema = _softmax(rng.standard_normal((C, C)), 1)
+    gc, gp = rng.standard_normal((C, C)), rng.standard_normal((C, C))
+    r = np_ntm.class_transition(eta.astype(np.float32).astype(np.float64), sigma, ema)
+    s32 = T(sigma).requires_grad_(True)
+    corr, nxt, cT, pT = class_transition(T(eta), s32, T(ema))
+    assert corr.dtype == torch.float32 and corr.grad_fn is not None and "ClassTransition" in type(corr.grad_fn).__name__
+    np.testing.assert_allclose(pT.detach().cpu().numpy(), r["prior_T"], rtol=2e-5, atol=1e-30)
+    np.testing.assert_allclose(corr.detach().cpu().numpy(), r["ema_t_corr"], rtol=2e-5)
+    np.testing.assert_allclose(nxt.cpu().numpy(), r["ema_t_next"], rtol=2e-5)
+    assert not nxt.requires_grad
+    ((corr * T(gc)).sum() + (pT * T(gp)).sum()).backward()
+    monkeypatch.setenv("GEOT_NTM_CT", "torch")
+    s64 = T(sigma, torch.float64).requires_grad_(True)
+    corr64, _, _, pT64 = class_transition(T(eta).double(), s64, T(ema, torch.float64))
+    ((corr64 * T(gc, torch.float64)).sum() + (pT64 * T(gp, torch.float64)).sum()).backward()
+    want = s64.grad.cpu().numpy()
+    np.testing.assert_allclose(s32.grad.cpu().numpy(), want, rtol=2e-4, atol=2e-5 * np.abs(want).max())
+
+
 @pytest.mark.parametrize("B,N", [(1, 70), (2, 1000)])
 def test_correct_logits_forward_backward(B, N):
     from geot_amd.ntm import correct_logits
