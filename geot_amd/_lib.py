@@ -68,6 +68,9 @@ PROTOTYPES.update({
                                        ctypes.c_longlong, _c_void_p],
     "geot_ntm_threed_loss_grad_graph": [_c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, ctypes.c_longlong,
                                         _P, _c_void_p],
+    "geot_grid_subsampling": [_c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
+    "geot_pc_norm_stats": [_c_int, _P, _P, _P, ctypes.c_longlong, _c_void_p],
+    "geot_cloud_sample": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_spatial_order": [_c_int, _c_int, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_ntm_feature_loss": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_feature_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P,
@@ -83,6 +86,8 @@ PLAIN = {
     "geot_ntm_threed_loss_ws_bytes": ([_c_int, _c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_correct_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_threed_graph_bytes": ([_c_int, _c_int, _c_int], ctypes.c_longlong),
+    "geot_grid_subsampling_ws_bytes": ([_c_int], ctypes.c_longlong),
+    "geot_pc_norm_ws_bytes": ([], ctypes.c_longlong),
     "geot_knn_grid_eligible": ([_c_int, _c_int, _c_int, _c_int], _c_int),
     "geot_ball_grid_eligible": ([_c_int, _c_int, _c_int, _c_float, _c_int], _c_int),
 }

@@ -301,6 +301,31 @@ int geot_ntm_feature_loss_grad(int b, int n, int c, int k, int feat_dim, float s
                                const float *feats, const int *labels, const float *ins_T, const int *nbr,
                                float *grad_ins_T, void *stream);
 
+/* ---- dataloader-side ops ---------------------------------------------------------------
+ * geot_grid_subsampling replaces cpp_subsampling.compute (openpoints/cpp/subsampling/wrapper.cpp:58-285 ->
+ * grid_subsampling/grid_subsampling.cpp:4-106): voxel size sample_dl, points (n,3), optional features
+ * (n,fdim) and integer labels (n,ldim).  Outputs have room for n rows; *out_count (device int) receives the
+ * number of voxels M; rows 0..M-1 are the voxel barycentres (fp32 sums in input order, bit-identical to the
+ * reference), mean features and majority labels, by ascending voxel key (the reference emits the same rows in
+ * its hash map's iteration order; on a label tie it takes the first maximum in that order, here the smallest
+ * tied label).  ws: geot_grid_subsampling_ws_bytes(n) bytes of device scratch (sized for the current device:
+ * -1 when the process has no GPU). */
+long long geot_grid_subsampling_ws_bytes(int n);
+int geot_grid_subsampling(int n, int fdim, int ldim, float sample_dl, const float *points, const float *features,
+                          const int *labels, float *out_points, float *out_features, int *out_labels,
+                          int *out_count, void *ws, long long ws_bytes, void *stream);
+/* pc_norm of openpoints/dataset/tooth_semi/tooth_dataset.py:108-114: stats (4 floats, device) = centroid xyz
+ * and scale = max row norm of the centred cloud.  ws: geot_pc_norm_ws_bytes() bytes. */
+long long geot_pc_norm_ws_bytes(void);
+int geot_pc_norm_stats(int n, const float *points, float *stats, void *ws, long long ws_bytes, void *stream);
+/* tooth_dataset.py:132-147: out_points[i] = (points[selected[i]] - centroid) / scale (m,3); with labels (n)
+ * also out_labels (m) int64 and class_weights (num_classes) = histogram of the gathered labels / m (inf -> 0).
+ * selected NULL = identity (m == n).  hist_ws: num_classes + 1 ints; the last one is set non-zero when an
+ * entry of selected was out of range (numpy raises IndexError there; the row is then read from point 0). */
+int geot_cloud_sample(int n, int m, int num_classes, const float *points, const int *labels,
+                      const long long *selected, const float *stats, float *out_points, long long *out_labels,
+                      float *class_weights, int *hist_ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
