@@ -149,8 +149,30 @@ def _transition_constants(C, dtype, device):
     return _TRANSITION_CONSTANTS[key]
 
 
-def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999):
+def exchange_anchor_rows(v_star, class_T, group):
+    """The one real exchange step of the NTM block when the unlabelled batch is sharded over ranks
+    (SURVEY.md section 8e): each rank holds, per class, its most confident point's probability v_star (C,)
+    and that point's softmax row class_T (C, C); the global anchor of a class is the row of the rank with the
+    largest v_star, the LOWEST rank among equals -- clouds are sharded contiguously by rank, so that is the
+    first maximum over the flattened (b, n) order of the whole batch, what a single process computes
+    (train.py:519-526).  One all-gather of C * (C + 1) floats (1.2 KB at 17 classes) over RCCL / gloo."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    pack = torch.cat([v_star.unsqueeze(1), class_T], dim=1).contiguous()
+    parts = [torch.empty_like(pack) for _ in range(world)]
+    dist.all_gather(parts, pack, group=group)
+    parts = torch.stack(parts)                                            # (W, C, 1 + C)
+    r_star = torch.argmax(parts[:, :, 0], dim=0)                          # first (= lowest) rank with the maximum
+    cols = torch.arange(class_T.shape[0], device=class_T.device)
+    return parts[r_star, cols, 1:]
+
+
+def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group=None):
     """The class-level transition estimate of train.py:505-545 + EMA update :556-557.
+
+    `group`: a torch.distributed process group (e.g. dist.group.WORLD) over which the unlabelled batch is
+    sharded -- the anchor rows are then the whole batch's (exchange_anchor_rows) and every rank gets the same
+    ema_t; None (default) keeps them per rank, which is what the reference does under DDP.
 
     eta (B_u, C, N): softmax of the weak view (detached), sigma (C,): learnable widths returned by
     the segmentor, ema_t (C, C).  Returns (ema_t_corr, ema_t_next, class_T, prior_T).
@@ -166,6 +188,10 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999):
     n_star = torch.gather(n_best, 0, b_star.unsqueeze(0)).squeeze(0)      # (C,)
     cols = torch.arange(C, device=eta.device)
     class_T = eta[b_star.unsqueeze(1), cols.unsqueeze(0), n_star.unsqueeze(1)]   # (C, C): row cc = eta[b*, :, n*]
+    if group is not None:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            class_T = exchange_anchor_rows(torch.gather(v_best, 0, b_star.unsqueeze(0)).squeeze(0), class_T, group)
     proj, row0, keep = _transition_constants(C, eta.dtype, eta.device)   # cached: no host->device copy per step
     if eta.is_cuda and C <= 32 and eta.dtype == torch.float32 and os.environ.get("GEOT_NTM_CT", "fused") == "fused":
         ema_t_corr, ema_next, prior_T = _ClassTransitionFn.apply(class_T.contiguous(), sigma, ema_t, proj,

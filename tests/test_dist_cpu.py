@@ -1,5 +1,8 @@
-"""world_size-2 gloo test of the multi-GPU plumbing: clouds are sharded by
-rank with no data-path collective; only the barrier and the MAX-over-ranks timing communicate."""
+"""world_size-2 gloo tests of the multi-GPU plumbing: clouds are sharded by
+rank with no data-path collective; only the barrier and the MAX-over-ranks timing communicate.  The NTM
+block's one optional exchange -- the per-class anchor rows, so that class_T / ema_t match what a single
+process computes on the whole batch -- is an all-gather of 17 x 18 floats, checked here against the
+single-process result."""
 import os
 import socket
 
@@ -59,3 +62,63 @@ def test_two_rank_sharding_and_timing():
     for r, (lo, hi) in enumerate([(0, 2), (2, 4)]):
         xyz, _ = make_batch(hi - lo, 512, start_index=lo)
         assert float(capi.fps_dense(xyz, 64, 512, True).astype(np.int64).sum()) == g0[r]
+
+
+def _anchor_batch():
+    rng = np.random.default_rng(5)
+    logits = rng.standard_normal((4, 17, 300))
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    eta = e / e.sum(1, keepdims=True)
+    # exact ties across ranks: class 3's best probability appears in cloud 1 (rank 0) and cloud 2 (rank 1),
+    # class 5's in clouds 2 and 3 (both rank 1) -- the first in flattened (b, n) order must win
+    for cls, (b1, n1), (b2, n2) in ((3, (1, 250), (2, 10)), (5, (2, 200), (3, 7))):
+        row = np.full(17, 0.001)
+        row[cls] = 1 - 0.016
+        eta[b1, :, n1] = row
+        row2 = np.roll(row, 0).copy()
+        row2[(cls + 1) % 17], row2[(cls + 2) % 17] = 0.0015, 0.0005     # same maximum, different row
+        eta[b2, :, n2] = row2
+    sigma = 0.5 + rng.random(17)
+    ema = rng.random((17, 17)) + 0.1
+    return eta, sigma, ema / ema.sum(1, keepdims=True)
+
+
+def _anchor_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    from geot_amd import dist_utils
+    from geot_amd.ntm import class_transition
+    dist_utils.init("gloo")
+    eta, sigma, ema = _anchor_batch()
+    lo, hi = dist_utils.cloud_range(rank, 2)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    corr, nxt, cT, _ = class_transition(T(eta[lo:hi]), T(sigma), T(ema), group=dist.group.WORLD)
+    local = class_transition(T(eta[lo:hi]), T(sigma), T(ema))[2]
+    q.put((rank, corr.numpy(), nxt.numpy(), cT.numpy(), local.numpy()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_anchor_rows_match_single_process():
+    from geot_amd.ntm import class_transition
+    from oracle import np_ntm
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_anchor_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    eta, sigma, ema = _anchor_batch()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    corr, nxt, cT, _ = class_transition(T(eta), T(sigma), T(ema))
+    want = np_ntm.class_transition(eta, sigma, ema)
+    assert np.array_equal(cT.numpy(), want["class_T"])
+    for rank, r_corr, r_nxt, r_cT, r_local in res:
+        assert np.array_equal(r_cT, cT.numpy()), "rank %d anchors differ from the single-process ones" % rank
+        np.testing.assert_allclose(r_corr, corr.numpy(), rtol=1e-14)
+        np.testing.assert_allclose(r_nxt, nxt.numpy(), rtol=1e-14)
+    assert not np.array_equal(res[0][4], res[1][4])          # per-rank anchors do differ without the exchange
+    assert np.array_equal(cT.numpy()[3], eta[1, :, 250]) and np.array_equal(cT.numpy()[5], eta[2, :, 200])
