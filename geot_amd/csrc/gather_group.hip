@@ -82,7 +82,7 @@ __global__ __launch_bounds__(GG_THREADS) void group_points_grad_kernel(
 // Evaluation order follows the reference expression p0*w0 + p1*w1 + p2*w2.
 __global__ __launch_bounds__(GG_THREADS) void three_interpolate_kernel(
     int c, int m, int n, const float *__restrict__ points, const int *__restrict__ idx,
-    const float *__restrict__ weight, float *__restrict__ out)
+    const float *__restrict__ weight, float *__restrict__ out, size_t out_bstride)
 {
     const int bi = blockIdx.z, c0 = blockIdx.y * GG_CCHUNK;
     const int j = blockIdx.x * GG_THREADS + threadIdx.x;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(GG_THREADS) void three_interpolate_kernel(
     const int cend = min(c0 + GG_CCHUNK, c);
     for (int l = c0; l < cend; ++l) {
         const float *P = points + ((size_t)bi * c + l) * m;
-        out[((size_t)bi * c + l) * n + j] = P[i0] * w0 + P[i1] * w1 + P[i2] * w2;
+        out[(size_t)bi * out_bstride + (size_t)l * n + j] = P[i0] * w0 + P[i1] * w1 + P[i2] * w2;
     }
 }
 
@@ -422,7 +422,7 @@ __device__ __forceinline__ void tlds_load_rows(float *__restrict__ dst, const fl
 template <int NT, bool WEIGHTED>
 __global__ __launch_bounds__(TLDS_THREADS) void table_gather_lds_kernel(
     int c, int m, int L, int ch, const float *__restrict__ table, const int *__restrict__ idx,
-    const float *__restrict__ weight, float *__restrict__ out)
+    const float *__restrict__ weight, float *__restrict__ out, size_t out_bstride)
 {
     extern __shared__ float tlds_rows[]; // [ch][m]
     const int bi = blockIdx.z, c0 = blockIdx.y * ch, nch = min(ch, c - c0);
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_lds_kernel(
                 } else {
                     v = R[ii[u][0]];
                 }
-                if (e < e1) out[((size_t)bi * c + c0 + l) * L + e] = v;
+                if (e < e1) out[(size_t)bi * out_bstride + (size_t)(c0 + l) * L + e] = v;
             }
         }
     }
@@ -502,12 +502,13 @@ static hipError_t tlds_set_lds(K kernel, size_t lds)
 
 template <int NT, bool WEIGHTED>
 static hipError_t tlds_gather(const TldsPlan &p, int b, int c, int m, int L, const float *table, const int *idx,
-                              const float *weight, float *out, hipStream_t s)
+                              const float *weight, float *out, hipStream_t s, size_t out_bstride = 0)
 {
     hipError_t e = tlds_set_lds(table_gather_lds_kernel<NT, WEIGHTED>, p.lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((table_gather_lds_kernel<NT, WEIGHTED>), dim3(p.slices, (c + p.ch - 1) / p.ch, b),
-                       dim3(TLDS_THREADS), p.lds, s, c, m, L, p.ch, table, idx, weight, out);
+                       dim3(TLDS_THREADS), p.lds, s, c, m, L, p.ch, table, idx, weight, out,
+                       out_bstride ? out_bstride : (size_t)c * L);
     return hipGetLastError();
 }
 // ---- gradients of the gathers as gathers: reverse index + source rows in LDS --------------------
@@ -768,16 +769,57 @@ GEOT_EXPORT int geot_group_points_grad(int b, int c, int n, int npoints, int nsa
     return hipGetLastError();
 }
 
-GEOT_EXPORT int geot_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
-                                       const float *weight, float *out, void *stream)
+static int three_interpolate_launch(int b, int c, int m, int n, const float *points, const int *idx, const float *weight,
+                                    float *out, size_t out_bstride, hipStream_t s)
 {
-    if (b < 0 || c < 0 || n < 0 || m < 0) return hipErrorInvalidValue;
+    if (b < 0 || c < 0 || n < 0 || m < 0 || out_bstride < (size_t)c * n) return hipErrorInvalidValue;
     if (b == 0 || c == 0 || n == 0) return hipSuccess;
     GEOT_CHECK_DIMS3(b, c);
     const TldsPlan tp = tlds_plan(b, c, m, n, 1);
-    if (tp.ch) return tlds_gather<3, true>(tp, b, c, m, n, points, idx, weight, out, (hipStream_t)stream);
-    hipLaunchKernelGGL(three_interpolate_kernel, grid3(n, c, b), dim3(GG_THREADS), 0,
-                       (hipStream_t)stream, c, m, n, points, idx, weight, out);
+    if (tp.ch) return tlds_gather<3, true>(tp, b, c, m, n, points, idx, weight, out, s, out_bstride);
+    hipLaunchKernelGGL(three_interpolate_kernel, grid3(n, c, b), dim3(GG_THREADS), 0, s, c, m, n, points, idx, weight, out,
+                       out_bstride);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                                       const float *weight, float *out, void *stream)
+{
+    return three_interpolate_launch(b, c, m, n, points, idx, weight, out, (size_t)(c > 0 ? c : 0) * (n > 0 ? n : 0),
+                                    (hipStream_t)stream);
+}
+
+// FP-module front end without the concat copy: `out` is the first c channels of a wider (B, c + c_skip, n)
+// buffer, out_bstride = (c + c_skip) * n floats between batches
+GEOT_EXPORT int geot_three_interpolate_into(int b, int c, int m, int n, const float *points, const int *idx,
+                                            const float *weight, float *out, long long out_bstride, void *stream)
+{
+    if (out_bstride < 0) return hipErrorInvalidValue;
+    return three_interpolate_launch(b, c, m, n, points, idx, weight, out, (size_t)out_bstride, (hipStream_t)stream);
+}
+
+// weight[b,j,t] = r_t / ((r_0 + r_1) + r_2), r_t = 1 / (sqrt(dist2[b,j,t]) + 1e-8): pointnet2_modules.py:621-623
+// on three_nn's squared distances, one kernel instead of sqrt / add / reciprocal / sum / div
+__global__ __launch_bounds__(256) void fp_weights_kernel(long long rows, const float *__restrict__ dist2,
+                                                         float *__restrict__ weight)
+{
+    const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (j >= rows) return;
+    const float r0 = 1.0f / (sqrtf(dist2[3 * j]) + 1e-8f), r1 = 1.0f / (sqrtf(dist2[3 * j + 1]) + 1e-8f),
+                r2 = 1.0f / (sqrtf(dist2[3 * j + 2]) + 1e-8f);
+    const float norm = (r0 + r1) + r2;
+    weight[3 * j] = r0 / norm;
+    weight[3 * j + 1] = r1 / norm;
+    weight[3 * j + 2] = r2 / norm;
+}
+
+GEOT_EXPORT int geot_fp_weights(int b, int n, const float *dist2, float *weight, void *stream)
+{
+    if (b < 0 || n < 0) return hipErrorInvalidValue;
+    const long long rows = (long long)b * n;
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(fp_weights_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, dist2,
+                       weight);
     return hipGetLastError();
 }
 
@@ -801,25 +843,42 @@ GEOT_EXPORT int geot_grad_ws_needs_zero(int b, int c, int m, long long L, int nt
     return csr_applies(b, c, m, L, nt, (long long)b * m * c) ? 0 : 1;
 }
 
+static int three_interpolate_grad_launch(int b, int c, int n, int m, const float *grad_out, size_t grad_bstride,
+                                         const int *idx, const float *weight, float *grad_points, float *workspace,
+                                         hipStream_t s)
+{
+    if (b < 0 || c < 0 || n < 0 || m < 0 || !workspace || grad_bstride < (size_t)c * n) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || n == 0 || m == 0) return hipSuccess;
+    if (b > 65535) return hipErrorInvalidValue;
+    {
+        hipError_t e = scatter_via_csr<3, true>(b, c, m, n, grad_bstride, grad_out, idx, weight, grad_points, workspace,
+                                                (long long)b * m * c, s);
+        if (e != hipErrorNotSupported) return e;
+    }
+    dim3 g1((n + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
+    hipLaunchKernelGGL((scatter_rows_cl_kernel<3, true>), g1, dim3(256), 0, s, c, n, m, grad_out, grad_bstride, idx, weight,
+                       workspace);
+    dim3 g2((m + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
+    hipLaunchKernelGGL(transpose_add_kernel, g2, dim3(256), 0, s, c, m, workspace, grad_points);
+    return hipGetLastError();
+}
+
 GEOT_EXPORT int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out,
                                                const int *idx, const float *weight, float *grad_points,
                                                float *workspace, void *stream)
 {
-    if (b < 0 || c < 0 || n < 0 || m < 0 || !workspace) return hipErrorInvalidValue;
-    if (b == 0 || c == 0 || n == 0 || m == 0) return hipSuccess;
-    if (b > 65535) return hipErrorInvalidValue;
-    {
-        hipError_t e = scatter_via_csr<3, true>(b, c, m, n, (size_t)c * n, grad_out, idx, weight, grad_points, workspace,
-                                                (long long)b * m * c, (hipStream_t)stream);
-        if (e != hipErrorNotSupported) return e;
-    }
-    dim3 g1((n + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
-    hipLaunchKernelGGL((scatter_rows_cl_kernel<3, true>), g1, dim3(256), 0, (hipStream_t)stream, c, n, m,
-                       grad_out, (size_t)c * n, idx, weight, workspace);
-    dim3 g2((m + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
-    hipLaunchKernelGGL(transpose_add_kernel, g2, dim3(256), 0, (hipStream_t)stream, c, m, workspace,
-                       grad_points);
-    return hipGetLastError();
+    return three_interpolate_grad_launch(b, c, n, m, grad_out, (size_t)(c > 0 ? c : 0) * (n > 0 ? n : 0), idx, weight,
+                                         grad_points, workspace, (hipStream_t)stream);
+}
+
+// as _grad_ws with grad_out being the first c channels of a wider (B, c + c_skip, n) gradient
+GEOT_EXPORT int geot_three_interpolate_grad_from(int b, int c, int n, int m, const float *grad_out,
+                                                 long long grad_bstride, const int *idx, const float *weight,
+                                                 float *grad_points, float *workspace, void *stream)
+{
+    if (grad_bstride < 0) return hipErrorInvalidValue;
+    return three_interpolate_grad_launch(b, c, n, m, grad_out, (size_t)grad_bstride, idx, weight, grad_points, workspace,
+                                         (hipStream_t)stream);
 }
 
 GEOT_EXPORT int geot_group_points_grad_ws(int b, int c, int n, int npoints, int nsample,

@@ -11,13 +11,20 @@ import torch
 from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace
 
 
+def _fresh(shape, dtype, dev, source_len):
+    """Output buffer of a forward op whose kernel writes every element: no zero-fill pass (the reference's
+    torch.zeros costs a full extra write of, e.g., the 295 MB level-0 interpolation at 8 clouds).  An empty
+    source (nothing to read from) keeps the zeros the reference would return."""
+    return (torch.empty if source_len > 0 else torch.zeros)(shape, dtype=dtype, device=dev)
+
+
 def gather_points(points, idx):
     f32(points, "points", 3); i32(idx, "idx", 2)
     dev = same_device(points, idx)
     b, c, n = points.shape
     need(idx.shape[0] == b, "idx batch mismatch")
     m = idx.shape[1]
-    out = torch.zeros((b, c, m), dtype=torch.float32, device=dev)
+    out = _fresh((b, c, m), torch.float32, dev, n)
     call("geot_gather_points", dev, b, c, n, m, ptr(points), ptr(idx), ptr(out))
     return out
 
@@ -50,8 +57,8 @@ def three_nn(unknowns, knows):
     b, n, _ = unknowns.shape
     need(knows.shape[0] == b and unknowns.shape[2] == 3 and knows.shape[2] == 3, "three_nn shape mismatch")
     m = knows.shape[1]
-    idx = torch.zeros((b, n, 3), dtype=torch.int32, device=dev)
-    dist2 = torch.zeros((b, n, 3), dtype=torch.float32, device=dev)
+    idx = _fresh((b, n, 3), torch.int32, dev, m)
+    dist2 = _fresh((b, n, 3), torch.float32, dev, m)
     wp, wb, _keep = knn_workspace(dev, b, n, m, 3)
     call("geot_three_nn_ws", dev, b, n, m, ptr(unknowns), ptr(knows), ptr(dist2), ptr(idx), wp, wb)
     return [dist2, idx]
@@ -63,7 +70,7 @@ def three_interpolate(points, idx, weight):
     b, c, m = points.shape
     n = idx.shape[1]
     need(tuple(idx.shape) == (b, n, 3) and tuple(weight.shape) == (b, n, 3), "idx/weight must be (B, n, 3)")
-    out = torch.zeros((b, c, n), dtype=torch.float32, device=dev)
+    out = _fresh((b, c, n), torch.float32, dev, m)
     call("geot_three_interpolate", dev, b, c, m, n, ptr(points), ptr(idx), ptr(weight), ptr(out))
     return out
 
@@ -80,6 +87,43 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     ws = grad_workspace(dev, b, c, int(m), n, 3)
     call("geot_three_interpolate_grad_ws", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out),
          ptr(ws))
+    return out
+
+
+def fp_weights(dist2):
+    """three_nn's squared distances (B,n,3) -> the inverse-distance weights of pointnet2_modules.py:621-623."""
+    f32(dist2, "dist2", 3)
+    need(dist2.shape[2] == 3, "dist2 must be (B, n, 3)")
+    w = torch.empty_like(dist2)
+    call("geot_fp_weights", dist2.device, dist2.shape[0], dist2.shape[1], ptr(dist2), ptr(w))
+    return w
+
+
+def three_interpolate_into(points, idx, weight, out, ch_offset=0):
+    """As three_interpolate, writing channels [ch_offset, ch_offset + c) of `out` (B, c + c_skip, n) in place."""
+    f32(points, "points", 3); i32(idx, "idx", 3); f32(weight, "weight", 3); f32(out, "out", 3)
+    dev = same_device(points, idx, weight, out)
+    b, c, m = points.shape
+    n = idx.shape[1]
+    need(tuple(idx.shape) == (b, n, 3) and tuple(weight.shape) == (b, n, 3), "idx/weight must be (B, n, 3)")
+    need(out.shape[0] == b and 0 <= ch_offset and ch_offset + c <= out.shape[1] and out.shape[2] == n,
+         "out must be (B, >= ch_offset + c, n)")
+    need(m > 0, "three_interpolate_into needs a non-empty source")
+    call("geot_three_interpolate_into", dev, b, c, m, n, ptr(points), ptr(idx), ptr(weight),
+         ptr(out) + 4 * int(ch_offset) * n, out.shape[1] * n)
+
+
+def three_interpolate_grad_from(grad_wide, c, idx, weight, m, ch_offset=0):
+    """Gradient of three_interpolate_into: reads channels [ch_offset, ch_offset + c) of grad_wide (B, c + c_skip, n)."""
+    f32(grad_wide, "grad_wide", 3); i32(idx, "idx", 3); f32(weight, "weight", 3)
+    dev = same_device(grad_wide, idx, weight)
+    b, cw, n = grad_wide.shape
+    need(c > 0 and ch_offset >= 0 and ch_offset + c <= cw and tuple(idx.shape) == (b, n, 3)
+         and tuple(weight.shape) == (b, n, 3), "shape mismatch")
+    out = torch.zeros((b, c, int(m)), dtype=torch.float32, device=dev)
+    ws = grad_workspace(dev, b, c, int(m), n, 3)
+    call("geot_three_interpolate_grad_from", dev, b, c, n, int(m), ptr(grad_wide) + 4 * int(ch_offset) * n, cw * n,
+         ptr(idx), ptr(weight), ptr(out), ptr(ws))
     return out
 
 
@@ -101,7 +145,7 @@ def group_points(points, idx):
     b, c, n = points.shape
     need(idx.shape[0] == b, "idx batch mismatch")
     npoints, nsample = idx.shape[1], idx.shape[2]
-    out = torch.zeros((b, c, npoints, nsample), dtype=torch.float32, device=dev)
+    out = _fresh((b, c, npoints, nsample), torch.float32, dev, n)
     call("geot_group_points", dev, b, c, n, npoints, nsample, ptr(points), ptr(idx), ptr(out))
     return out
 

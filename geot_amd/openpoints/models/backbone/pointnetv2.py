@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from ..layers.subsample import furthest_point_sample, random_sample
 from ..layers.upsampling import three_interpolation
+from ....pointnet2.pointnet2_utils import fp_interpolate_concat
 from ..layers.local_aggregation import LocalAggregation, create_convblock1d
 
 
@@ -63,9 +64,13 @@ class PointNetFPModule(nn.Module):
         super().__init__()
         self.convs = nn.Sequential(*[create_convblock1d(mlp[i], mlp[i + 1], norm_args=norm_args, act_args=act_args)
                                      for i in range(len(mlp) - 1)])
+        self.fused_front_end = True     # False: the reference's op-by-op chain (kept as the parity baseline)
 
     def forward(self, unknown, known, unknow_feats, known_feats):
         """unknown (B,n,3), known (B,m,3), unknow_feats (B,C1,n) or None, known_feats (B,C2,m) -> (B,mlp[-1],n)."""
+        if known is not None and self.fused_front_end and known.shape[1] > 0:
+            # three_nn -> weights -> interpolate -> cat([skip, interpolated]) as one op (same values)
+            return self.convs(fp_interpolate_concat(unknown, known, unknow_feats, known_feats, True))
         if known is not None:
             interpolated_feats = three_interpolation(unknown, known, known_feats)
         else:

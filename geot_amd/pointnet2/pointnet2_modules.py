@@ -130,8 +130,13 @@ class PointnetFPModule(nn.Module):
     def __init__(self, mlp: List[int], bn: bool = True):
         super().__init__()
         self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+        self.fused_front_end = True     # False: the reference's op-by-op chain (kept as the parity baseline)
 
     def forward(self, unknown, known, unknow_feats, known_feats):
+        if known is not None and self.fused_front_end and known.shape[1] > 0:
+            # three_nn -> weights -> interpolate -> concat as one op (same values; pointnet2_utils.FPInterpolateConcat)
+            new_features = pointnet2_utils.fp_interpolate_concat(unknown, known, unknow_feats, known_feats)
+            return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
         if known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)

@@ -92,6 +92,43 @@ class ThreeInterpolate(Function):
 three_interpolate = ThreeInterpolate.apply
 
 
+class FPInterpolateConcat(Function):
+    """PointnetFPModule front end (pointnet2_modules.py:619-626) as one op: three_nn -> inverse-distance weights
+    -> three_interpolate -> cat([interpolated, unknow_feats], 1), without the (B,n,3) weight temporaries and
+    without the concat's copy of the interpolated half: the interpolation kernel
+    writes straight into the wide tensor, its gradient kernel reads straight from the wide gradient."""
+
+    @staticmethod
+    def forward(ctx, unknown, known, unknow_feats, known_feats, skip_first=False):
+        """-> cat([interpolated, unknow_feats], 1), or cat([unknow_feats, interpolated], 1) with skip_first
+        (openpoints' PointNetFPModule order, pointnetv2.py:141-142); unknow_feats may be None."""
+        dist2, idx = _ext.three_nn(unknown.contiguous(), known.contiguous())
+        weight = _ext.fp_weights(dist2)
+        b, c, m = known_feats.shape
+        n = unknown.shape[1]
+        cs = 0 if unknow_feats is None else unknow_feats.shape[1]
+        off = cs if skip_first else 0                      # first channel of the interpolated block
+        wide = torch.empty((b, c + cs, n), dtype=torch.float32, device=known_feats.device)
+        _ext.three_interpolate_into(known_feats.contiguous(), idx, weight, wide, off)
+        if cs:
+            (wide[:, :cs] if skip_first else wide[:, c:]).copy_(unknow_feats)
+        ctx.fp = (idx, weight, c, m, cs, off)
+        return wide
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, weight, c, m, cs, off = ctx.fp
+        g = g.contiguous()
+        g_known = _ext.three_interpolate_grad_from(g, c, idx, weight, m, off) if ctx.needs_input_grad[3] else None
+        g_skip = None
+        if cs and ctx.needs_input_grad[2]:
+            g_skip = g[:, :cs] if off else g[:, c:]
+        return None, None, g_skip, g_known, None
+
+
+fp_interpolate_concat = FPInterpolateConcat.apply
+
+
 class GroupingOperation(Function):
     @staticmethod
     def forward(ctx, features, idx):

@@ -8,6 +8,8 @@ GroupNorm stacks) are stock PyTorch in the reference and out of scope here, so t
 nothing (features are random tensors of the right shape).  ``ntm_step`` does the same for the
 unlabelled half of a FixMatch+NTM step (train.py:505-571).
 """
+import os
+
 import torch
 
 from .pointnet2 import pointnet2_utils as pu
@@ -20,7 +22,10 @@ TRANS_DIM, GROUPS, GROUP_SIZE = 384, 512, 32   # cfgs/tooth_semi/transformer_fin
 
 
 def _fp(unknown, known, feats):
-    """PointnetFPModule front end (pointnet2_modules.py:619-626): three_nn -> weights -> interpolate."""
+    """PointnetFPModule front end (pointnet2_modules.py:619-626): three_nn -> weights -> interpolate, as the
+    one fused op the FP modules use (GEOT_FP_IMPL=chain: the reference's op-by-op chain, for A/B runs)."""
+    if os.environ.get("GEOT_FP_IMPL", "fused") == "fused":
+        return pu.fp_interpolate_concat(unknown, known, None, feats)
     dist, idx = pu.three_nn(unknown, known)
     r = 1.0 / (dist + 1e-8)
     return pu.three_interpolate(feats, idx, r / torch.sum(r, dim=2, keepdim=True))

@@ -94,6 +94,18 @@ int geot_grad_ws_needs_zero(int b, int c, int m_targets, long long n_sources, in
 int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                    const float *weight, float *grad_points, float *workspace,
                                    void *stream);
+/* PointnetFPModule front end (pointnet2/pointnet2_modules.py:619-626; openpoints' three_interpolation is the same
+ * chain) without its temporaries.  geot_fp_weights: the inverse-distance weights from three_nn's SQUARED
+ * distances, weight = r / ((r0 + r1) + r2), r = 1 / (sqrt(d2) + 1e-8), in one launch.  _into / _grad_from: the
+ * interpolation writes (reads its gradient from) the first c channels of the wider (B, c + c_skip, n) tensor
+ * that `torch.cat([interpolated, unknow_feats], dim=1)` would build; *_bstride = floats between batches there
+ * (>= c * n).  Workspace of _grad_from as for _grad_ws. */
+int geot_fp_weights(int b, int n, const float *dist2, float *weight, void *stream);
+int geot_three_interpolate_into(int b, int c, int m, int n, const float *points, const int *idx,
+                                const float *weight, float *out, long long out_bstride, void *stream);
+int geot_three_interpolate_grad_from(int b, int c, int n, int m, const float *grad_out, long long grad_bstride,
+                                     const int *idx, const float *weight, float *grad_points, float *workspace,
+                                     void *stream);
 
 /* Grid-accelerated variants of geot_knn_sorted / geot_three_nn (geot_amd/csrc/knn_grid.hip): identical
  * outputs, bit for bit, but only the cells around each query are visited (exact: the search widens until

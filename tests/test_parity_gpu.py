@@ -636,3 +636,56 @@ def test_knn_sorted_nd_matches_numpy_restatement(ext, d, k):
     wi, wd = np_ref.knn_sorted_nd(qry, ref, k)
     assert idx.dtype == torch.int64 and np.array_equal(host(idx), wi)
     np.testing.assert_array_equal(host(dist), np.sqrt(wd))
+
+
+@pytest.mark.parametrize("B,n,m,c,cs,skip_first", [(2, 3000, 700, 20, 7, False), (1, 24000, 8192, 64, 32, True),
+                                                    (2, 513, 64, 5, 0, False), (3, 1000, 3, 33, 4, True)])
+def test_fp_front_end_fused_matches_chain(B, n, m, c, cs, skip_first):
+    """FPInterpolateConcat (three_nn -> weights -> interpolate -> concat in place) against the reference's
+    op-by-op chain on the same HIP ops: forward values identical, both gradients within the scatter tolerance."""
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    g = torch.Generator().manual_seed(B * n + m)
+    dev = torch.device("cuda:0")
+    unknown, known = torch.rand(B, n, 3, generator=g).to(dev), torch.rand(B, m, 3, generator=g).to(dev)
+    kf = torch.randn(B, c, m, generator=g).to(dev).requires_grad_(True)
+    uf = torch.randn(B, cs, n, generator=g).to(dev).requires_grad_(True) if cs else None
+    up = torch.randn(B, c + cs, n, generator=g).to(dev)
+    wide = pu.fp_interpolate_concat(unknown, known, uf, kf, skip_first)
+    wide.backward(up)
+    got_k, got_u = kf.grad.clone(), (uf.grad.clone() if cs else None)
+    kf.grad = None
+    if cs:
+        uf.grad = None
+    dist, idx = pu.three_nn(unknown, known)
+    r = 1.0 / (dist + 1e-8)
+    w = r / torch.sum(r, dim=2, keepdim=True)
+    inter = pu.three_interpolate(kf, idx, w)
+    want = inter if not cs else torch.cat([uf, inter] if skip_first else [inter, uf], dim=1)
+    want.backward(up)
+    np.testing.assert_allclose(wide.detach().cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got_k.cpu().numpy(), kf.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    if cs:
+        assert torch.equal(got_u, uf.grad)
+    # and against the oracle's interpolation of the oracle's neighbours
+    from oracle import capi, np_ref
+    d2, oi = capi.three_nn(unknown.cpu().numpy(), known.cpu().numpy())
+    ow = 1.0 / (np.sqrt(d2) + np.float32(1e-8))
+    ow = (ow / ow.sum(2, keepdims=True)).astype(np.float32)
+    oref = np_ref.three_interpolate(kf.detach().cpu().numpy(), oi, ow)
+    lo = cs if skip_first else 0
+    np.testing.assert_allclose(wide.detach().cpu().numpy()[:, lo:lo + c], oref, rtol=1e-5, atol=1e-6)
+
+
+def test_fp_modules_fused_front_end_equals_chain():
+    from geot_amd.openpoints.models.backbone.pointnetv2 import PointNetFPModule
+    from geot_amd.pointnet2.pointnet2_modules import PointnetFPModule
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    unknown, known = torch.rand(2, 2000, 3, device=dev), torch.rand(2, 500, 3, device=dev)
+    uf, kf = torch.randn(2, 6, 2000, device=dev), torch.randn(2, 10, 500, device=dev)
+    for mod in (PointnetFPModule([16, 32, 8]).to(dev).eval(), PointNetFPModule([16, 32, 8]).to(dev).eval()):
+        assert mod.fused_front_end
+        a = mod(unknown, known, uf, kf)
+        mod.fused_front_end = False
+        b = mod(unknown, known, uf, kf)
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
