@@ -841,8 +841,8 @@ __global__ __launch_bounds__(256) void tl_overflow_kernel(int cap, float gscale,
 //   N = geo*class_T + (1-geo)*B, row 0 := class_T[0];   M = N / rowsum(N)[k]
 //   E = dec*ema_t + (1-dec)*M;  ema_corr = E / rowsum(E)[k];   ema_next = likewise from class_T alone
 // One workgroup, one thread per matrix entry: ~40 tiny torch kernels forward and as many backward become one
-// launch each.  Backward (only sigma is learnable) uses forward-mode derivatives, one sigma component at a
-// time: d/d sigma[c0] touches a single row of P0, the three quirky normalisations carry it everywhere.
+// launch each.  Backward (only sigma is learnable) uses forward-mode derivatives, one sigma component per
+// workgroup: d/d sigma[c0] touches a single row of P0, the three quirky normalisations carry it everywhere.
 constexpr int CT_MAXC = 32;
 
 __device__ __forceinline__ float ct_rowsum(float v, int r, int k, int C, float *buf)
@@ -890,7 +890,8 @@ __global__ __launch_bounds__(CT_MAXC * CT_MAXC) void class_transition_kernel(
         return;
     }
     const float gc = (in && g_corr) ? g_corr[r * C + k] : 0.f, gp = (in && g_prior) ? g_prior[r * C + k] : 0.f;
-    for (int c0 = 0; c0 < C; ++c0) {
+    {
+        const int c0 = blockIdx.x;   // one workgroup per sigma component (the forward fields are recomputed: cheap)
         // derivative fields w.r.t. sigma[c0]
         const float dP0 = (in && r == c0) ? P0 * (-1.f / sg + delta * delta / (sg * sg * sg)) : 0.f;
         const float dA = (r >= 1 && k >= 1) ? dP0 : 0.f;
@@ -1055,7 +1056,7 @@ GEOT_EXPORT int geot_ntm_class_transition_grad(int c, float geo_lambda, float em
                                                float *grad_sigma, void *stream)
 {
     if (c < 1 || c > CT_MAXC || !grad_sigma) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((class_transition_kernel<true>), dim3(1), dim3(CT_MAXC * CT_MAXC), 0, (hipStream_t)stream, c,
+    hipLaunchKernelGGL((class_transition_kernel<true>), dim3(c), dim3(CT_MAXC * CT_MAXC), 0, (hipStream_t)stream, c,
                        geo_lambda, ema_decay, class_T, sigma, ema_t, proj, nullptr, nullptr, nullptr, nullptr,
                        grad_ema_t_corr, grad_prior_T, grad_sigma);
     return hipGetLastError();
