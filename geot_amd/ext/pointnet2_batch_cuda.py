@@ -7,8 +7,6 @@ reference (which only checks ball_query and exit(-1)s) every call validates its
 tensors and raises RuntimeError.  Outputs may be uninitialised
 (torch.cuda.FloatTensor(...)); they are written in full.
 """
-import torch
-
 from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace
 
 

@@ -23,7 +23,7 @@ def T(a, dtype=torch.float32):
 
 @pytest.mark.parametrize("B,N", [(1, 64), (2, 500), (3, 1001), (1, 7), (2, 24000)])
 def test_sig_t_mean_forward_backward(B, N):
-    from geot_amd.ntm import sig_t_mean, Ins_T_mean
+    from geot_amd.ntm import Ins_T_mean
     torch.manual_seed(0)
     rng = np.random.default_rng(0)
     p = _softmax(rng.standard_normal((B, C, N)) * 2, 1).astype(np.float32)

@@ -36,7 +36,6 @@ def build():
 
 
 def run():
-    import numpy as np
     import torch
     sys.path.insert(0, ROOT)
     from geot_amd.synth import make_batch

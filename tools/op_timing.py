@@ -1,9 +1,7 @@
 """Per-op timings at the BASELINE shapes (developer tool; bench.py is the judged harness)."""
 import os
 import sys
-import time
 
-import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
