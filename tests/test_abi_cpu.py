@@ -56,6 +56,14 @@ def test_cpu_tensors_are_rejected_not_emulated(built):
     with pytest.raises(RuntimeError, match="CPU not supported"):
         pointnet2_batch_cuda.three_nn_wrapper(1, 4, 4, torch.zeros(1, 4, 3), torch.zeros(1, 4, 3),
                                               torch.zeros(1, 4, 3), torch.zeros(1, 4, 3, dtype=torch.int32))
+    # dataloader-side ops: CPU tensors are refused as well (the reference's CPU code is not re-implemented here)
+    from geot_amd.openpoints.dataset import grid_subsampling, pc_norm, prepare_sample
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        grid_subsampling(torch.zeros(8, 3), sampleDl=0.1, device=torch.device("cpu"))
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        pc_norm(torch.zeros(8, 3))
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        prepare_sample(torch.zeros(8, 3), torch.zeros(8, dtype=torch.int32), torch.zeros(4, dtype=torch.int64))
 
 
 def test_missing_library_fails_loudly(tmp_path):
