@@ -82,6 +82,35 @@ def test_sa_module_fused_equals_unfused(nsample, mlp_spec, c_feat, normalize):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mlp_spec,c_feat", [([3, 64, 64, 128], 3), ([8, 32, 64], 8), ([2, 64, 256], 2), ([0, 128], 0)])
+def test_sa_kernel_paths_agree(mlp_spec, c_feat, monkeypatch):
+    """The fused kernel has three loop forms for nsample = 32: the generic one (LDS pooling), the register-pooled
+    software-pipelined one with one group per store, and the same with runs of 8 groups per wave (sector-sized
+    stores; needs npoint % 8 == 0).  Same MFMA arithmetic => bit-identical results; and all match the unfused
+    composition."""
+    from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(11)
+    xyz_np, _ = make_batch(3, 4000, start_index=9)
+    xyz = torch.from_numpy(xyz_np).cuda()
+    feats = torch.randn(3, c_feat, 4000, device="cuda:0") if c_feat else None
+    sa = PointnetSAModuleVotes(mlp=list(mlp_spec), npoint=520, radius=0.15, nsample=32).cuda().eval()
+    outs = {}
+    with torch.no_grad():
+        for name, env in (("generic", {"GEOT_SA_FAST": "0"}), ("run1", {"GEOT_SA_RUN": "1"}), ("run8", {"GEOT_SA_RUN": "8"})):
+            for k in ("GEOT_SA_FAST", "GEOT_SA_RUN"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            outs[name] = sa(xyz, feats)[1]
+        for k in ("GEOT_SA_FAST", "GEOT_SA_RUN"):
+            monkeypatch.delenv(k, raising=False)
+        sa.fused_eval = False
+        ref = sa(xyz, feats)[1]
+    assert torch.equal(outs["generic"], outs["run1"]) and torch.equal(outs["generic"], outs["run8"])
+    np.testing.assert_allclose(outs["run8"].cpu().numpy(), ref.cpu().numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.gpu
 def test_sa_and_fp_modules_train_mode_backward():
     from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes, PointnetFPModule, PointnetSAModuleMSG
     torch.manual_seed(1)  # mirrors the reference smoke test pointnet2_modules.py:725-744
