@@ -912,7 +912,7 @@ __global__ __launch_bounds__(CT_MAXC * CT_MAXC) void class_transition_kernel(
         if (tid == 0) {
             float t = 0.f;
             for (int w = 0; w < CT_MAXC * CT_MAXC / 64; ++w) t += red[w];
-            g_sigma[c0] += t;
+            g_sigma[c0] = t;   // sole writer: the caller's buffer needs no zero-fill
         }
     }
 }

@@ -127,7 +127,7 @@ class _ClassTransitionFn(Function):
     def backward(ctx, g_corr, g_next, g_prior):
         class_T, sigma_c, ema_t, proj = ctx.saved_tensors
         geo_lambda, ema_decay = ctx.consts
-        gs = torch.zeros_like(sigma_c)
+        gs = torch.empty_like(sigma_c)      # written in full by the kernel
         gc = g_corr.contiguous() if g_corr is not None else None
         gp = g_prior.contiguous() if g_prior is not None else None
         call("geot_ntm_class_transition_grad", class_T.device, class_T.shape[0], geo_lambda, ema_decay, ptr(class_T),

@@ -246,8 +246,9 @@ int geot_ntm_correct_grad(int b, int n, int c, float lam, const float *logits, c
  * tooth-adjacency prior from sigma (c) over the label projection proj (c) (train.py:48), blend, the three
  * `X / X.sum(1)` normalisations exactly as written there (column k divided by row-sum k), EMA.  c <= 32.
  * Writes ema_t_corr, ema_t_next, prior_T (c,c) and, when ema_t_keep is not NULL, a copy of ema_t there (a caller
- * that keeps ema_t in one persistent buffer overwrites it with ema_t_next, train.py:556-557, before backward).  _grad accumulates d/d sigma (c) given d/d ema_t_corr and
- * d/d prior_T (either may be NULL); sigma is the only learnable input. */
+ * that keeps ema_t in one persistent buffer overwrites it with ema_t_next, train.py:556-557, before backward).
+ * _grad writes d/d sigma (c) given d/d ema_t_corr and d/d prior_T (either may be NULL); sigma is the only
+ * learnable input. */
 int geot_ntm_class_transition(int c, float geo_lambda, float ema_decay, const float *class_T, const float *sigma,
                               const float *ema_t, const float *proj, float *ema_t_corr, float *ema_t_next,
                               float *prior_T, float *ema_t_keep, void *stream);
