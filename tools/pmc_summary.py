@@ -1,0 +1,55 @@
+"""Turn rocprofv3 --pmc CSV outputs (separate FETCH_SIZE / WRITE_SIZE passes, optional MFMA pass) of one
+command into the per-kernel JSON summaries kept under profiles/.
+
+    python tools/pmc_summary.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<command>"
+    python tools/pmc_summary.py mfma <counter_collection.csv> <out.json> "<command>" <kernel substring>
+
+traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB per launch: FETCH doubled per the gfx950 rule of
+MI355X_MICROARCH.md (HBM section).  Warm-up launches are included in the averages (they move the same bytes).
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path):
+    acc = defaultdict(lambda: defaultdict(list))
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return acc
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def main():
+    if sys.argv[1] == "traffic":
+        fetch, write, out, cmd = sys.argv[2:6]
+        F, W = per_kernel(fetch), per_kernel(write)
+        kernels = {}
+        for k in F:
+            if not k.startswith(("void geot", "geot")):
+                continue
+            f = sum(F[k]["FETCH_SIZE"]) / len(F[k]["FETCH_SIZE"])
+            w = sum(W[k]["WRITE_SIZE"]) / len(W[k]["WRITE_SIZE"]) if k in W else 0.0
+            kernels[short(k)] = {"fetch_kb": f, "write_kb": w, "traffic_bytes": int(round((2 * f + w) * 1024))}
+        json.dump({"command": cmd, "unit": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes); traffic_bytes = "
+                   "(2 x FETCH_SIZE + WRITE_SIZE) KB: FETCH doubled per the gfx950 rule in MI355X_MICROARCH.md (HBM section)",
+                   "kernels": kernels}, open(out, "w"), indent=1)
+    else:
+        path, out, cmd, sub = sys.argv[2:6]
+        M = per_kernel(path)
+        k = [x for x in M if sub in x][0]
+        c = {n: sum(v) / len(v) for n, v in M[k].items()}
+        util = c["SQ_VALU_MFMA_BUSY_CYCLES"] / ((c["GRBM_GUI_ACTIVE"] / 8) * 1024) * 100
+        json.dump({"command": cmd, "kernel": short(k), "counters": c, "MfmaUtil_percent": util,
+                   "note": "rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs: MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / "
+                           "((GRBM_GUI_ACTIVE / 8) * 1024 SIMDs)"}, open(out, "w"), indent=1)
+    print(open(out).read()[:1500])
+
+
+if __name__ == "__main__":
+    main()
