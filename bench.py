@@ -69,7 +69,9 @@ def pmc_traffic(kernel):
     process, so the figure is the profiled one, not a live one; None if no profile is committed."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01 ... v11 after v7
     if not files:
         return None
     with open(files[-1]) as f:
