@@ -5,6 +5,8 @@ mixes AT_ASSERT -> RuntimeError, exit(-1) and no checks at all; we never exit an
 never silently read a bad tensor).  CPU tensors are rejected like the
 reference's AT_ASSERT(false, "CPU not supported") -- there is no CPU path.
 """
+import os
+
 import torch
 
 from .. import _lib
@@ -43,6 +45,17 @@ def same_device(*ts):
 def need(cond, msg):
     if not cond:
         raise RuntimeError(msg)
+
+
+def check_index(idx, upper, name):
+    """GEOT_DEBUG=1: verify 0 <= idx < upper before a gather-type launch (one host sync; off by default).
+    The reference never checks, and an out-of-range neighbour index is an out-of-bounds read on the GPU --
+    this turns it into an IndexError while a caller's index pipeline is being brought up."""
+    if os.environ.get("GEOT_DEBUG", "0") != "1" or idx.numel() == 0:
+        return
+    lo, hi = int(idx.min().item()), int(idx.max().item())
+    if lo < 0 or hi >= int(upper):
+        raise IndexError("%s holds indices in [%d, %d], valid range is [0, %d)" % (name, lo, hi, int(upper)))
 
 
 def stream_of(dev):

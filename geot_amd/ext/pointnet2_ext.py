@@ -8,7 +8,7 @@ ball_query.cpp:22-24; group_points.cpp:25-27,50-52; interpolate.cpp:26-31,58-60,
 """
 import torch
 
-from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace
+from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace, check_index
 
 
 def _fresh(shape, dtype, dev, source_len):
@@ -24,6 +24,7 @@ def gather_points(points, idx):
     b, c, n = points.shape
     need(idx.shape[0] == b, "idx batch mismatch")
     m = idx.shape[1]
+    check_index(idx, n, "gather_points: idx")
     out = _fresh((b, c, m), torch.float32, dev, n)
     call("geot_gather_points", dev, b, c, n, m, ptr(points), ptr(idx), ptr(out))
     return out
@@ -70,6 +71,7 @@ def three_interpolate(points, idx, weight):
     b, c, m = points.shape
     n = idx.shape[1]
     need(tuple(idx.shape) == (b, n, 3) and tuple(weight.shape) == (b, n, 3), "idx/weight must be (B, n, 3)")
+    check_index(idx, m, "three_interpolate: idx")
     out = _fresh((b, c, n), torch.float32, dev, m)
     call("geot_three_interpolate", dev, b, c, m, n, ptr(points), ptr(idx), ptr(weight), ptr(out))
     return out
@@ -109,6 +111,7 @@ def three_interpolate_into(points, idx, weight, out, ch_offset=0):
     need(out.shape[0] == b and 0 <= ch_offset and ch_offset + c <= out.shape[1] and out.shape[2] == n,
          "out must be (B, >= ch_offset + c, n)")
     need(m > 0, "three_interpolate_into needs a non-empty source")
+    check_index(idx, m, "three_interpolate_into: idx")
     call("geot_three_interpolate_into", dev, b, c, m, n, ptr(points), ptr(idx), ptr(weight),
          ptr(out) + 4 * int(ch_offset) * n, out.shape[1] * n)
 
@@ -145,6 +148,7 @@ def group_points(points, idx):
     b, c, n = points.shape
     need(idx.shape[0] == b, "idx batch mismatch")
     npoints, nsample = idx.shape[1], idx.shape[2]
+    check_index(idx, n, "group_points: idx")
     out = _fresh((b, c, npoints, nsample), torch.float32, dev, n)
     call("geot_group_points", dev, b, c, n, npoints, nsample, ptr(points), ptr(idx), ptr(out))
     return out

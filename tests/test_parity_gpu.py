@@ -689,3 +689,21 @@ def test_fp_modules_fused_front_end_equals_chain():
         mod.fused_front_end = False
         b = mod(unknown, known, uf, kf)
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_debug_mode_rejects_out_of_range_indices(ext, monkeypatch):
+    """GEOT_DEBUG=1 turns an out-of-range gather index into an IndexError (the reference would read out of
+    bounds); without the flag nothing is checked and no host sync happens."""
+    feats = torch.randn(2, 4, 100, device=DEV)
+    good = torch.randint(0, 100, (2, 30), device=DEV, dtype=torch.int32)
+    bad = good.clone()
+    bad[1, 7] = 100
+    monkeypatch.setenv("GEOT_DEBUG", "1")
+    assert ext.p2.gather_points(feats, good).shape == (2, 4, 30)
+    with pytest.raises(IndexError, match="gather_points"):
+        ext.p2.gather_points(feats, bad)
+    neg = torch.full((2, 5, 3), -1, dtype=torch.int32, device=DEV)
+    with pytest.raises(IndexError, match="three_interpolate"):
+        ext.p2.three_interpolate(feats, neg, torch.ones(2, 5, 3, device=DEV))
+    with pytest.raises(IndexError, match="group_points"):
+        ext.p2.group_points(feats, bad.view(2, 10, 3))
