@@ -139,9 +139,14 @@ def main():
     from geot_amd import dist_utils
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     world, rank, local = dist_utils.env_world()
+    # GEOT_BENCH_REHEARSAL=1: N ranks share GPU 0 and talk over gloo -- rehearses the N > 1 control flow
+    # (rendezvous, barriers, MAX over ranks, rank-0 JSON) on a one-GPU box; never a measurement
+    rehearsal = os.environ.get("GEOT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist_utils.init("nccl")
+    dist_utils.init("gloo" if rehearsal else "nccl")
 
     from geot_amd import _lib
     from geot_amd.synth import make_batch
@@ -222,7 +227,7 @@ def main():
         setattr(patch_owner, patch_name, orig_fn)
     if workload == "sa":
         sa_fused_mod.fused_group_mlp_max = orig_mlp
-    elapsed = dist_utils.max_over_ranks(elapsed, dev)
+    elapsed = dist_utils.max_over_ranks(elapsed, "cpu" if rehearsal else dev)
     assert torch.isfinite(out).all()
 
     fps_ms = timer.mean_ms()
@@ -240,7 +245,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
         "config": {"workload": desc, "clouds_per_gpu": B, "points": N_POINTS,
                    "parallelism": "independent clouds per rank, no collective" +
                                   ("" if args.streams == 1 else "; consecutive steps overlap on %d HIP streams" % args.streams)},
@@ -275,6 +280,8 @@ def main():
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
+        import torch.distributed as dist
+        dist.barrier()                      # rank 0 may still be printing: leave together
         dist.destroy_process_group()
 
 

@@ -156,3 +156,43 @@ def test_header_is_plain_c_and_links(tmp_path):
            "-L", lib_dir, "-lgeot_hip", "-Wl,-rpath," + lib_dir, "-Wl,--unresolved-symbols=ignore-in-shared-libs"]
     subprocess.check_call(cmd)
     assert len(names) >= 50
+
+
+def test_no_undefined_global_names():
+    """Static check (pyflakes is not installed): every LOAD_GLOBAL in the product, bench and tool sources
+    resolves to a module-level name or a builtin.  A typo'd or never-imported global in a rarely taken branch --
+    e.g. the N > 1 tail of bench.py, which no CPU test can execute -- otherwise surfaces only on the GPU box."""
+    import ast
+    import builtins
+    import dis
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    for sub in ("geot_amd", "tools", "oracle"):
+        files += glob.glob(os.path.join(root, sub, "**", "*.py"), recursive=True)
+    bad = []
+    for path in files:
+        src = open(path).read()
+        tree = ast.parse(src)
+        defined = set(dir(builtins)) | {"__file__", "__name__", "__doc__", "__builtins__", "__spec__", "__package__"}
+        for node in ast.walk(tree):     # any binding anywhere that can create a module-level name
+            if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                defined.add(node.name)
+            elif isinstance(node, ast.Import):
+                defined.update((a.asname or a.name).split(".")[0] for a in node.names)
+            elif isinstance(node, ast.ImportFrom):
+                defined.update(a.asname or a.name for a in node.names)
+            elif isinstance(node, ast.Name) and isinstance(node.ctx, (ast.Store, ast.Del)):
+                defined.add(node.id)
+            elif isinstance(node, ast.Global):
+                defined.update(node.names)
+
+        def walk(code):
+            for ins in dis.get_instructions(code):
+                if ins.opname in ("LOAD_GLOBAL", "LOAD_NAME") and ins.argval not in defined:
+                    bad.append("%s: %s (line %s)" % (os.path.relpath(path, root), ins.argval, ins.starts_line))
+            for c in code.co_consts:
+                if hasattr(c, "co_code"):
+                    walk(c)
+        walk(compile(src, path, "exec"))
+    assert not bad, "undefined global names:\n" + "\n".join(sorted(set(bad)))
