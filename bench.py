@@ -148,9 +148,12 @@ def main():
     dev = torch.device("cuda", local)
     dist_utils.init("gloo" if rehearsal else "nccl")
 
-    from geot_amd import _lib
+    from geot_amd import _lib, build as hip_build
     from geot_amd.synth import make_batch
     from geot_amd.pointnet2 import pointnet2_utils
+    if not os.path.exists(hip_build.LIB) and rank == 0:      # fresh checkout: built artefacts are git-ignored
+        hip_build.build()
+    dist_utils.barrier()
     _lib.load()
 
     workload = args.workload
