@@ -207,8 +207,6 @@ __global__ __launch_bounds__(MAXW >= 8 ? 512 : SA_WAVES * 64) void sa_group_mlp_
     float *act = sa_lds + d.total + wave * (32 * d.act_stride + gpt * cp_last);
     float *pool = act + 32 * d.act_stride;
     const int nwaves = blockDim.x >> 6;
-    for (int i = threadIdx.x; i < d.total; i += blockDim.x) P[i] = params[i];
-    __syncthreads();
 
     const int tpg = nsample >= 32 ? nsample / 32 : 1;  // tiles per group
     const long long ngroups = (long long)b * npoint;
@@ -303,10 +301,10 @@ __global__ __launch_bounds__(MAXW >= 8 ? 512 : SA_WAVES * 64) void sa_group_mlp_
         const int rend = min((int)(blockIdx.x + 1) * rchunk, nruns);
         int run = blockIdx.x * rchunk + wave, j = 0;
         SaRow R;
-        if (run < rend) {
-            load(R, run * run_len);
-            commit(R);
-        }
+        if (run < rend) load(R, run * run_len);   // the first rows travel while the weights are staged
+        for (int i = threadIdx.x; i < d.total; i += blockDim.x) P[i] = params[i];
+        __syncthreads();
+        if (run < rend) commit(R);
         while (run < rend) {
             for (int l = 0; l < d.nlayers; ++l) {
                 const int w32 = d.cp[l] >> 5;
@@ -335,6 +333,8 @@ __global__ __launch_bounds__(MAXW >= 8 ? 512 : SA_WAVES * 64) void sa_group_mlp_
         }
         return;
     }
+    for (int i = threadIdx.x; i < d.total; i += blockDim.x) P[i] = params[i];
+    __syncthreads();
     const long long uchunk = (nunits + gridDim.x - 1) / gridDim.x, uend = min((long long)(blockIdx.x + 1) * uchunk, nunits);
     for (long long u = (long long)blockIdx.x * uchunk + wave; u < uend; u += nwaves) {   // contiguous run per workgroup
         for (int i = lane; i < gpt * cp_last; i += 64) pool[i] = -INFINITY;
