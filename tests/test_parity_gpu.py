@@ -707,3 +707,17 @@ def test_debug_mode_rejects_out_of_range_indices(ext, monkeypatch):
         ext.p2.three_interpolate(feats, neg, torch.ones(2, 5, 3, device=DEV))
     with pytest.raises(IndexError, match="group_points"):
         ext.p2.group_points(feats, bad.view(2, 10, 3))
+
+
+@pytest.mark.parametrize("m", [1, 2])
+def test_three_nn_with_fewer_than_three_known_points(ext, oracle, m):
+    """The reference kernel's initial values survive in the unused slots (index 0, distance 1e40 -> inf in fp32);
+    every output element is written (the wrappers hand the kernels uninitialised buffers)."""
+    rng = np.random.default_rng(m)
+    q, k = rng.random((2, 300, 3)).astype(np.float32), rng.random((2, m, 3)).astype(np.float32)
+    junk = torch.full((2, 300, 3), -12345.0, device=DEV)     # poison the allocator's free list
+    del junk
+    d2, idx = ext.p2.three_nn(dev(q), dev(k))
+    wd, wi = oracle.three_nn(q, k)
+    assert np.array_equal(host(idx), wi) and np.array_equal(host(d2), wd)
+    assert np.isinf(host(d2)[:, :, m:]).all() and (host(idx)[:, :, m:] == 0).all()
