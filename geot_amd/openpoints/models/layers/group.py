@@ -1,4 +1,4 @@
-"""Mirror of openpoints/models/layers/group.py: KNN :12-28, GroupingOperation :76-117,
+"""Mirror of openpoints/models/layers/group.py: KNN :12-28, DenseDilated / DilatedKNN :31-73, GroupingOperation :76-117,
 torch_grouping_operation :120-137, GatherOperation :140-174, BallQuery :177-203, QueryAndGroup :206-255,
 GroupAll :258-275, KNNGroup :275-320, get_aggregation_feautres, create_grouper :336-352."""
 import copy
@@ -9,8 +9,9 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from ...cpp import pointnet2_cuda
-from ....knn_cuda import knn_sorted
+from ....knn_cuda import knn_sorted  # noqa: F401  (re-exported: KNNGroup helpers import it from here)
 from .subsample import GatherOperation, gather_operation  # noqa: F401  (same op, defined twice in the reference)
+from .knn import _knn, DenseDilated  # noqa: F401  (group.py:31-54 repeats knn.py's class)
 
 
 class KNN(nn.Module):
@@ -22,8 +23,22 @@ class KNN(nn.Module):
 
     @torch.no_grad()
     def forward(self, support, query):
-        d2, idx = knn_sorted(query.contiguous().float(), support.contiguous().float(), self.neighbors)
-        return torch.sqrt(d2).transpose(1, 2).contiguous(), idx
+        dist, idx = _knn(query, support, self.neighbors)      # 3-D: grid / wave kernel; C <= 32: N-D wave kernel
+        return dist.transpose(1, 2).contiguous(), idx
+
+
+class DilatedKNN(nn.Module):
+    """group.py:57-73: kNN with k * dilation neighbours, every dilation-th kept."""
+
+    def __init__(self, k=9, dilation=1, stochastic=False, epsilon=0.0):
+        super().__init__()
+        self.dilation, self.stochastic, self.epsilon, self.k = dilation, stochastic, epsilon, k
+        self._dilated = DenseDilated(k, dilation, stochastic, epsilon)
+        self.knn = KNN(k * self.dilation, transpose_mode=True)
+
+    def forward(self, query):
+        _, idx = self.knn(query, query)
+        return self._dilated(idx)
 
 
 class GroupingOperation(Function):

@@ -284,3 +284,19 @@ def test_get_pred_whole_matches_oracle(oracle):
         got = preds[i][0].cpu().numpy()
         assert got.shape == (whole[i].shape[0],)
         assert np.array_equal(got[clear], lw.argmax(0)[clear]) and clear.mean() > 0.99
+
+
+def test_group_knn_feature_space_and_dilated():
+    """group.KNN on non-3-D inputs (the reference's cdist + topk works for any C) and DilatedKNN."""
+    from geot_amd.openpoints.models.layers.group import KNN, DilatedKNN
+    torch.manual_seed(5)
+    sup, qry = torch.randn(2, 500, 7, device="cuda:0"), torch.randn(2, 90, 7, device="cuda:0")
+    dist, idx = KNN(6)(sup, qry)
+    assert dist.shape == (2, 6, 90) and idx.shape == (2, 90, 6) and idx.dtype == torch.int32
+    ref = torch.cdist(qry, sup).topk(6, dim=-1, largest=False, sorted=True)
+    assert torch.equal(idx.long(), ref.indices)
+    assert torch.allclose(dist.transpose(1, 2), ref.values, rtol=1e-4, atol=1e-5)
+    pts = torch.rand(2, 400, 3, device="cuda:0")
+    dil = DilatedKNN(k=4, dilation=3)(pts)
+    _, full = KNN(12)(pts, pts)
+    assert torch.equal(dil, full[:, :, ::3])
