@@ -9,7 +9,6 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from ...cpp import pointnet2_cuda
-from ....knn_cuda import knn_sorted  # noqa: F401  (re-exported: KNNGroup helpers import it from here)
 from .subsample import GatherOperation, gather_operation  # noqa: F401  (same op, defined twice in the reference)
 from .knn import _knn, DenseDilated  # noqa: F401  (group.py:31-54 repeats knn.py's class)
 
