@@ -1,10 +1,53 @@
-"""Mirror of openpoints/models/layers/subsample.py:42-156 over ``pointnet2_cuda`` (HIP):
-random_sample, FurthestPointSampling (no origin-skip, tie rule of a <=1024-thread block),
-GatherOperation (+ scatter-add backward), fps."""
+"""Mirror of openpoints/models/layers/subsample.py:11-156 over ``pointnet2_cuda`` (HIP):
+BaseSampler / RandomSample, random_sample, FurthestPointSampling (no origin-skip, tie rule of a <=1024-thread
+block), GatherOperation (+ scatter-add backward), fps."""
+import math
+from abc import ABC, abstractmethod
+
 import torch
 from torch.autograd import Function
 
 from ...cpp import pointnet2_cuda
+
+
+class BaseSampler(ABC):
+    """subsample.py:11-50: sample exactly num_to_sample points, or floor(N * ratio)."""
+
+    def __init__(self, ratio=None, num_to_sample=None, subsampling_param=None):
+        if num_to_sample is not None:
+            if ratio is not None or subsampling_param is not None:
+                raise ValueError("Can only specify ratio or num_to_sample or subsampling_param, not several !")
+            self._num_to_sample = num_to_sample
+        elif ratio is not None:
+            self._ratio = ratio
+        elif subsampling_param is not None:
+            self._subsampling_param = subsampling_param
+        else:
+            raise Exception('At least ["ratio, num_to_sample, subsampling_param"] should be defined')
+
+    def __call__(self, xyz):
+        return self.sample(xyz)
+
+    def _get_num_to_sample(self, npoints) -> int:
+        return self._num_to_sample if hasattr(self, "_num_to_sample") else math.floor(npoints * self._ratio)
+
+    def _get_ratio_to_sample(self, batch_size) -> float:
+        return self._ratio if hasattr(self, "_ratio") else self._num_to_sample / float(batch_size)
+
+    @abstractmethod
+    def sample(self, xyz, feature=None, batch=None):
+        pass
+
+
+class RandomSample(BaseSampler):
+    """subsample.py:53-68: uniform indices with replacement, xyz (B,N,3) -> (sampled (B,m,3), idx (B,m))."""
+
+    def sample(self, xyz, **kwargs):
+        if len(xyz.shape) != 3:
+            raise ValueError(" Expects the xyz tensor to be of dimension 3")
+        B, N, _ = xyz.shape
+        idx = torch.randint(0, N, (B, self._get_num_to_sample(N)), device=xyz.device)
+        return torch.gather(xyz, 1, idx.unsqueeze(-1).expand(-1, -1, 3)), idx
 
 
 def random_sample(xyz, npoint):
