@@ -8,6 +8,7 @@ After ``geot_amd.aliases.install()`` these reference import lines resolve to thi
     import pointnet2_batch_cuda                            (openpoints/cpp/pointnet2_batch/__init__.py:1)
     from knn_cuda import KNN                               (openpoints/models/backbone/transformer.py:11)
     from pointnet2_ops import pointnet2_utils              (examples/segmentation/train.py:39)
+    import openpoints.cpp.subsampling.grid_subsampling     (openpoints/dataset/grid_sample.py:1; its `compute`)
 
 so the reference's own wrapper files (pointnet2_utils.py, pointops.py, subsample.py, ...) run on
 MI355X unchanged.  Nothing is registered implicitly: call install() before importing the
@@ -54,4 +55,23 @@ def install(force=False):
         put("openpoints.cpp", op_cpp)
         sys.modules["openpoints"].cpp = op_cpp
     put("openpoints.cpp.pointnet2_batch", op_p2b)
+    # `import openpoints.cpp.subsampling.grid_subsampling as cpp_subsampling` -> .compute(points, features=, classes=,
+    # sampleDl=, method=, verbose=): the CPython extension of openpoints/cpp/subsampling/wrapper.cpp:58-285
+    from .openpoints.dataset import grid_sample as _gs
+
+    def compute(points, features=None, classes=None, sampleDl=0.1, method="barycenters", verbose=0):
+        if method not in ("barycenters", "voxelcenters"):       # wrapper.cpp:86-90
+            raise RuntimeError('Error parsing method. Valid method names are "barycenters" and "voxelcenters" ')
+        return _gs.grid_subsampling(points, features=features, labels=classes, sampleDl=sampleDl, verbose=verbose)
+
+    sub = types.ModuleType("openpoints.cpp.subsampling")
+    sub.__path__ = []
+    gsm = types.ModuleType("openpoints.cpp.subsampling.grid_subsampling")
+    gsm.compute = compute
+    sub.grid_subsampling = gsm
+    put("openpoints.cpp.subsampling", sub)
+    put("openpoints.cpp.subsampling.grid_subsampling", gsm)
+    cpp_pkg = sys.modules.get("openpoints.cpp")
+    if cpp_pkg is not None and not hasattr(cpp_pkg, "subsampling"):
+        cpp_pkg.subsampling = sys.modules["openpoints.cpp.subsampling"]     # `import a.b.c as x` walks attributes
     return ["pointnet2._ext", "pointops_cuda", "pointnet2_batch_cuda", "knn_cuda", "pointnet2_ops"]

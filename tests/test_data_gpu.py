@@ -136,3 +136,18 @@ def test_prepare_sample_flags_bad_index():
     lab = torch.zeros(100, dtype=torch.int32, device=dev)
     with pytest.raises(IndexError):
         prepare_sample(pc, lab, torch.tensor([0, 5, 100], device=dev))
+
+
+def test_reference_extension_name_resolves_to_the_gpu_op():
+    """`import openpoints.cpp.subsampling.grid_subsampling as cpp_subsampling; cpp_subsampling.compute(...)`
+    (openpoints/dataset/grid_sample.py:1-23) after aliases.install()."""
+    import geot_amd.aliases
+    geot_amd.aliases.install()
+    import openpoints.cpp.subsampling.grid_subsampling as cpp_subsampling
+    p, f, lab = _cloud(21, 2500, 2, 1)
+    pts, feats, labs = cpp_subsampling.compute(p, features=f, classes=lab[:, 0], sampleDl=0.25, verbose=0)
+    want = np_data.grid_subsampling(p, f, lab, 0.25)
+    assert np.array_equal(pts, want["points"]) and np.array_equal(feats, want["features"])
+    assert np.array_equal(labs, want["labels"])
+    with pytest.raises(RuntimeError, match="Valid method names"):
+        cpp_subsampling.compute(p, method="nearest")
