@@ -250,7 +250,7 @@ def correct_logits(pred_u_strong, ins_T, ema_t_corr, lam):
 # ---------------------------------------------------------------------------------------------
 class _ThreeDLossFn(Function):
     @staticmethod
-    def forward(ctx, positions, labels, ins_T, nbr, sigma):
+    def forward(ctx, positions, labels, ins_T, nbr, sigma, order=None):
         positions = f32(positions.contiguous(), "positions", 3)
         ins_T = f32(ins_T.contiguous(), "ins_T", 3)
         labels = i32(labels.contiguous(), "labels", 2)
@@ -262,7 +262,8 @@ class _ThreeDLossFn(Function):
         need(tuple(ins_T.shape) == (b * n, c, c) and tuple(labels.shape) == (b, n) and tuple(nbr.shape) == (b, n, k),
              "threeD_space_loss shape mismatch")
         per_point = torch.empty(b * n, dtype=torch.float32, device=dev)
-        order = spatial_order(positions)      # processing order only: neighbour rows then hit L2
+        if order is None:
+            order = spatial_order(positions)      # processing order only: neighbour rows then hit L2
         mode = os.environ.get("GEOT_NTM_GRAD", "graph")   # graph | gather | atomic (A/B tests)
         graph = None
         if ctx.needs_input_grad[2] and mode == "graph":
@@ -289,7 +290,7 @@ class _ThreeDLossFn(Function):
             up = grad_out.reshape(1).float().contiguous()
             call("geot_ntm_threed_loss_grad_graph", positions.device, b, n, c, k, 1.0 / (b * n), ptr(up), ptr(ins_T),
                  ptr(nbr), ptr(order), ptr(graph), graph.numel(), ptr(g))
-            return None, None, g, None, None
+            return None, None, g, None, None, None
         g = torch.zeros_like(ins_T)
         scale = float(grad_out.item()) / (b * n) if grad_out.numel() == 1 else 1.0 / (b * n)
         if ctx.mode == "atomic":     # the scatter form
@@ -300,7 +301,7 @@ class _ThreeDLossFn(Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=positions.device)
             call("geot_ntm_threed_loss_grad_ws", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
                  ptr(labels), ptr(ins_T), ptr(nbr), ptr(order), ptr(g), ptr(ws), nbytes)
-        return None, None, g, None, None
+        return None, None, g, None, None, None
 
 
 @torch.no_grad()
@@ -334,10 +335,13 @@ class threeD_space_loss(nn.Module):
         _, idx = knn_sorted(positions.contiguous().float(), positions.contiguous().float(), self.k + 1)
         return idx[:, :, 1:].contiguous()
 
-    def forward(self, positions, labels, ins_T, nbr=None):
+    def forward(self, positions, labels, ins_T, nbr=None, order=None):
+        """nbr / order: the kNN graph (self.neighbours) and the processing order (spatial_order) of `positions`
+        when the caller has already computed them -- e.g. on a side stream, beside the segmentor's own work: they
+        depend on the coordinates only."""
         if nbr is None:
             nbr = self.neighbours(positions)
-        return _ThreeDLossFn.apply(positions, labels.to(torch.int32), ins_T, nbr, self.sigma)
+        return _ThreeDLossFn.apply(positions, labels.to(torch.int32), ins_T, nbr, self.sigma, order)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -100,14 +100,36 @@ class NtmHotPath(torch.nn.Module):
         self.sigma = torch.nn.Parameter(torch.ones(num_classes))
         self.register_buffer("ema_t", torch.eye(num_classes) * 0.9 + 0.1 / num_classes)
         self.register_buffer("cm", torch.eye(num_classes) * 0.9 + 0.1 / num_classes)
+        self.overlap = os.environ.get("GEOT_NTM_OVERLAP", "1") != "0"
+        self.overlap_min_points = int(os.environ.get("GEOT_NTM_OVERLAP_MIN", "60000"))
+        self._side = None
 
     def forward(self, raw_pos, pred_weak, pred_strong):
+        # The kNN graph and the processing order depend on the coordinates only: they are built on a second HIP
+        # stream beside the soft-max / class-transition / per-point-matrix / correction chain (the kNN search is
+        # latency-bound, that chain HBM-bound: together they fill the chip better than one after the other).
+        nbr = order = None
+        big = raw_pos.shape[0] * raw_pos.shape[1] >= self.overlap_min_points   # launch-bound below: the stream hand-offs cost more than they hide
+        if self.overlap and big:
+            dev = raw_pos.device
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                nbr = self.loss3d.neighbours(raw_pos)
+                order = ntm_mod.spatial_order(raw_pos)
         eta = torch.softmax(pred_weak.detach(), dim=1)
         _, label_u = torch.max(eta, dim=1)
         ema_corr, ema_next, _, _ = ntm_mod.class_transition(eta, self.sigma, self.ema_t)
         ins_t = self.predictor(torch.softmax(pred_strong, dim=1).detach(), self.cm)
         corr = ntm_mod.correct_logits(pred_strong, ins_t, ema_corr, 0.9)
-        loss3d = self.loss3d(raw_pos, label_u, ins_t) * 0.1
+        if nbr is not None:
+            main.wait_stream(self._side)
+            nbr.record_stream(main)
+            if order is not None:
+                order.record_stream(main)
+        loss3d = self.loss3d(raw_pos, label_u, ins_t, nbr=nbr, order=order) * 0.1
         self.ema_t.copy_(ema_next.detach())
         return corr, loss3d
 
