@@ -102,6 +102,7 @@ class NtmHotPath(torch.nn.Module):
         self.register_buffer("cm", torch.eye(num_classes) * 0.9 + 0.1 / num_classes)
         self.overlap = os.environ.get("GEOT_NTM_OVERLAP", "1") != "0"
         self.overlap_min_points = int(os.environ.get("GEOT_NTM_OVERLAP_MIN", "60000"))
+        self.overlap_loss = os.environ.get("GEOT_NTM_OVERLAP_LOSS", "1") != "0"
         self._side = None
 
     def forward(self, raw_pos, pred_weak, pred_strong):
@@ -123,6 +124,20 @@ class NtmHotPath(torch.nn.Module):
         _, label_u = torch.max(eta, dim=1)
         ema_corr, ema_next, _, _ = ntm_mod.class_transition(eta, self.sigma, self.ema_t)
         ins_t = self.predictor(torch.softmax(pred_strong, dim=1).detach(), self.cm)
+        if nbr is not None and self.overlap_loss:
+            # ... and the graph loss itself stays on that stream: its forward runs beside the logit correction, and --
+            # autograd replays every node on its forward stream -- its L2-bound gradient gather beside the HBM-bound
+            # correction backward.  The two meet again in the per-point-matrix backward (sum of both ins_T gradients).
+            self._side.wait_stream(main)                  # ins_t, label_u
+            ins_t.record_stream(self._side)
+            label_u.record_stream(self._side)
+            with torch.cuda.stream(self._side):
+                loss3d = self.loss3d(raw_pos, label_u, ins_t, nbr=nbr, order=order) * 0.1
+            corr = ntm_mod.correct_logits(pred_strong, ins_t, ema_corr, 0.9)
+            main.wait_stream(self._side)
+            loss3d.record_stream(main)
+            self.ema_t.copy_(ema_next.detach())
+            return corr, loss3d
         corr = ntm_mod.correct_logits(pred_strong, ins_t, ema_corr, 0.9)
         if nbr is not None:
             main.wait_stream(self._side)

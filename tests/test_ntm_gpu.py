@@ -243,3 +243,35 @@ def test_ntm_step_composition():
     assert all(l.weight.grad is not None and torch.isfinite(l.weight.grad).all() for l in predictor.T_predictor.fc)
     assert sigma.grad.abs().sum() > 0 and pred_strong.grad.abs().sum() > 0
     assert ema_next.shape == (C, C)
+
+
+def test_ntm_workload_two_stream_schedule_gives_the_same_step(monkeypatch):
+    """workloads.NtmHotPath builds the kNN graph / processing order on a second HIP stream and keeps the graph
+    loss (forward and, through autograd's stream replay, backward) there: loss and every gradient must equal the
+    single-stream schedule's (atomics reorder a few float adds: 1e-5)."""
+    from geot_amd import workloads as wl
+    from geot_amd.synth import make_logits
+    xyz_np = make_batch(3, 6000, start_index=11)[0]
+    xyz = T(xyz_np)
+    pw, ps = T(make_logits(xyz_np, 0)), T(make_logits(xyz_np, 1, sharp=3.0))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GEOT_NTM_OVERLAP", mode)
+        monkeypatch.setenv("GEOT_NTM_OVERLAP_MIN", "1")
+        torch.manual_seed(0)
+        nt = wl.NtmHotPath().to(DEV)
+        assert nt.overlap == (mode == "1")
+        strong = ps.clone().requires_grad_(True)
+        for _ in range(2):          # second step: ema_t has moved, streams are warm
+            corr, loss3d = nt(xyz, pw, strong)
+            loss = corr.square().mean() + loss3d
+            nt.zero_grad(set_to_none=True)
+            strong.grad = None
+            loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (loss.item(), strong.grad.clone(), nt.sigma.grad.clone(),
+                     torch.stack([l.weight.grad for l in nt.predictor.T_predictor.fc]).clone(), nt.ema_t.clone())
+    a, b = res["0"], res["1"]
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0])
+    for x, y in zip(a[1:], b[1:]):
+        np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(x.abs().max()) + 1e-12)
