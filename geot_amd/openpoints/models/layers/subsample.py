@@ -11,32 +11,32 @@ from ...cpp import pointnet2_cuda
 
 
 class BaseSampler(ABC):
-    """subsample.py:11-50: sample exactly num_to_sample points, or floor(N * ratio)."""
+    """subsample.py:11-50: a sampler is configured by exactly one of num_to_sample (that many points), ratio
+    (floor(N * ratio) points) or subsampling_param; num_to_sample excludes the other two."""
 
     def __init__(self, ratio=None, num_to_sample=None, subsampling_param=None):
-        if num_to_sample is not None:
-            if ratio is not None or subsampling_param is not None:
-                raise ValueError("Can only specify ratio or num_to_sample or subsampling_param, not several !")
-            self._num_to_sample = num_to_sample
-        elif ratio is not None:
-            self._ratio = ratio
-        elif subsampling_param is not None:
-            self._subsampling_param = subsampling_param
-        else:
+        given = [(name, value) for name, value in (("_num_to_sample", num_to_sample), ("_ratio", ratio),
+                                                   ("_subsampling_param", subsampling_param)) if value is not None]
+        if not given:
             raise Exception('At least ["ratio, num_to_sample, subsampling_param"] should be defined')
+        if num_to_sample is not None and len(given) > 1:
+            raise ValueError("Can only specify ratio or num_to_sample or subsampling_param, not several !")
+        setattr(self, *given[0])        # same precedence as the reference: num_to_sample, ratio, subsampling_param
 
     def __call__(self, xyz):
         return self.sample(xyz)
 
     def _get_num_to_sample(self, npoints) -> int:
-        return self._num_to_sample if hasattr(self, "_num_to_sample") else math.floor(npoints * self._ratio)
+        fixed = getattr(self, "_num_to_sample", None)
+        return fixed if fixed is not None else math.floor(npoints * self._ratio)
 
     def _get_ratio_to_sample(self, batch_size) -> float:
-        return self._ratio if hasattr(self, "_ratio") else self._num_to_sample / float(batch_size)
+        ratio = getattr(self, "_ratio", None)
+        return ratio if ratio is not None else self._num_to_sample / float(batch_size)
 
     @abstractmethod
     def sample(self, xyz, feature=None, batch=None):
-        pass
+        ...
 
 
 class RandomSample(BaseSampler):
