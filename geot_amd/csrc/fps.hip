@@ -684,7 +684,10 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
                 bool conflict = false;
                 if (cs < ct && ct < nvalid && ct < TMAX) {
                     const float d = sqdist3(b_x, b_y, b_z, a_x, a_y, a_z); // point first, sample second: as the update
-                    conflict = !(__float_as_int(d) >= Mt && d >= 0.f) || !(a_v2 < Mt);
+                    // Mt <= 0: a candidate whose min-distance is exactly 0 (every valid point already sampled) ties with
+                    // the sample committed before it, which keeps its smaller key and is picked AGAIN by the sequential
+                    // algorithm -- so nothing may be committed behind it
+                    conflict = !(__float_as_int(d) >= Mt && d >= 0.f) || !(a_v2 < Mt) || Mt <= 0;
                 }
                 const unsigned long long cmask = __ballot(conflict);
                 int tn = 1;

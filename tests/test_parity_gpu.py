@@ -721,3 +721,20 @@ def test_three_nn_with_fewer_than_three_known_points(ext, oracle, m):
     wd, wi = oracle.three_nn(q, k)
     assert np.array_equal(host(idx), wi) and np.array_equal(host(d2), wd)
     assert np.isinf(host(d2)[:, :, m:]).all() and (host(idx)[:, :, m:] == 0).all()
+
+
+def test_fps_exhausted_valid_points_repeat_the_smallest_key(ext, oracle, fps_impl):
+    """Found by tools/fuzz_parity.py (seed 7, case 57): a cloud whose points almost all fall inside the K1 kernel's
+    origin-skip ball has fewer valid points than samples; once they are exhausted every min-distance is 0 and the
+    reference picks the smallest-key point again and again.  With one valid point per wave the multi-commit
+    resolve used to commit the next wave's zero-valued candidate behind it."""
+    rng = np.random.default_rng(7 * 100003 + 57)
+    xyz = (rng.standard_normal((3, 2500, 3)) * 0.01).astype(np.float32)
+    assert ((xyz ** 2).sum(-1) > 1e-3).sum(1).max() < 100
+    assert np.array_equal(fps_k1(ext, xyz, 279), oracle.fps_dense(xyz, 279, 512, True))
+    # the same situation spread thinly: exactly one valid point in a few waves' share of the sorted cloud
+    xyz2 = np.zeros((2, 3000, 3), dtype=np.float32)
+    far = rng.choice(3000, 9, replace=False)
+    xyz2[:, far] = (rng.random((2, 9, 3)).astype(np.float32) + 0.5)
+    got = fps_k1(ext, xyz2, 40)
+    assert np.array_equal(got, oracle.fps_dense(xyz2, 40, 512, True))
