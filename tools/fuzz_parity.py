@@ -4,7 +4,7 @@
 
 Random batch sizes, point counts (1 .. a few thousand, ragged segments for the offset-batched ops), sample
 counts above and below n, radii / nsample / k over their whole range, point sets with duplicates, lattice
-ties, collinear and coplanar clouds; every implementation switch (GEOT_FPS_IMPL multi|single|basic,
+ties, collinear and coplanar clouds, clouds with fewer valid / distinct points than samples; every implementation switch (GEOT_FPS_IMPL multi|single|basic,
 GEOT_NN_IMPL grid|wave|basic).  Every output must be bit-identical to the oracle's.  Prints one line per op
 and exits non-zero on the first mismatch (the failing case is printed with its seed).
 """
@@ -29,7 +29,7 @@ def dev(a, dt=None):
 
 
 def cloud(rng, b, n):
-    kind = rng.integers(0, 6)
+    kind = rng.integers(0, 8)
     if kind == 0:
         p = rng.random((b, n, 3))
     elif kind == 1:                                   # lattice: exact distance ties
@@ -42,8 +42,15 @@ def cloud(rng, b, n):
     elif kind == 4:                                   # a plane + an outlier
         p = rng.random((b, n, 3)) * np.array([1.0, 1.0, 0.0])
         p[:, 0] = 40.0
-    else:                                             # tight clusters around the origin (K1 origin-skip rule)
+    elif kind == 5:                                   # tight clusters around the origin (K1 origin-skip rule)
         p = rng.standard_normal((b, n, 3)) * 0.01
+    elif kind == 6:                                   # almost everything AT the origin, a handful of valid points:
+        p = np.zeros((b, n, 3))                       # fewer valid points than samples (exhaustion, repeated picks)
+        far = rng.choice(n, min(n, int(rng.integers(1, 60))), replace=False)
+        p[:, far] = rng.random((b, len(far), 3)) + 0.5
+    else:                                             # few distinct locations, each many times over
+        d = int(rng.integers(2, 50))
+        p = rng.random((b, d, 3))[:, rng.integers(0, d, n)]
     return p.astype(np.float32)
 
 
