@@ -78,7 +78,7 @@ def main():
         xyz = cloud(rng, b, n)
         info = "case %d seed %d b %d n %d" % (case, a.seed, b, n)
         # ---- FPS, the three rule sets, the three kernels
-        m = int(rng.integers(1, n + 6)) if n < 600 else int(rng.integers(1, 400))
+        m = int(rng.integers(1, n + 6)) if (n < 600 or (n <= 2500 and rng.random() < 0.3)) else int(rng.integers(1, 400))
         for impl in ("multi", "single", "basic"):
             os.environ["GEOT_FPS_IMPL"] = impl
             check("fps_k1/" + impl, p2.furthest_point_sampling(dev(xyz), m).cpu().numpy(), capi.fps_dense(xyz, m, 512, True), info)
@@ -88,7 +88,8 @@ def main():
             check("fps_k1p/" + impl, out.cpu().numpy(), capi.fps_dense(xyz, m, 1024, False), info)
             sizes, off = ragged(rng, b, 1, n)
             flat = np.concatenate([xyz[i, :sizes[i]] for i in range(b)])
-            msz = np.array([int(rng.integers(1, s + 3)) if s < 600 else int(rng.integers(1, 300)) for s in sizes])
+            msz = np.array([int(rng.integers(1, s + 3)) if (s < 600 or (s <= 2500 and rng.random() < 0.3)) else int(rng.integers(1, 300))
+                            for s in sizes])
             noff = np.cumsum(msz).astype(np.int32)
             w = (0.5 + rng.random(len(flat))).astype(np.float32) if rng.random() < 0.5 else None
             idx = torch.full((int(noff[-1]),), -7, dtype=torch.int32, device=DEV)
