@@ -10,21 +10,32 @@ from geot_amd.synth import make_cloud  # noqa: E402
 from geot_amd.knn_cuda import knn_sorted  # noqa: E402
 from geot_amd.ext import pointnet2_ext as p2  # noqa: E402
 
-rng = np.random.default_rng(7)
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--seed", type=int, default=7)
+ap.add_argument("--trials", type=int, default=12)
+args = ap.parse_args()
+rng = np.random.default_rng(args.seed)
 bad = 0
-for trial in range(12):
+for trial in range(args.trials):
     n = int(rng.choice([5000, 12000, 24000]))
-    B = 4
+    B = 6
     clouds = []
     for i in range(B):
-        x = make_cloud(n, 1000 + trial * 10 + i, dup_frac=0.02 * (i % 2))[0]
+        x = make_cloud(n, 1000 * args.seed + trial * 10 + i, dup_frac=0.02 * (i % 2))[0]
         if i == 1:
             x = x * np.array([1.0, 1.0, 0.02], np.float32)          # nearly flat
         if i == 2:
             x = (x * 64).round() / 64                               # quantised: many exact ties
         if i == 3:
             x[: n // 3] *= 0.05                                      # a dense core
-        clouds.append(x.astype(np.float32))
+        if i == 4:                                                   # few distinct locations: more coincident points
+            d = int(rng.integers(20, 400))                           # than any k, every distance tied many times
+            x = x[rng.integers(0, d, n)]
+        if i == 5:                                                   # one tight blob + a few far outliers: one cell
+            x = x * 1e-3                                             # holds nearly everything
+            x[rng.integers(0, n, 5)] += 3.0
+        clouds.append(np.ascontiguousarray(x, dtype=np.float32))
     ref = torch.from_numpy(np.stack(clouds)).cuda()
     q = torch.cat([ref[:, : n // 2], ref[:, : 500] * 1.7 + 0.01], 1).contiguous()
     for k in (3, 8, 33, 48, 64):
