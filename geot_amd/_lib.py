@@ -54,6 +54,7 @@ PROTOTYPES.update({
     "geot_three_nn_ws": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_graph_feature": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_graph_feature_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_class_anchors": [_c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
     "geot_ntm_class_transition": [_c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_class_transition_grad": [_c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean_grad_w": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_void_p],

@@ -835,6 +835,56 @@ __global__ __launch_bounds__(256) void tl_overflow_kernel(int cap, float gscale,
     }
 }
 
+// ---- class anchors (train.py:505-526): for every class cc the point with the largest eta[b, cc, n] -- the FIRST
+// maximum in flattened (b, n) order, as torch.argmax / the reference's loop pick it -- and that point's whole
+// soft-max row: class_T[cc][:] = eta[b*, :, n*].  One workgroup per class scans the B*N values (coalesced along n),
+// replaces ~6 torch launches (argmax, gathers, advanced indexing).  v_star (nullable): the maxima themselves.
+__global__ __launch_bounds__(1024) void class_anchor_kernel(int b, int n, int c, const float *__restrict__ eta,
+                                                            float *__restrict__ class_T, float *__restrict__ v_star)
+{
+    __shared__ float sv[16];
+    __shared__ long long si[16];
+    __shared__ long long win;
+    const int cc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long total = (long long)b * n;
+    float bv = -INFINITY;
+    long long bi = -1;          // flat (b, n) index; NaN never wins (torch.argmax would return a NaN's position:
+                                // soft-max outputs of finite logits have none)
+    for (long long f = tid; f < total; f += 1024) {
+        const int bb = (int)(f / n);
+        const float v = eta[((size_t)bb * c + cc) * n + (f - (long long)bb * n)];
+        if (bi < 0 || v > bv) { bv = v; bi = f; }   // ascending f per thread: the first maximum is kept
+    }
+    // wave reduce by (value desc, index asc)
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const long long oi = __shfl_xor(bi, o);
+        const bool take = oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi));
+        bv = take ? ov : bv;
+        bi = take ? oi : bi;
+    }
+    if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float v = sv[0];
+        long long i = si[0];
+        for (int w = 1; w < 16; ++w) {
+            const bool take = si[w] >= 0 && (i < 0 || sv[w] > v || (sv[w] == v && si[w] < i));
+            v = take ? sv[w] : v;
+            i = take ? si[w] : i;
+        }
+        win = i;
+        if (v_star) v_star[cc] = v;
+    }
+    __syncthreads();
+    const long long w = win;
+    if (tid < c && w >= 0) {
+        const int bb = (int)(w / n);
+        class_T[cc * c + tid] = eta[((size_t)bb * c + tid) * n + (w - (long long)bb * n)];
+    }
+}
+
 // ---- class-level transition block (train.py:505-557 after the anchor rows are known) -----------
 //   P0[r][k] = gauss(proj[k]; mu = proj[r], s = sigma[r]);  A = P0 with row 0 := e_0 and column 0 := 0 below it
 //   B = A / rowsum(A)[k]        (the reference's `X / X.sum(1)`: column k is divided by ROW-sum k)
@@ -1036,6 +1086,13 @@ GEOT_EXPORT int geot_ntm_correct_grad(int b, int n, int c, float lam, const floa
     hipLaunchKernelGGL((ntm_correct_kernel<C, true>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
                        (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, grad_out, nullptr,
                        grad_logits, grad_ins_T, grad_ema_t, nullptr);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_ntm_class_anchors(int b, int n, int c, const float *eta, float *class_T, float *v_star, void *stream)
+{
+    if (b < 1 || n < 1 || c < 1 || c > 1024 || !eta || !class_T) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(class_anchor_kernel, dim3(c), dim3(1024), 0, (hipStream_t)stream, b, n, c, eta, class_T, v_star);
     return hipGetLastError();
 }
 

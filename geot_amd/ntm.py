@@ -180,6 +180,20 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group
     the last axis, i.e. divides column j by row-sum j)."""
     B, C, N = eta.shape
     eta = eta.detach()
+    fused = eta.is_cuda and C <= 32 and eta.dtype == torch.float32 and os.environ.get("GEOT_NTM_CT", "fused") == "fused"
+    if fused:      # anchors in one launch (+ the transition block in another) instead of ~6 + ~40 torch launches
+        eta_c = eta.contiguous()
+        class_T = torch.empty((C, C), dtype=torch.float32, device=eta.device)
+        v_star = torch.empty(C, dtype=torch.float32, device=eta.device)
+        call("geot_ntm_class_anchors", eta.device, B, N, C, ptr(eta_c), ptr(class_T), ptr(v_star))
+        if group is not None:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+                class_T = exchange_anchor_rows(v_star, class_T, group)
+        proj, _, _ = _transition_constants(C, eta.dtype, eta.device)
+        ema_t_corr, ema_next, prior_T = _ClassTransitionFn.apply(class_T.contiguous(), sigma, ema_t, proj,
+                                                                 float(geo_lambda), float(ema_decay))
+        return ema_t_corr, ema_next, class_T, prior_T
     # first maximum of class cc over the flattened (b, n) order, without materialising the two (C, B*N) /
     # (B*N, C) transposes the reference builds: arg-max over n per (b, cc), then the first b that attains it
     n_best = torch.argmax(eta, dim=2)                                     # (B, C), first maximum along n
@@ -193,10 +207,6 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             class_T = exchange_anchor_rows(torch.gather(v_best, 0, b_star.unsqueeze(0)).squeeze(0), class_T, group)
     proj, row0, keep = _transition_constants(C, eta.dtype, eta.device)   # cached: no host->device copy per step
-    if eta.is_cuda and C <= 32 and eta.dtype == torch.float32 and os.environ.get("GEOT_NTM_CT", "fused") == "fused":
-        ema_t_corr, ema_next, prior_T = _ClassTransitionFn.apply(class_T.contiguous(), sigma, ema_t, proj,
-                                                                 float(geo_lambda), float(ema_decay))
-        return ema_t_corr, ema_next, class_T, prior_T
     prior_T = gaussian(proj.unsqueeze(0), proj.unsqueeze(1), sigma.unsqueeze(1))   # [cc][k]
     prior_T = torch.cat([row0.unsqueeze(0), prior_T[1:] * keep.unsqueeze(0)], dim=0)  # [:,0]=0; [0,0]=1
     prior_T = prior_T / torch.sum(prior_T, 1)

@@ -242,6 +242,10 @@ int geot_ntm_correct(int b, int n, int c, float lam, const float *logits, const 
 int geot_ntm_correct_grad(int b, int n, int c, float lam, const float *logits, const float *ins_T,
                           const float *ema_t, const float *grad_out, float *grad_logits,
                           float *grad_ins_T, float *grad_ema_t, void *stream);
+/* Class anchors, train.py:505-526: class_T (c,c) row cc = eta[b*, :, n*] of the point with the largest
+ * eta[b, cc, n] (eta (b,c,n) fp32: the weak view's soft-max), the first maximum in flattened (b, n) order as
+ * torch.argmax picks it; v_star (c, nullable) receives the maxima (the multi-rank exchange compares them). */
+int geot_ntm_class_anchors(int b, int n, int c, const float *eta, float *class_T, float *v_star, void *stream);
 /* Class-level transition block, train.py:505-557 once the anchor rows class_T (c,c) are gathered: Gaussian
  * tooth-adjacency prior from sigma (c) over the label projection proj (c) (train.py:48), blend, the three
  * `X / X.sum(1)` normalisations exactly as written there (column k divided by row-sum k), EMA.  c <= 32.

@@ -275,3 +275,38 @@ def test_ntm_workload_two_stream_schedule_gives_the_same_step(monkeypatch):
     assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0])
     for x, y in zip(a[1:], b[1:]):
         np.testing.assert_allclose(y.cpu().numpy(), x.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(x.abs().max()) + 1e-12)
+
+
+def test_class_anchor_kernel_first_maximum_and_rows():
+    """geot_ntm_class_anchors: per class the FIRST maximum over the flattened (b, n) order (exact ties planted within
+    a cloud and across clouds), its value, and the whole soft-max row of that point."""
+    from geot_amd.ext._common import call, ptr
+    rng = np.random.default_rng(9)
+    B, N = 3, 5000
+    eta = _softmax(rng.standard_normal((B, C, N)), 1).astype(np.float32)
+    for cls, spots in ((2, [(0, 4000), (0, 4999), (1, 3)]), (7, [(1, 77), (2, 0)]), (16, [(2, 4999)])):
+        for bb, nn in spots:
+            row = np.full(C, 0.0005, dtype=np.float32)
+            row[cls] = 0.99
+            row[(cls + 1 + nn) % C if (cls + 1 + nn) % C != cls else (cls + 2) % C] = 0.0021   # rows differ
+            eta[bb, :, nn] = row
+    te = T(eta)
+    cT = torch.empty((C, C), device=DEV)
+    vs = torch.empty(C, device=DEV)
+    call("geot_ntm_class_anchors", te.device, B, N, C, ptr(te), ptr(cT), ptr(vs))
+    flat = eta.transpose(1, 0, 2).reshape(C, B * N)
+    first = flat.argmax(1)                                     # numpy: first maximum
+    want = np.stack([eta[f // N, :, f % N] for f in first])
+    assert np.array_equal(cT.cpu().numpy(), want) and np.array_equal(vs.cpu().numpy(), flat.max(1))
+    assert first[2] == 0 * N + 4000 and first[7] == 1 * N + 77
+    # and through the public function, against torch's own op chain
+    from geot_amd.ntm import class_transition
+    import os
+    sig, ema = T(0.5 + rng.random(C)), T(_softmax(rng.standard_normal((C, C)), 1))
+    a = class_transition(te, sig, ema)[2]
+    os.environ["GEOT_NTM_CT"] = "torch"
+    try:
+        b_ = class_transition(te, sig, ema)[2]
+    finally:
+        del os.environ["GEOT_NTM_CT"]
+    assert torch.equal(a, b_)
