@@ -1,27 +1,32 @@
 #!/usr/bin/env python
-"""bench.py -- throughput of the GeoT sampling/grouping hot path on MI355X.
+"""bench.py -- throughput of the GeoT sampling/grouping hot path and of the model that calls it, on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--clouds B] [--workload sa|backbone_ops|ntm]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--clouds B] [--workload model|sa|backbone_ops|ntm|fixmatch]
 
-Workload (default, BASELINE.json configs[1]): one 24 000-point synthetic tooth cloud per
-GPU through a PointNet++ SetAbstraction forward (PointnetSAModuleVotes npoint=6000,
-radius=0.1, nsample=32, mlp=[3,64,64,128], use_xyz) = furthest_point_sample ->
-gather_operation -> ball_query -> fused {group xyz, group features, centre subtraction,
-SharedMLP on fp32 MFMA, max over nsample}, eval mode, inputs resident in HBM.
-One "step" = one such forward over the rank's clouds.  N > 1: one process per GPU
-(torchrun), every rank works on its own clouds (weak scaling, no data-path collective);
-the timed region is bracketed by barrier + synchronize and the max over ranks is used.
+Default workload = BASELINE.json configs[2] (the config the metric "clouds/s ... fwd+bwd" is quoted on):
+B = 8 synthetic 24 000-point tooth clouds per GPU through the configured backbone PointTransformer_seg_T
+(cfgs/tooth_semi/transformer_finetune_fixmatch_ntm.yaml:6-15; random init) -- forward, Poly1FocalLoss, backward,
+gradient all-reduce (N > 1), AdamW step -- fp32 throughout, inputs resident in HBM.  One "step" = one such
+iteration over the rank's clouds.
 
-Other workloads (not the judged default): `--workload backbone_ops` = every sampling / grouping /
-interpolation op of one PointTransformer_seg_T forward+backward at the configs[2] shapes (B=8 clouds
-per GPU unless --clouds; dense layers excluded, see geot_amd/workloads.py); `--workload ntm` = the
-unlabelled half of a FixMatch+NTM step (sig_t_mean, class transition, logit correction, 3-D loss).
+--gpus N > 1 (configs[3]): this script starts N ranks itself (one process per GPU, before the parent touches a
+GPU; under torchrun it uses the ranks it is given), binds rank -> GPU, converts BatchNorm to SyncBatchNorm and
+wraps the model in DistributedDataParallel over backend "nccl" (= RCCL over xGMI) exactly as
+examples/segmentation/train.py:159-166 does; the 108 MB gradient all-reduce is inside the timed step.  The timed
+region is bracketed by barrier + synchronize and the MAX over ranks is used.  Weak scaling: B clouds per rank.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Other workloads: `sa` = configs[1] (one SetAbstraction forward, eval); `backbone_ops` = the hot-path ops of the
+backbone alone (dense layers replaced by nothing); `ntm` = the unlabelled half of the NTM block alone;
+`fixmatch` = configs[4], one full FixMatch+NTM iteration (teacher 2 clouds, student 6 clouds, NTM block, losses,
+both optimisers) per rank.
+
+Prints ONE JSON line on rank 0 (DESIGN.md section 5 explains every field).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,67 +34,66 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 N_POINTS = 24000
 NPOINT, RADIUS, NSAMPLE, MLP = 6000, 0.1, 32, [3, 64, 64, 128]
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector (= fp32 MFMA) rate
-FP32_MATRIX_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (same figure)
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak (no xf32/TF32 on gfx950)
 HBM_PEAK_GBS = 8000.0
 FPS_FLOP_PER_UPDATE = 10          # 3 sub, 3 mul, 2 add, min, compare
+# dense (GEMM) flops of one PointTransformer_seg_T forward per cloud as the REFERENCE executes it
+DENSE_GFLOP_FWD_REFERENCE = 204.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--clouds", type=int, default=None, help="clouds per GPU per step (sa: 1, backbone_ops/ntm: 8)")
-    ap.add_argument("--workload", choices=["sa", "backbone_ops", "ntm"], default="sa")
+    ap.add_argument("--clouds", type=int, default=None,
+                    help="clouds per GPU per step (model/backbone_ops/ntm: 8, sa: 1, fixmatch: 2 labelled + 2 unlabelled)")
+    ap.add_argument("--workload", choices=["model", "sa", "backbone_ops", "ntm", "fixmatch"], default="model")
+    ap.add_argument("--dense", choices=["factored", "reference"], default=None,
+                    help="model: how the first 1x1 conv behind a gather is evaluated (see transformer.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams the steps are dealt to round-robin (default 1 = strictly one after the other; "
-                         "2 lets step i+1's FPS, which occupies one CU per cloud, run beside step i's ball query + MLP)")
+    ap.add_argument("--streams", type=int, default=1, help="sa only: HIP streams the steps are dealt to")
     return ap.parse_args()
 
 
-def build_module(device):
-    from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
-    torch.manual_seed(1609)
-    sa = PointnetSAModuleVotes(mlp=list(MLP), npoint=NPOINT, radius=RADIUS, nsample=NSAMPLE, use_xyz=True)
-    return sa.to(device).eval()
+# ---------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (children of a parent that has NOT touched the
+    GPU), rank r -> GPU r, rendezvous on 127.0.0.1; rank 0 prints the JSON line; exit with the worst code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), GEOT_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        for p in procs:
+            worst = max(worst, abs(p.wait()))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of THIS command
-    (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes, FETCH
-    doubled as MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read from inside the
-    process, so the figure is the profiled one, not a live one; None if no profile is committed."""
-    import glob
-    here = os.path.dirname(os.path.abspath(__file__))
-    import re
-    files = sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")),
-                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])   # r01 ... v11 after v7
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        prof = json.load(f)
-    for name, rec in prof.get("kernels", {}).items():
-        if kernel in name:
-            return rec.get("traffic_bytes")
-    return None
-
-
-class FpsTimer:
-    """HIP events around the dominant kernel (FPS) on the stream it is launched on
-    (torch's current stream, which is where the C ABI launcher puts it)."""
+class EventTimer:
+    """HIP events around one call, recorded on the stream that is current at the call (the C ABI and torch both
+    launch there -- inside `with torch.cuda.stream(side)` that is the side stream)."""
 
     def __init__(self):
         self.pairs = []
 
     def wrap(self, fn):
+        import torch
+
         def timed(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -99,18 +103,57 @@ class FpsTimer:
             return out
         return timed
 
+    def hook(self, module):
+        import torch
+
+        def pre(mod, inp):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            mod._geot_e0 = e0
+
+        def post(mod, inp, out):
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            self.pairs.append((mod._geot_e0, e1))
+        return [module.register_forward_pre_hook(pre), module.register_forward_hook(post)]
+
     def mean_ms(self):
+        import numpy as np
         return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
 
 
-def cpu_baseline(xyz_np, feats_np, sa_cpu, steps):
-    """The CPU port of the same step: oracle (C restatement, OpenMP over all host cores) for
-    FPS / ball query / grouping + the same SharedMLP on torch-CPU.  Checker code, used here
-    only as the reported baseline, never as the thing shipped."""
+def pmc_traffic(kernel, tag):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this command
+    (profiles/*<tag>*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, FETCH doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  Counters cannot be read in-process: the figure is the profiled
+    one; `source` names the file and the commit it was taken at so a stale figure is visible."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s*_pmc_traffic.json" % tag)),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        prof = json.load(f)
+    for name, rec in prof.get("kernels", {}).items():
+        if kernel in name:
+            return rec.get("traffic_bytes"), {"file": os.path.relpath(files[-1], ROOT), "commit": prof.get("commit")}
+    return None, None
+
+
+def affinity_cores(cap=16):
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return min(cap, n)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def cpu_baseline_sa(xyz_np, feats_np, sa_cpu, steps):
+    """configs[1] on the host: oracle (C restatement, OpenMP) for FPS / ball query / grouping + the same SharedMLP
+    on torch-CPU.  Checker code, used here only as the reported baseline."""
+    import numpy as np
+    import torch
     from oracle import capi
-    # the GPU box gives a one-GPU job a 16-core share; use what the affinity mask allows up to that
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    cores = capi.set_threads(cores)
+    cores = capi.set_threads(affinity_cores())
     torch.set_num_threads(cores)
 
     def one():
@@ -131,42 +174,149 @@ def cpu_baseline(xyz_np, feats_np, sa_cpu, steps):
     dt = time.perf_counter() - t0
     return {"value": xyz_np.shape[0] * steps / dt, "unit": "clouds/s", "cores": cores, "kind": "port",
             "sample": "%d SetAbstraction forwards of %d cloud(s) x %d pts (oracle C/OpenMP FPS+ball_query+group, "
-                      "torch-CPU SharedMLP+max; FPS rounds are sequential so its share runs on 1 thread per cloud), %.1f s" % (steps, xyz_np.shape[0], N_POINTS, dt)}
+                      "torch-CPU SharedMLP+max), %.1f s" % (steps, xyz_np.shape[0], N_POINTS, dt)}
+
+
+def cpu_baseline_model():
+    """configs[2] on the host, bounded sample: ONE fwd+loss+bwd+AdamW step of the same PointTransformer_seg_T over
+    2 clouds x 24 000 points on torch-CPU, the sampling / grouping ops (a) from the reference's own pure-torch
+    fallbacks (pointmlp.py:45-143 + layers/knn.py:7-20, restated in oracle/torch_cpu_ref.py) = "reference-fallback",
+    (b) from the C/OpenMP oracle = "port"."""
+    import torch
+    from oracle import torch_cpu_ref
+    cores = affinity_cores()
+    v_ref, t_ref = torch_cpu_ref.time_model_step("reference-fallback", 2, N_POINTS, cores)
+    v_port, t_port = torch_cpu_ref.time_model_step("port", 2, N_POINTS, cores)
+    return {"value": v_ref, "unit": "clouds/s", "cores": cores, "kind": "reference-fallback",
+            "torch": torch.__version__,
+            "sample": "1 step (fwd + Poly1Focal + bwd + AdamW) of PointTransformer_seg_T on 2 clouds x %d pts, torch-CPU "
+                      "dense layers, hot-path ops = the reference's torch fallbacks (pointmlp.py:45-143, knn.py:7-20), "
+                      "%.1f s" % (N_POINTS, t_ref),
+            "port": {"value": v_port, "unit": "clouds/s", "cores": cores, "kind": "port",
+                     "sample": "same step, index-producing ops from the C/OpenMP oracle (exact CUDA semantics), %.1f s" % t_port}}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def hot_path_attribution(step, steps=2):
+    """Run `steps` extra (untimed) steps with HIP events around every C-ABI launch: per-entry-point GPU time.
+    Returns {entry: ms per step}.  Overlapped launches (side streams) are counted at their own duration."""
+    import torch
+    from geot_amd.ext import _common
+    rec = {}
+
+    def bracket(launch, name):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        rec.setdefault(name, []).append((e0, e1))
+    _common.trace = bracket
+    try:
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+    finally:
+        _common.trace = None
+    return {k: sum(a.elapsed_time(b) for a, b in v) / steps for k, v in rec.items()}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
+    import torch
     from geot_amd import dist_utils
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     world, rank, local = dist_utils.env_world()
     # GEOT_BENCH_REHEARSAL=1: N ranks share GPU 0 and talk over gloo -- rehearses the N > 1 control flow
-    # (rendezvous, barriers, MAX over ranks, rank-0 JSON) on a one-GPU box; never a measurement
+    # (spawn, rendezvous, DDP all-reduce, barriers, MAX over ranks, rank-0 JSON) on a one-GPU box; never a measurement
     rehearsal = os.environ.get("GEOT_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
+    elif world > 1 and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (GEOT_BENCH_REHEARSAL=1 rehearses the control "
+                         "flow on one GPU over gloo)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist_utils.init("gloo" if rehearsal else "nccl")
 
     from geot_amd import _lib, build as hip_build
-    from geot_amd.synth import make_batch
-    from geot_amd.pointnet2 import pointnet2_utils
-    if not os.path.exists(hip_build.LIB) and rank == 0:      # fresh checkout: built artefacts are git-ignored
-        hip_build.build()
+    from geot_amd.synth import make_batch, region_labels
+    if rank == 0:
+        hip_build.build()          # mtime-incremental; a stale git-ignored .so must not be loaded as-is
     dist_utils.barrier()
     _lib.load()
 
     workload = args.workload
-    B = args.clouds if args.clouds is not None else (1 if workload == "sa" else 8)
+    default_b = {"sa": 1, "fixmatch": 2}.get(workload, 8)
+    B = args.clouds if args.clouds is not None else default_b
+    clouds_per_step = B
     xyz_np, _ = make_batch(B, N_POINTS, start_index=dist_utils.cloud_range(rank, B)[0])
     xyz = torch.from_numpy(xyz_np).to(dev)
-    timer = FpsTimer()
-    feats_np = sa = None
-    if workload == "sa":
+    fps_timer, gemm_timer, mlp_timer = EventTimer(), EventTimer(), EventTimer()
+    feats_np = sa = model = None
+    patch_owner = patch_name = None
+    unpatch = []
+    fps_rounds = 0
+    parallelism = "independent clouds per rank, no collective"
+
+    if workload == "model":
+        from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T, TOOTH_SEG_CFG
+        from geot_amd import train_step as ts
+        from geot_amd.pointops.functions import pointops as pops
+        torch.manual_seed(1609)
+        model = PointTransformer_seg_T(**TOOTH_SEG_CFG, dense=args.dense).to(dev)
+        dense_mode = model.dense
+        net = ts.ddp(model, dev, unused=ts.UNUSED_SUPERVISED)
+        trainer = ts.SupervisedStep(net)
+        target = torch.from_numpy(region_labels(xyz_np)).to(dev)
+        cls = torch.from_numpy(np.random.default_rng(1609 + rank).integers(0, 2, size=(B, 1))).to(dev)
+        patch_owner, patch_name = pops, "furthestsampling_uniform"
+        fps_rounds = max(TOOTH_SEG_CFG["downsample_targets"]) - 1
+        desc = ("configs[2]: B=%d x 24k-pt clouds, full transformer_finetune backbone PointTransformer_seg_T "
+                "(trans_dim 384, depth 12, 512 groups x 32, targets 8192/4096/2048) fwd + Poly1FocalLoss + bwd + AdamW, "
+                "train mode, random init" % B) if world == 1 else \
+               ("configs[3]: data-parallel %d x (B=%d x 24k-pt clouds), same model; SyncBatchNorm + DDP gradient "
+                "all-reduce over %s" % (world, B, "gloo (rehearsal)" if rehearsal else "RCCL"))
+        if world > 1:
+            parallelism = "dp%d: DistributedDataParallel (25 MB buckets, overlapped with backward) + SyncBatchNorm" % world
+        unpatch += gemm_timer.hook(model.propogation_0.mlp.layer1.conv)
+
+        def step():
+            return trainer(xyz, cls, target)
+    elif workload == "fixmatch":
+        from geot_amd import train_step as ts
+        torch.manual_seed(1609)
+        trainer = ts.build_fixmatch(dev, use_ddp=True,
+                                    group=torch.distributed.group.WORLD if world > 1 else None)
+        bl = bu = B
+        clouds_per_step = bl + bu
+        xyz_u_np, _ = make_batch(bu, N_POINTS, start_index=10_000 + dist_utils.cloud_range(rank, bu)[0])
+        xyz_u = torch.from_numpy(xyz_u_np).to(dev)
+        rng = np.random.default_rng(1609 + rank)
+        strong = (xyz_u * torch.from_numpy(rng.uniform(0.8, 1.2, size=(bu, 1, 3)).astype(np.float32)).to(dev)).contiguous()
+        data = {"pos": xyz, "x": xyz.transpose(1, 2).contiguous(), "cls": torch.zeros(bl, 1, dtype=torch.long, device=dev),
+                "y": torch.from_numpy(region_labels(xyz_np)).to(dev)}
+        data_u = {"pos_w": xyz_u, "x_w": xyz_u.transpose(1, 2).contiguous(), "cls_w": torch.zeros(bu, 1, dtype=torch.long, device=dev),
+                  "pos_s": strong, "x_s": strong.transpose(1, 2).contiguous(), "cls_s": torch.zeros(bu, 1, dtype=torch.long, device=dev),
+                  "raw_pos": xyz_u}
+        desc = ("configs[4]: FixMatch+NTM semi-supervised step per rank: teacher fwd on %d weak clouds, student fwd+bwd on "
+                "%d labelled + %d strong + %d weak clouds x 24k pts, class transition + sig_t_mean + logit correction + "
+                "threeD_space_loss(k=32) + Poly1Focal losses, AdamW x2" % (bu, bl, bu, bu))
+        if world > 1:
+            parallelism = "dp%d: DDP(student) + DDP(T_predictor) + SyncBatchNorm + all-gather of the class anchors" % world
+
+        def step():
+            return trainer(data, data_u)["loss"]
+    elif workload == "sa":
+        from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+        import geot_amd.pointnet2.pointnet2_modules as mods
         feats_np = np.random.default_rng(1609 + rank).standard_normal((B, MLP[0], N_POINTS)).astype(np.float32)
         feats = torch.from_numpy(feats_np).to(dev)
-        sa = build_module(dev)
-        import geot_amd.pointnet2.pointnet2_modules as mods
+        torch.manual_seed(1609)
+        sa = PointnetSAModuleVotes(mlp=list(MLP), npoint=NPOINT, radius=RADIUS, nsample=NSAMPLE, use_xyz=True).to(dev).eval()
         patch_owner, patch_name = mods.pointnet2_utils, "furthest_point_sample"
         fps_rounds, desc = NPOINT - 1, ("configs[1]: PointNet++ SetAbstraction fwd (FPS 24000->6000, ball_query r=0.1 "
                                         "ns=32, group, SharedMLP [6,64,64,128], max), eval")
@@ -187,15 +337,12 @@ def main():
             return wl.backbone_hotpath_step(hot, xyz, tokens)
     else:
         from geot_amd import workloads as wl
-        from geot_amd import knn_cuda as kmod
-        nt = wl.NtmHotPath().to(dev)
         from geot_amd.synth import make_logits
-        # spatially coherent predictions (weak and strong view of the same regions), see synth.region_labels
+        nt = wl.NtmHotPath().to(dev)
         pw = torch.from_numpy(make_logits(xyz_np, index=2 * rank)).to(dev)
         ps = torch.from_numpy(make_logits(xyz_np, index=2 * rank + 1, sharp=3.0)).to(dev)
-        patch_owner, patch_name = None, None
-        fps_rounds, desc = 0, ("configs[4] NTM half-step: sig_t_mean + class transition + logit correction + "
-                               "threeD_space_loss(k=32) fwd+bwd on B_u clouds")
+        desc = ("configs[4] NTM half-step: sig_t_mean + class transition + logit correction + "
+                "threeD_space_loss(k=32) fwd+bwd on B_u clouds")
 
         def step():
             return wl.ntm_step(nt, xyz, pw, ps)
@@ -204,8 +351,7 @@ def main():
         step()
     if patch_owner is not None:
         orig_fn = getattr(patch_owner, patch_name)
-        setattr(patch_owner, patch_name, timer.wrap(orig_fn))
-    mlp_timer = FpsTimer()
+        setattr(patch_owner, patch_name, fps_timer.wrap(orig_fn))
     if workload == "sa":
         import geot_amd.sa_fused as sa_fused_mod
         orig_mlp = sa_fused_mod.fused_group_mlp_max
@@ -214,7 +360,7 @@ def main():
     dist_utils.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if args.streams > 1:
+    if args.streams > 1 and workload == "sa":
         pool = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
         for i in range(args.steps):
             with torch.cuda.stream(pool[i % args.streams]):
@@ -230,56 +376,94 @@ def main():
         setattr(patch_owner, patch_name, orig_fn)
     if workload == "sa":
         sa_fused_mod.fused_group_mlp_max = orig_mlp
+    for h in unpatch:
+        h.remove()
     elapsed = dist_utils.max_over_ranks(elapsed, "cpu" if rehearsal else dev)
     assert torch.isfinite(out).all()
 
-    fps_ms = timer.mean_ms()
+    ms_per_step = 1e3 * elapsed / args.steps
+    fps_ms = fps_timer.mean_ms()
     fps_flop = B * N_POINTS * fps_rounds * FPS_FLOP_PER_UPDATE
-    achieved = fps_flop / (fps_ms * 1e-3) / 1e12 if fps_rounds else float("nan")
+    fps_tf = fps_flop / (fps_ms * 1e-3) / 1e12 if fps_rounds else float("nan")
+    tag = {"model": "bench_model", "sa": "bench_sa"}.get(workload, workload)
+    traffic, source = pmc_traffic("fps_pruned_kernel", tag) if B == default_b else (None, None)
+    fps_roofline = {
+        "kernel": "fps_pruned_kernel", "bound": "valu", "achieved": fps_tf, "peak": FP32_VECTOR_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": fps_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
+        "avg_launch_ms": fps_ms, "cus_used": B,
+        "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic flop = clouds*N*(m-1) updates "
+                "* 10 (what the reference executes); the pruned kernel skips most of them exactly; one workgroup "
+                "(one CU of 256) per cloud"}
     result = {
-        "metric": "point-clouds/sec (24k pts, 17 classes)",
-        "value": world * B * args.steps / elapsed,
+        "metric": "point-clouds/sec (24k pts, 17 classes) fwd+bwd" if workload in ("model", "fixmatch") else
+                  "point-clouds/sec (24k pts, 17 classes)",
+        "value": world * clouds_per_step * args.steps / elapsed,
         "unit": "clouds/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
-        "config": {"workload": desc, "clouds_per_gpu": B, "points": N_POINTS,
-                   "parallelism": "independent clouds per rank, no collective" +
-                                  ("" if args.streams == 1 else "; consecutive steps overlap on %d HIP streams" % args.streams)},
-        "roofline": {"kernel": "fps_pruned_kernel", "bound": "valu",
-                     "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
-                     "traffic": pmc_traffic("fps_pruned_kernel") if workload == "sa" and B == 1 else None,
-                     "avg_launch_ms": fps_ms,
-                     # one cloud = one workgroup = one CU: the share of the chip a launch can reach is B / 256
-                     "cus_used": B, "frac_of_cus_used": achieved / (FP32_VECTOR_PEAK_TFLOPS * min(B, 256) / 256.0),
-                     "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic "
-                             "flop = clouds*N*(m-1) updates * 10 (what the reference executes); the pruned kernel "
-                             "skips most of them exactly; one workgroup (one CU of 256) per cloud"},
+        "config": {"workload": desc, "clouds_per_gpu": clouds_per_step, "points": N_POINTS, "parallelism": parallelism},
+        "roofline": fps_roofline if fps_rounds else None,
     }
-    if workload == "ntm":
-        result["roofline"] = None
+    if workload == "model":
+        # the dominant kernel of the step by rocprofv3 time is the widest 1x1-conv GEMM of the decoder
+        # (propogation_0.mlp.layer1: 1536 -> 384 over B*24000 points), a stock rocBLAS/MIOpen launch; the dominant
+        # HAND-WRITTEN kernel (FPS, on the side stream) is reported next to it.
+        g_ms = gemm_timer.mean_ms()
+        g_flop = 2.0 * 384 * 1536 * B * N_POINTS
+        g_tf = g_flop / (g_ms * 1e-3) / 1e12
+        result["roofline"] = {"kernel": "propogation_0.mlp.layer1.conv (1x1 conv 1536->384 = rocBLAS/MIOpen fp32 GEMM)",
+                              "bound": "mfma", "achieved": g_tf, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": g_tf / FP32_MATRIX_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": g_ms,
+                              "note": "algorithmic flop = 2*384*1536*B*N per forward launch; library kernel (dense layers are "
+                                      "out of scope, SURVEY.md 2.1 row 12), timed with HIP events from module hooks"}
+        result["roofline_hot_path"] = fps_roofline
+        att = hot_path_attribution(step)
+        hot_ms = sum(att.values())
+        top = dict(sorted(att.items(), key=lambda kv: -kv[1])[:8])
+        result["hot_path"] = {"c_abi_gpu_ms_per_step": hot_ms, "share_of_step": hot_ms / ms_per_step,
+                              "dense_and_glue_share": 1.0 - hot_ms / ms_per_step, "top_entry_points_ms": top,
+                              "note": "sum of HIP-event durations around every C-ABI launch in 2 extra untimed steps; the "
+                                      "8192-point FPS runs on a side stream beside the encoder, so shares are of GPU work, "
+                                      "not of wall time"}
+        f_ms = att.get("geot_furthestsampling_offset", float("nan"))
+        k_ms = att.get("geot_knn_sorted_ws", float("nan"))
+        result["micro"] = {"fps_24000_to_8192_Mpoints_per_s": B * N_POINTS / (fps_ms * 1e-3) / 1e6,
+                           "fps_all_launches_ms_per_step": f_ms + att.get("geot_furthest_point_sampling", 0.0),
+                           "knn_all_launches_ms_per_step": k_ms,
+                           "knn_Mqueries_per_s": B * (512 + 4096 * 2 + 8192 * 2) / (k_ms * 1e-3) / 1e6,
+                           "note": "kNN: k=32 512x24000 + k=4 {512->4096, 4096^2, 4096->8192, 8192^2} per cloud per step"}
+        result["dense"] = {"mode": dense_mode,
+                           "reference_gflop_fwd_per_cloud": DENSE_GFLOP_FWD_REFERENCE,
+                           "note": "factored: first 1x1 conv behind a gather evaluated before the gather (same function, "
+                                   "fewer flops); reference: the reference's op order"}
     if workload == "sa" and mlp_timer.pairs:
         mlp_ms = mlp_timer.mean_ms()
         widths = [MLP[0] + 3] + MLP[1:]   # use_xyz: 3 relative coordinates + 3 features
         mlp_flop = 2.0 * B * NPOINT * NSAMPLE * sum(a * b for a, b in zip(widths[:-1], widths[1:]))
         mlp_tf = mlp_flop / (mlp_ms * 1e-3) / 1e12
+        t2, s2 = pmc_traffic("sa_group_mlp_max_kernel", tag) if B == 1 else (None, None)
         result["roofline_secondary"] = {
             "kernel": "sa_group_mlp_max_kernel", "bound": "mfma", "achieved": mlp_tf, "peak": FP32_MATRIX_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": mlp_tf / FP32_MATRIX_PEAK_TFLOPS,
-            "traffic": pmc_traffic("sa_group_mlp_max_kernel") if B == 1 else None, "avg_launch_ms": mlp_ms,
+            "unit": "TFLOP/s", "frac": mlp_tf / FP32_MATRIX_PEAK_TFLOPS, "traffic": t2, "traffic_source": s2,
+            "avg_launch_ms": mlp_ms,
             "note": "fused group + [6,64,64,128] 1x1-conv stack on fp32 MFMA + max over nsample; algorithmic flop = "
                     "2*rows*sum(Cin*Cout) with the unpadded 3+3 input channels"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and workload == "sa":
-        sa_cpu = build_module("cpu")
-        sa_cpu.load_state_dict(sa.state_dict())
-        result["cpu_baseline"] = cpu_baseline(xyz_np, feats_np, sa_cpu, args.cpu_steps)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if workload == "sa":
+            from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+            torch.manual_seed(1609)
+            sa_cpu = PointnetSAModuleVotes(mlp=list(MLP), npoint=NPOINT, radius=RADIUS, nsample=NSAMPLE, use_xyz=True).eval()
+            sa_cpu.load_state_dict(sa.state_dict())
+            result["cpu_baseline"] = cpu_baseline_sa(xyz_np, feats_np, sa_cpu, args.cpu_steps)
+        elif workload == "model":
+            result["cpu_baseline"] = cpu_baseline_model()
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:

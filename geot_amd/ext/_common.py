@@ -62,9 +62,18 @@ def stream_of(dev):
     return torch.cuda.current_stream(dev).cuda_stream
 
 
+trace = None     # bench.py's attribution pass sets this to a callable(launch, name) that brackets the launch
+
+
 def call(name, dev, *args):
     """Launch C-ABI entry `name` on torch's current stream of `dev` (under a device guard when `dev` is not
     the current device; the composite steps are launch-bound at one cloud, so the common case stays lean)."""
+    if trace is not None:
+        return trace(lambda: _launch(name, dev, *args), name)
+    return _launch(name, dev, *args)
+
+
+def _launch(name, dev, *args):
     lib = _lib.load()
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx == torch.cuda.current_device():

@@ -114,6 +114,8 @@ class _ClassTransitionFn(Function):
         sigma_c, proj = f32(sigma.detach().contiguous(), "sigma", 1), f32(proj.contiguous(), "proj", 1)
         dev = same_device(class_T, sigma_c, ema_t, proj)
         c = class_T.shape[0]
+        need(tuple(class_T.shape) == (c, c) and tuple(ema_t.shape) == (c, c) and proj.numel() == c
+             and sigma_c.numel() == c, "class transition: class_T / ema_t must be (C, C), sigma / proj (C,)")
         corr, nxt, prior, keep = torch.empty((4, c, c), dtype=torch.float32, device=dev).unbind(0)
         call("geot_ntm_class_transition", dev, c, geo_lambda, ema_decay, ptr(class_T), ptr(sigma_c), ptr(ema_t), ptr(proj),
              ptr(corr), ptr(nxt), ptr(prior), ptr(keep))
@@ -167,7 +169,26 @@ def exchange_anchor_rows(v_star, class_T, group):
     return parts[r_star, cols, 1:]
 
 
-def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group=None):
+def _filtered_anchor_rows(eta, q):
+    """train.py:510-517 (cfg.filter_outlier): before the arg-max of class cc every probability of that class at or
+    above its q-quantile over the unlabelled batch is set to 0 -- IN PLACE in ``eta_corr`` (``robust_eta`` is a view,
+    :511-513), so the anchor row read afterwards (:526) sees columns 0..cc already filtered and the later ones not.
+    Returns (class_T (C,C), v_star (C,)) with exactly that sequential semantics, vectorised."""
+    B, C, N = eta.shape
+    flat = eta.transpose(0, 1).reshape(C, B * N)
+    thresh = torch.quantile(flat, q, dim=1)                                # (C,), linear interpolation like :511
+    filt = torch.where(eta >= thresh.view(1, C, 1), torch.zeros_like(eta), eta)
+    best = torch.argmax(filt.transpose(0, 1).reshape(C, B * N), dim=1)     # first maximum over the flattened (b, n)
+    b_star, n_star = best // N, best % N
+    rows_f = filt[b_star, :, n_star]                                       # (C, C): row cc = filt[b*, :, n*]
+    rows_u = eta[b_star, :, n_star]
+    done = torch.ones((C, C), dtype=torch.bool, device=eta.device).tril()  # column c' <= cc already filtered
+    cols = torch.arange(C, device=eta.device)
+    return torch.where(done, rows_f, rows_u), rows_f[cols, cols]
+
+
+def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group=None, filter_outlier=False,
+                     outlier_q=0.97):
     """The class-level transition estimate of train.py:505-545 + EMA update :556-557.
 
     `group`: a torch.distributed process group (e.g. dist.group.WORLD) over which the unlabelled batch is
@@ -181,11 +202,16 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group
     B, C, N = eta.shape
     eta = eta.detach()
     fused = eta.is_cuda and C <= 32 and eta.dtype == torch.float32 and os.environ.get("GEOT_NTM_CT", "fused") == "fused"
+    need(sigma.numel() == C and tuple(ema_t.shape) == (C, C), "class_transition: sigma must be (C,), ema_t (C, C)")
+    fused = fused and C <= len(LABEL_PROJ)            # the tooth-adjacency projection has 17 entries (train.py:48)
     if fused:      # anchors in one launch (+ the transition block in another) instead of ~6 + ~40 torch launches
-        eta_c = eta.contiguous()
-        class_T = torch.empty((C, C), dtype=torch.float32, device=eta.device)
-        v_star = torch.empty(C, dtype=torch.float32, device=eta.device)
-        call("geot_ntm_class_anchors", eta.device, B, N, C, ptr(eta_c), ptr(class_T), ptr(v_star))
+        if filter_outlier:
+            class_T, v_star = _filtered_anchor_rows(eta, outlier_q)
+        else:
+            eta_c = eta.contiguous()
+            class_T = torch.empty((C, C), dtype=torch.float32, device=eta.device)
+            v_star = torch.empty(C, dtype=torch.float32, device=eta.device)
+            call("geot_ntm_class_anchors", eta.device, B, N, C, ptr(eta_c), ptr(class_T), ptr(v_star))
         if group is not None:
             import torch.distributed as dist
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -196,16 +222,20 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group
         return ema_t_corr, ema_next, class_T, prior_T
     # first maximum of class cc over the flattened (b, n) order, without materialising the two (C, B*N) /
     # (B*N, C) transposes the reference builds: arg-max over n per (b, cc), then the first b that attains it
-    n_best = torch.argmax(eta, dim=2)                                     # (B, C), first maximum along n
-    v_best = torch.gather(eta, 2, n_best.unsqueeze(2)).squeeze(2)         # (B, C)
-    b_star = torch.argmax(v_best, dim=0)                                  # (C,), first b with the maximum
-    n_star = torch.gather(n_best, 0, b_star.unsqueeze(0)).squeeze(0)      # (C,)
-    cols = torch.arange(C, device=eta.device)
-    class_T = eta[b_star.unsqueeze(1), cols.unsqueeze(0), n_star.unsqueeze(1)]   # (C, C): row cc = eta[b*, :, n*]
+    if filter_outlier:
+        class_T, v_star = _filtered_anchor_rows(eta, outlier_q)
+    else:
+        n_best = torch.argmax(eta, dim=2)                                     # (B, C), first maximum along n
+        v_best = torch.gather(eta, 2, n_best.unsqueeze(2)).squeeze(2)         # (B, C)
+        b_star = torch.argmax(v_best, dim=0)                                  # (C,), first b with the maximum
+        n_star = torch.gather(n_best, 0, b_star.unsqueeze(0)).squeeze(0)      # (C,)
+        cols = torch.arange(C, device=eta.device)
+        class_T = eta[b_star.unsqueeze(1), cols.unsqueeze(0), n_star.unsqueeze(1)]   # (C, C): row cc = eta[b*, :, n*]
+        v_star = torch.gather(v_best, 0, b_star.unsqueeze(0)).squeeze(0)
     if group is not None:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            class_T = exchange_anchor_rows(torch.gather(v_best, 0, b_star.unsqueeze(0)).squeeze(0), class_T, group)
+            class_T = exchange_anchor_rows(v_star, class_T, group)
     proj, row0, keep = _transition_constants(C, eta.dtype, eta.device)   # cached: no host->device copy per step
     prior_T = gaussian(proj.unsqueeze(0), proj.unsqueeze(1), sigma.unsqueeze(1))   # [cc][k]
     prior_T = torch.cat([row0.unsqueeze(0), prior_T[1:] * keep.unsqueeze(0)], dim=0)  # [:,0]=0; [0,0]=1

@@ -1,0 +1,334 @@
+"""The configured backbone ``PointTransformer_seg_T`` as a runnable model over the HIP hot path --
+mirror of openpoints/models/backbone/transformer.py: Mlp :16-33, Attention :36-61, Block :64-83,
+Encoder :106-136, fps :266-273, Group :275-303, DGCNN_Propagation :305-379, TransformerEncoder_h
+:381-410, PointTransformer_seg_T :913-1068 (cfg: cfgs/tooth_semi/transformer_finetune_fixmatch_ntm.yaml:6-15).
+
+Same constructor arguments, forward signature, returned tuple ``(logit, correction, sigma, f_l0)`` and
+``state_dict`` keys as the reference, so its checkpoints load unchanged.  Every sampling / grouping /
+interpolation step goes through the HIP operators (FPS K1 + gather + kNN in ``Group``; ``pointops.fps``
+K2 once, sliced for the three targets; the fused FP front end; the fused EdgeConv graph feature); the
+dense layers (1x1 convolutions, Linear, LayerNorm / BatchNorm / GroupNorm, attention) are stock PyTorch
+-> rocBLAS / MIOpen, as they are stock PyTorch -> cuBLAS / cuDNN in the reference (out of scope,
+SURVEY.md section 2.1 row 12).
+
+Two things are scheduled differently from the reference, neither changes a value:
+* the 8192-point FPS needs the coordinates only; it occupies one CU per cloud for milliseconds, so it
+  is queued on a second HIP stream beside the patch embedding + the 12 transformer blocks;
+* ``dense="factored"`` (default) uses the linearity of the first 1x1 convolution behind a gather:
+  EdgeConv  W.[x_k[idx] - x_q ; x_q] = (W_d.x_k)[idx] + ((W_q - W_d).x_q)  (k x fewer GEMM flops, the
+  (B,2C,Nq,k) operand is never built), FP module  W.[interp(f) ; skip] = interp(W_a.f) + W_b.skip
+  (the interpolation weights sum to 1; the GEMM runs on the m known points instead of the n unknown).
+  Same function, fp32 summation order differs (tests: 2e-5 relative); ``dense="reference"`` keeps the
+  reference's op order literally.
+"""
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ....pointops.functions import pointops
+from ....pointnet2.pointnet2_modules import PointnetFPModule
+from ....pointnet2 import pointnet2_utils as pt_utils
+from ....knn_cuda import KNN, knn_sorted
+from .transformer_ops import Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused  # noqa: F401
+from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
+
+
+class DropPath(nn.Module):
+    """timm.models.layers.DropPath (stochastic depth per sample), which the reference imports (:4)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask.div_(keep)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        attn = (q @ k.transpose(-2, -1)) * self.scale
+        attn = self.attn_drop(attn.softmax(dim=-1))
+        x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+        return self.proj_drop(self.proj(x))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop)
+
+    def forward(self, x):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class TransformerEncoder_h(nn.Module):
+    """Plain (non-hierarchical) encoder returning the outputs of ``extract_layers`` (transformer.py:381-410)."""
+
+    def __init__(self, embed_dim=768, depth=4, num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., finetune=False, extract_layers=None):
+        super().__init__()
+        self.finetune = finetune
+        self.extract_layers = extract_layers
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate,
+                  drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
+            for i in range(depth)])
+
+    def forward(self, x, pos):
+        inter_feats = []
+        for i, block in enumerate(self.blocks):
+            x = block(x + pos)
+            if self.extract_layers is not None and i + 1 in self.extract_layers:
+                inter_feats.append(x)
+        return inter_feats if self.extract_layers is not None else x
+
+
+class Encoder(nn.Module):
+    """Mini-PointNet over each group of points (transformer.py:106-136): (B,G,n,3) -> (B,G,C)."""
+
+    def __init__(self, encoder_channel):
+        super().__init__()
+        self.encoder_channel = encoder_channel
+        self.first_conv = nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                        nn.Conv1d(128, 256, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                         nn.Conv1d(512, self.encoder_channel, 1))
+
+    def forward(self, point_groups):
+        bs, g, n, _ = point_groups.shape
+        point_groups = point_groups.reshape(bs * g, n, 3)
+        feature = self.first_conv(point_groups.transpose(2, 1))
+        feature_global = torch.max(feature, dim=2, keepdim=True)[0]
+        feature = torch.cat([feature_global.expand(-1, -1, n), feature], dim=1)
+        feature = self.second_conv(feature)
+        feature_global = torch.max(feature, dim=2, keepdim=False)[0]
+        return feature_global.reshape(bs, g, self.encoder_channel)
+
+
+def _knn_idx(coor_q, coor_k, k):
+    """coor (B,3,N) channel-first -> int32 (B,Nq,k) neighbour ids of every query among the keys."""
+    with torch.no_grad():
+        return knn_sorted(coor_q.transpose(1, 2).contiguous().float(), coor_k.transpose(1, 2).contiguous().float(), k)[1]
+
+
+class DGCNN_Propagation(nn.Module):
+    """EdgeConv up-sampling (transformer.py:305-379): two rounds of kNN graph feature -> 1x1 Conv2d ->
+    GroupNorm -> LeakyReLU -> max over the k neighbours."""
+
+    def __init__(self, k=16, dense="factored"):
+        super().__init__()
+        self.k = k
+        self.knn = KNN(k=k, transpose_mode=False)
+        self.dense = dense
+        self.layer1 = nn.Sequential(nn.Conv2d(768, 512, kernel_size=1, bias=False), nn.GroupNorm(4, 512),
+                                    nn.LeakyReLU(negative_slope=0.2))
+        self.layer2 = nn.Sequential(nn.Conv2d(1024, 384, kernel_size=1, bias=False), nn.GroupNorm(4, 384),
+                                    nn.LeakyReLU(negative_slope=0.2))
+
+    fps_downsample = staticmethod(fps_downsample)
+
+    def get_graph_feature(self, coor_q, x_q, coor_k, x_k):
+        """(B, 2C, Nq, k) = cat(x_k[nbr] - x_q, x_q), one fused kernel (transformer.py:343-364)."""
+        return graph_feature(x_q, x_k, _knn_idx(coor_q, coor_k, self.k))
+
+    def _edge(self, layer, coor_q, x_q, coor_k, x_k):
+        conv, norm, act = layer[0], layer[1], layer[2]
+        if self.dense != "factored":
+            y = conv(self.get_graph_feature(coor_q, x_q, coor_k, x_k))
+        else:
+            c = x_q.shape[1]
+            w = conv.weight.view(conv.out_channels, 2 * c)
+            w_d, w_q = w[:, :c], w[:, c:]
+            idx = _knn_idx(coor_q, coor_k, self.k)
+            p = torch.matmul(w_d, x_k)                                   # (B, Cout, Nk)
+            q = torch.matmul(w_q - w_d, x_q)                             # (B, Cout, Nq)
+            y = pt_utils.grouping_operation(p.contiguous(), idx) + q.unsqueeze(-1)
+        return act(norm(y)).max(dim=-1, keepdim=False)[0]
+
+    def forward(self, coor, f, coor_q, f_q):
+        """coor, f: (B,3,G), (B,C,G) source; coor_q, f_q: (B,3,N), (B,C,N) target."""
+        f_q = self._edge(self.layer1, coor_q, f_q, coor, f)
+        return self._edge(self.layer2, coor_q, f_q, coor_q, f_q)
+
+
+def _fp_factored(fp, unknown, known, unknow_feats, known_feats):
+    """forward of a PointnetFPModule (pointnet2_modules.py:597-642) with the first 1x1 convolution moved in
+    front of the interpolation (see the module docstring); the parameters are ``fp``'s own."""
+    layers = list(fp.mlp.children())
+    first = layers[0]
+    conv = first.conv
+    c = known_feats.shape[1]
+    w = conv.weight.view(conv.out_channels, -1)
+    a = torch.matmul(w[:, :c], known_feats)                              # (B, Cout, m): GEMM on the known points
+    dist, idx = pt_utils.three_nn(unknown, known)
+    r = 1.0 / (dist + 1e-8)
+    y = pt_utils.three_interpolate(a.contiguous(), idx, r / torch.sum(r, dim=2, keepdim=True))
+    if unknow_feats is not None:
+        y = y + torch.matmul(w[:, c:], unknow_feats)
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, -1, 1)
+    y = y.unsqueeze(-1)
+    for name, mod in first.named_children():
+        if name != "conv":
+            y = mod(y)
+    for layer in layers[1:]:
+        y = layer(y)
+    return y.squeeze(-1)
+
+
+class PointTransformer_seg_T(nn.Module):
+    def __init__(self, trans_dim, depth, drop_path_rate, nclasses, num_heads, group_size, num_group,
+                 downsample_targets, extract_layers, encoder_dims, dense=None, overlap=True, **kwargs):
+        super().__init__()
+        self.trans_dim = trans_dim
+        self.depth = depth
+        self.drop_path_rate = drop_path_rate
+        self.nclasses = nclasses
+        self.num_heads = num_heads
+        self.group_size = group_size
+        self.num_group = num_group
+        self.downsample_targets = downsample_targets
+        self.dense = dense or os.environ.get("GEOT_DENSE", "factored")
+        self.overlap = overlap
+        self._side = {}
+
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.encoder_dims = encoder_dims
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.reduce_dim = nn.Identity()
+        if self.encoder_dims != self.trans_dim:
+            self.reduce_dim = nn.Linear(self.encoder_dims, self.trans_dim)
+        self.extract_layers = extract_layers
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, self.trans_dim))
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder_h(embed_dim=self.trans_dim, depth=self.depth, drop_path_rate=dpr,
+                                           num_heads=self.num_heads, finetune=True,
+                                           extract_layers=self.extract_layers)
+        self.norm = nn.LayerNorm(self.trans_dim)
+
+        self.propogation_2 = PointnetFPModule([self.trans_dim + 3, self.trans_dim * 4, self.trans_dim])
+        self.propogation_1 = PointnetFPModule([self.trans_dim + 3, self.trans_dim * 4, self.trans_dim])
+        self.propogation_0 = PointnetFPModule([self.trans_dim + 3 + 2, self.trans_dim * 4, self.trans_dim])
+        self.dgcnn_pro_1 = DGCNN_Propagation(k=4, dense=self.dense)
+        self.dgcnn_pro_2 = DGCNN_Propagation(k=4, dense=self.dense)
+        self.seg_head = nn.Sequential(nn.Conv1d(self.trans_dim, 128, 1), nn.BatchNorm1d(128), nn.Dropout(0.5),
+                                      nn.Conv1d(128, self.nclasses, 1))
+        self.apply(self._init_weights)
+
+        self.T_revision = nn.Linear(self.nclasses, self.nclasses, False)
+        nn.init.constant_(self.T_revision.weight, 0.0)
+        self.T_linear = nn.Linear(self.nclasses, self.nclasses, False)
+        nn.init.constant_(self.T_linear.weight, 0.0)
+        self.sigma = nn.Parameter(torch.Tensor(self.nclasses), requires_grad=True)
+        nn.init.constant_(self.sigma, 0.4)
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+        elif isinstance(m, (nn.Conv1d, nn.Conv2d)):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def _side_stream(self, device):
+        key = str(device)
+        if key not in self._side:
+            self._side[key] = torch.cuda.Stream(device=device)
+        return self._side[key]
+
+    def _fp(self, module, unknown, known, unknow_feats, known_feats):
+        if self.dense == "factored":
+            return _fp_factored(module, unknown, known, unknow_feats, known_feats)
+        return module(unknown, known, unknow_feats, known_feats)
+
+    def forward(self, pts, x=None, cls_label=None, T=None):
+        B, N, _ = pts.shape
+        pts = pts.contiguous()
+        # the long FPS (largest target; the shorter ones are prefixes, pointops.fps_indices) beside the encoder
+        side = self._side_stream(pts.device) if (self.overlap and pts.is_cuda) else None
+        top = max(self.downsample_targets)
+        if side is not None:
+            main = torch.cuda.current_stream(pts.device)
+            side.wait_stream(main)        # every side-stream allocation starts behind all earlier main-stream uses
+            with torch.cuda.stream(side):
+                pointops.fps_indices(pts, top)
+
+        neighborhood, center, idx = self.group_divider(pts)
+        group_input_tokens = self.reduce_dim(self.encoder(neighborhood))
+        pos = self.pos_embed(center)
+        inter_feats = self.blocks(group_input_tokens, pos)
+        inter_feats = [self.norm(t).transpose(-1, -2).contiguous() for t in inter_feats]
+        cls_label_one_hot = F.one_hot(cls_label, 2).transpose(1, 2).float().repeat(1, 1, N)
+
+        center_original = pts
+        center_trans = center.transpose(-1, -2).contiguous()
+        f_l0 = torch.cat([cls_label_one_hot, center_original.transpose(-1, -2).contiguous()], 1)
+
+        assert len(inter_feats) == len(self.downsample_targets), \
+            "the length of the cardinality and the features should be the same"
+        if side is not None:
+            main.wait_stream(side)
+        center_pts = [pointops.fps(pts, t) for t in self.downsample_targets]
+        center_pts_trans = [pt.transpose(-1, -2).contiguous() for pt in center_pts]
+
+        f_l3 = inter_feats[2]
+        f_l2 = self._fp(self.propogation_2, center_pts[1], center, center_pts_trans[1], inter_feats[1])
+        f_l1 = self._fp(self.propogation_1, center_pts[0], center, center_pts_trans[0], inter_feats[0])
+        f_l2 = self.dgcnn_pro_2(center_trans, f_l3, center_pts_trans[1], f_l2)
+        f_l1 = self.dgcnn_pro_1(center_pts_trans[1], f_l2, center_pts_trans[0], f_l1)
+        f_l0 = self._fp(self.propogation_0, center_original, center_pts[0], f_l0, f_l1)
+
+        logit = self.seg_head(f_l0)
+        correction = self.T_linear(T) if T is not None else None
+        return logit, correction, self.sigma, f_l0
+
+
+TOOTH_SEG_CFG = dict(trans_dim=384, depth=12, num_heads=4, group_size=32, num_group=512, encoder_dims=256,
+                     nclasses=17, drop_path_rate=0.1, downsample_targets=[8192, 4096, 2048],
+                     extract_layers=[4, 8, 12])   # cfgs/tooth_semi/transformer_finetune_fixmatch_ntm.yaml:6-15

@@ -1,0 +1,167 @@
+"""The training steps the BASELINE configs time, composed from the mirrored modules -- the part of
+examples/segmentation/train.py that drives the hot path, and nothing else of the driver (no loaders,
+meters, logging, checkpoints):
+
+* ``SupervisedStep``  -- configs[2]/[3]: forward of the segmentor on a batch of clouds, Poly1FocalLoss,
+  backward, (DDP gradient all-reduce when wrapped,) clip + AdamW step (train.py:436-452, 646-657).
+* ``FixMatchNTMStep`` -- configs[4]: one semi-supervised iteration (train.py:455-602, 646-660): frozen
+  teacher on the weak view -> pseudo labels; student on labelled + strong + weak (WholePartSeg, 6 clouds
+  at B_l = B_u = 2); class-level transition (anchors, Gaussian prior, EMA); per-point transition matrices
+  (T_predictor); corrected strong logits; 3-D smoothness loss; Poly1Focal losses; backward; both optimisers.
+
+Both are plain callables over device tensors; `ddp()` wraps student and T_predictor the way train.py:159-166
+does (SyncBatchNorm + DistributedDataParallel) -- and also wraps T_predictor, which the reference leaves
+unsynchronised (last row: an intentional divergence).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ntm as ntm_mod
+from .openpoints.loss import Poly1FocalLoss, Poly1FocalLoss_U_corr
+from .openpoints.models.segmentation import WholePartSeg
+
+NTM_CFG = dict(threshold=0.0, unsupervised_loss_weight=1.0, ema_t_decay=0.999, lambma=0.9, geo_lambma=0.999,
+               threed_loss_weight=0.1, threed_k=32, threed_sigma=1.0, filter_outlier=False, lr=1e-3,
+               weight_decay=1e-4, grad_norm_clip=None, batch_size_l=2, batch_size_u=2, num_classes=17)
+# cfgs/tooth_semi/transformer_finetune_fixmatch_ntm.yaml:45-96 (+ default.yaml)
+
+
+# parameters the configured step never differentiates: T_revision is not used by forward() at all and the
+# `correction` output of T_linear is dropped by the caller (train.py:490 `pred_all, delta_T, sigma = ...`, delta_T
+# unused); `sigma` only receives a gradient through the class-transition prior of the FixMatch step.  DDP's reducer
+# must be told, or it waits for their gradients (the reference never ran its DDP path: train.py:7 pins one GPU).
+UNUSED_SUPERVISED = ("T_revision.weight", "T_linear.weight", "sigma")
+UNUSED_FIXMATCH = ("T_revision.weight", "T_linear.weight")
+
+
+def ddp(module, device, sync_bn=True, unused=(), **kw):
+    """train.py:159-166: SyncBatchNorm conversion + DistributedDataParallel when a process group is up."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return module
+    if sync_bn:
+        module = nn.SyncBatchNorm.convert_sync_batchnorm(module)
+    skip = [n for n, _ in module.named_parameters() if any(n.endswith(u) for u in unused)]
+    skip += ["." + n for n in skip if "." not in n]     # DDP spells a root-level parameter "<module_name>.<param>" = ".sigma"
+    if skip:
+        nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(module, skip)
+    ids = [device.index] if device.type == "cuda" else None
+    return nn.parallel.DistributedDataParallel(module, device_ids=ids, **kw)
+
+
+def make_optimizer(params, lr=1e-3, weight_decay=1e-4):
+    params = [p for p in params if p.requires_grad]
+    fused = bool(params) and all(p.is_cuda for p in params)
+    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=fused)
+
+
+class SupervisedStep:
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, grad_norm_clip=None):
+        self.model = model
+        self.criterion = Poly1FocalLoss()
+        self.optimizer = make_optimizer(model.parameters(), lr, weight_decay)
+        self.clip = grad_norm_clip
+
+    def __call__(self, pos, cls, target):
+        """pos (B,N,3) f32, cls (B,1) int64 jaw id, target (B,N) int64 -> detached loss."""
+        self.model.train()
+        logits = self.model(pos, pos.transpose(1, 2).contiguous(), cls)[0]
+        loss = self.criterion(logits, target)
+        loss.backward()
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        return loss.detach()
+
+
+class FixMatchNTMStep:
+    """State of train_one_epoch that survives an iteration: ema_t (C,C), cm (C,C), both optimisers."""
+
+    def __init__(self, student, teacher, t_predictor, cm=None, cfg=None, group=None):
+        self.cfg = dict(NTM_CFG, **(cfg or {}))
+        c = self.cfg["num_classes"]
+        self.model, self.model_t, self.T_predictor = student, teacher, t_predictor
+        for p in self.model_t.parameters():
+            p.requires_grad = False                                                    # train.py:221-222
+        dev = next(student.parameters()).device
+        self.criterion, self.criterion_u = Poly1FocalLoss(), Poly1FocalLoss_U_corr()
+        self.threed_loss = ntm_mod.threeD_space_loss(self.cfg["threed_k"], self.cfg["threed_sigma"], c)
+        self.optimizer = make_optimizer(student.parameters(), self.cfg["lr"], self.cfg["weight_decay"])
+        self.T_optimizer = make_optimizer(t_predictor.parameters(), self.cfg["lr"], self.cfg["weight_decay"])
+        self.ema_t = torch.eye(c, device=dev)                                          # train.py:274
+        self.cm = cm if cm is not None else torch.full((c, c), 1.0 / c, device=dev)    # cal_mean_feature's output
+        self.group = group
+        self._side = None
+
+    def __call__(self, data, data_u):
+        """data: labelled batch {pos (B_l,N,3), x (B_l,3,N), cls (B_l,1), y (B_l,N)}; data_u: unlabelled batch
+        {pos_w, x_w, cls_w, pos_s, x_s, cls_s, raw_pos (B_u,N,3)} -> dict of detached losses."""
+        cfg = self.cfg
+        bl, bu = data["pos"].shape[0], data_u["pos_w"].shape[0]
+        n = data["pos"].shape[1]
+        # the kNN graph of the 3-D loss needs raw_pos only: build it beside the teacher / student forwards
+        dev = data["pos"].device
+        nbr = order = None
+        if dev.type == "cuda":
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=dev)
+            main = torch.cuda.current_stream(dev)
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                raw = data_u["raw_pos"].contiguous()
+                nbr = self.threed_loss.neighbours(raw)
+                order = ntm_mod.spatial_order(raw)
+        # 1. pseudo labels from the frozen teacher on the weak view (train.py:462-475)
+        with torch.no_grad():
+            self.model_t.eval()
+            pred_u = F.softmax(self.model_t(data_u, if_teacher=True)[0], dim=1)
+            logits_u_aug, label_u_aug = torch.max(pred_u, dim=1)
+        # 2. student on labelled + strong + weak (train.py:478-492)
+        self.model.train()
+        self.T_predictor.train()
+        data_u = dict(data_u, T=self.ema_t)
+        pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True)
+        pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
+        # 3. class-level transition matrix, prior, EMA (train.py:502-545, 556-557)
+        ema_t_corr, ema_next, _, _ = ntm_mod.class_transition(
+            pred_u, sigma, self.ema_t, cfg["geo_lambma"], cfg["ema_t_decay"], group=self.group,
+            filter_outlier=cfg["filter_outlier"])
+        # 4. per-point matrices + corrected strong logits (train.py:547-552)
+        ins_t = self.T_predictor(F.softmax(pred_u_strong, dim=1).detach(), self.cm)
+        pred_u_strong_corr = ntm_mod.correct_logits(pred_u_strong, ins_t, ema_t_corr, cfg["lambma"])
+        self.ema_t = ema_next.detach()
+        # 5. losses (train.py:570-602)
+        if nbr is not None:
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+        loss_3d = self.threed_loss(data_u["raw_pos"], label_u_aug, ins_t, nbr=nbr, order=order) * cfg["threed_loss_weight"]
+        sup_loss = self.criterion(pred_l, data["y"])
+        unsup_loss = self.criterion_u(pred_u_strong_corr, label_u_aug.detach(), logits_u_aug.detach(),
+                                      thresh=cfg["threshold"])
+        thresh_mask = logits_u_aug.ge(cfg["threshold"])
+        unsup_loss = unsup_loss * (cfg["unsupervised_loss_weight"] * (bu * n) / thresh_mask.sum())
+        loss = sup_loss + unsup_loss + loss_3d
+        loss.backward()
+        if cfg["grad_norm_clip"] is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["grad_norm_clip"])
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        self.T_optimizer.step()
+        self.T_optimizer.zero_grad(set_to_none=True)
+        return {"loss": loss.detach(), "sup": sup_loss.detach(), "unsup": unsup_loss.detach(), "threed": loss_3d.detach()}
+
+
+def build_fixmatch(device, seg_cfg=None, cfg=None, use_ddp=True, group=None):
+    """Student, frozen teacher and T_predictor as train.py:154-226 builds them (random init: the pretrained
+    checkpoints are the authors' local files)."""
+    from .openpoints.models.backbone.transformer import TOOTH_SEG_CFG
+    seg = dict(NAME="PointTransformer_seg_T", **(seg_cfg or TOOTH_SEG_CFG))
+    student = WholePartSeg(segmentor_args=seg).to(device)
+    teacher = WholePartSeg(segmentor_args=seg).to(device)
+    teacher.load_state_dict(student.state_dict())
+    t_pred = ntm_mod.Ins_T_mean(nclasses=(cfg or NTM_CFG).get("num_classes", 17)).to(device)
+    if use_ddp:
+        student = ddp(student, device, unused=UNUSED_FIXMATCH)
+        t_pred = ddp(t_pred, device, sync_bn=False)
+    return FixMatchNTMStep(student, teacher, t_pred, cfg=cfg, group=group)

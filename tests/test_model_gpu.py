@@ -1,0 +1,111 @@
+"""GPU tests of the runnable backbone and the training steps built on the HIP hot path (BASELINE configs[2]/[4]):
+the model's index-producing steps against the C oracle at full size, the factored dense mode against the
+reference op order, and one FixMatch+NTM iteration end to end."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SMALL = dict(trans_dim=384, depth=2, num_heads=4, group_size=32, num_group=128, encoder_dims=256, nclasses=17,
+             drop_path_rate=0.0, downsample_targets=[2048, 1024, 512], extract_layers=[1, 2, 2])
+
+
+def _batch(b, n, dev):
+    from geot_amd.synth import make_batch, region_labels
+    xyz, _ = make_batch(b, n)
+    return xyz, torch.from_numpy(xyz).to(dev), torch.from_numpy(region_labels(xyz)).to(dev)
+
+
+def test_factored_dense_equals_reference_order():
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    dev = torch.device("cuda:0")
+    _, pos, target = _batch(2, 6000, dev)
+    cls = torch.tensor([[0], [1]], device=dev)
+    torch.manual_seed(0)
+    ref = PointTransformer_seg_T(**SMALL, dense="reference").to(dev).train()
+    fac = PointTransformer_seg_T(**SMALL, dense="factored").to(dev).train()
+    fac.load_state_dict(ref.state_dict())
+    for m in (ref, fac):
+        m.seg_head[2].p = 0.0                       # the only random layer left (drop_path_rate is 0)
+    outs, grads = [], []
+    for m in (ref, fac):
+        logit, corr, sigma, f_l0 = m(pos, pos.transpose(1, 2).contiguous(), cls, torch.eye(17, device=dev))
+        assert logit.shape == (2, 17, 6000) and f_l0.shape == (2, 384, 6000) and corr.shape == (17, 17)
+        torch.nn.functional.cross_entropy(logit, target).backward()
+        outs.append((logit.detach(), f_l0.detach()))
+        grads.append({n: p.grad.detach() for n, p in m.named_parameters() if p.grad is not None})
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(a.abs().max())), float((a - b).abs().max())
+    assert set(grads[0]) == set(grads[1])
+    for k in grads[0]:
+        err = float((grads[0][k] - grads[1][k]).norm() / (grads[0][k].norm() + 1e-20))
+        assert err < 2e-3, (k, err)
+
+
+def test_model_sampling_steps_match_oracle_full_size(oracle):
+    """The index-producing steps of one forward at the configs[2] shapes (B=2 of the 8 clouds to keep the oracle in
+    seconds): Group's FPS(K1, origin-skip)+kNN, pointops.fps prefixes (K2), three_nn of every FP module, DGCNN kNN."""
+    from geot_amd.openpoints.models.backbone import transformer as tr
+    from geot_amd.pointops.functions import pointops
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    dev = torch.device("cuda:0")
+    xyz_np, pos, _ = _batch(2, 24000, dev)
+    group = tr.Group(512, 32)
+    neighborhood, center, flat = group(pos)
+    want_c = oracle.fps_dense(xyz_np, 512, 512, True)
+    c_np = np.take_along_axis(xyz_np, want_c[..., None].astype(np.int64).repeat(3, -1), 1)
+    assert np.array_equal(center.cpu().numpy(), c_np)
+    want_nn = oracle.knn_sorted(c_np, xyz_np, 32)[0]
+    got_nn = flat.view(2, 512, 32).cpu().numpy() - (np.arange(2) * 24000)[:, None, None]
+    assert np.array_equal(got_nn, want_nn)
+    off = (np.arange(1, 3) * 24000).astype(np.int32)
+    want8 = oracle.fps_offset(xyz_np.reshape(-1, 3), off, (np.arange(1, 3) * 8192).astype(np.int32)).reshape(2, 8192)
+    c8 = pointops.fps(pos, 8192)
+    c4 = pointops.fps(pos, 4096)
+    flat_xyz = xyz_np.reshape(-1, 3)
+    assert np.array_equal(c8.cpu().numpy(), flat_xyz[want8])
+    assert np.array_equal(c4.cpu().numpy(), flat_xyz[want8[:, :4096]])            # prefix property (App. A.1)
+    d, i3 = pu.three_nn(pos, c8)
+    wd2, wi = oracle.three_nn(xyz_np, c8.cpu().numpy())
+    assert np.array_equal(i3.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), np.sqrt(wd2))
+    idx = tr._knn_idx(c8.transpose(1, 2).contiguous(), c4.transpose(1, 2).contiguous(), 4)
+    assert np.array_equal(idx.cpu().numpy(), oracle.knn_sorted(c8.cpu().numpy(), c4.cpu().numpy(), 4)[0])
+
+
+def test_supervised_step_trains():
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd.train_step import SupervisedStep
+    dev = torch.device("cuda:0")
+    _, pos, target = _batch(2, 6000, dev)
+    torch.manual_seed(1)
+    model = PointTransformer_seg_T(**SMALL).to(dev)
+    step = SupervisedStep(model, lr=1e-3)
+    cls = torch.zeros(2, 1, dtype=torch.long, device=dev)
+    losses = [float(step(pos, cls, target)) for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_fixmatch_ntm_step_end_to_end():
+    from geot_amd import train_step as ts
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    trainer = ts.build_fixmatch(dev, seg_cfg=SMALL, use_ddp=False)
+    _, pos, target = _batch(2, 6000, dev)
+    from geot_amd.synth import make_batch
+    xu = torch.from_numpy(make_batch(2, 6000, start_index=50)[0]).to(dev)
+    xs = (xu * 1.1).contiguous()
+    z = torch.zeros(2, 1, dtype=torch.long, device=dev)
+    data = {"pos": pos, "x": pos.transpose(1, 2).contiguous(), "cls": z, "y": target}
+    data_u = {"pos_w": xu, "x_w": xu.transpose(1, 2).contiguous(), "cls_w": z, "pos_s": xs,
+              "x_s": xs.transpose(1, 2).contiguous(), "cls_s": z, "raw_pos": xu}
+    w0 = [l.weight.detach().clone() for l in trainer.T_predictor.T_predictor.fc]
+    s0 = trainer.model.segmentor.sigma.detach().clone()
+    out = [trainer(data, data_u) for _ in range(2)]
+    for o in out:
+        assert all(torch.isfinite(v) for v in o.values()), o
+    assert float(out[0]["threed"]) >= 0
+    assert not torch.equal(trainer.ema_t, torch.eye(17, device=dev))                    # EMA moved (train.py:556-557)
+    assert any(not torch.equal(a, l.weight) for a, l in zip(w0, trainer.T_predictor.T_predictor.fc))   # T_optimizer stepped
+    assert not torch.equal(s0, trainer.model.segmentor.sigma)                           # sigma learns through the prior
+    assert all(not p.requires_grad for p in trainer.model_t.parameters())               # frozen teacher
