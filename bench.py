@@ -282,7 +282,6 @@ def main():
                 "all-reduce over %s" % (world, B, "gloo (rehearsal)" if rehearsal else "RCCL"))
         if world > 1:
             parallelism = "dp%d: DistributedDataParallel (25 MB buckets, overlapped with backward) + SyncBatchNorm" % world
-        unpatch += gemm_timer.hook(model.propogation_0.mlp.layer1.conv)
 
         def step():
             return trainer(xyz, cls, target)
@@ -352,6 +351,8 @@ def main():
     if patch_owner is not None:
         orig_fn = getattr(patch_owner, patch_name)
         setattr(patch_owner, patch_name, fps_timer.wrap(orig_fn))
+    if workload == "model":
+        unpatch += gemm_timer.hook(model.propogation_0.mlp.layer1.conv)
     if workload == "sa":
         import geot_amd.sa_fused as sa_fused_mod
         orig_mlp = sa_fused_mod.fused_group_mlp_max

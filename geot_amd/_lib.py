@@ -80,6 +80,10 @@ PROTOTYPES.update({
     "geot_ntm_feature_loss_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _P, _P, _P, _P, _P,
                                    _c_void_p],
 })
+PROTOTYPES.update({
+    "geot_edgeconv_gn_max": [_c_int] * 6 + [_c_float, _c_float] + [_P] * 11 + [ctypes.c_longlong, _c_void_p],
+    "geot_edgeconv_gn_max_grad": [_c_int] * 6 + [_c_float] + [_P] * 15 + [ctypes.c_longlong, _c_void_p],
+})
 # entry points that do not follow the "(..., stream) -> hipError_t" shape
 PLAIN = {
     "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),
@@ -94,7 +98,10 @@ PLAIN = {
     "geot_pc_norm_ws_bytes": ([], ctypes.c_longlong),
     "geot_knn_grid_eligible": ([_c_int, _c_int, _c_int, _c_int], _c_int),
     "geot_ball_grid_eligible": ([_c_int, _c_int, _c_int, _c_float, _c_int], _c_int),
+    "geot_edgeconv_eligible": ([_c_int] * 6, _c_int),
+    "geot_edgeconv_ws_bytes": ([_c_int] * 5, ctypes.c_longlong),
 }
+ABI_VERSION = 2     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
 
 _lib = None
 
@@ -128,6 +135,9 @@ def load():
         raise GeotLibraryError("geot_amd: cannot load %s: %s" % (LIB_PATH, e))
     lib.geot_abi_version.restype = _c_int
     lib.geot_abi_version.argtypes = []
+    if lib.geot_abi_version() != ABI_VERSION:
+        raise GeotLibraryError("geot_amd: %s is ABI version %d, this package binds version %d -- rebuild it with "
+                               "`python -m geot_amd.build`" % (LIB_PATH, lib.geot_abi_version(), ABI_VERSION))
     lib.geot_error_string.restype = ctypes.c_char_p
     lib.geot_error_string.argtypes = [_c_int]
     for name, argtypes in PROTOTYPES.items():

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libgeot_hip.so")
 
-SOURCES = ["fps.hip", "neighbors.hip", "knn_grid.hip", "gather_group.hip", "ntm.hip", "sa_mlp.hip", "dataprep.hip"]
+SOURCES = ["fps.hip", "neighbors.hip", "knn_grid.hip", "gather_group.hip", "ntm.hip", "sa_mlp.hip", "dataprep.hip", "edgeconv.hip"]
 HEADERS = ["geot_common.h", os.path.join(ROOT, "include", "geot_hip.h")]
 
 # -ffp-contract=off: squared distances must be un-contracted IEEE fp32 so that

@@ -30,8 +30,10 @@ import torch.nn.functional as F
 from ....pointops.functions import pointops
 from ....pointnet2.pointnet2_modules import PointnetFPModule
 from ....pointnet2 import pointnet2_utils as pt_utils
+from ....pointnet2.pytorch_utils import PointwiseConv1d, PointwiseConv2d
 from ....knn_cuda import KNN, knn_sorted
-from .transformer_ops import Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused  # noqa: F401
+from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused,  # noqa: F401
+                              edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
 
 
@@ -125,7 +127,12 @@ class TransformerEncoder_h(nn.Module):
 
 
 class Encoder(nn.Module):
-    """Mini-PointNet over each group of points (transformer.py:106-136): (B,G,n,3) -> (B,G,C)."""
+    """Mini-PointNet over each group of points (transformer.py:106-136): (B,G,n,3) -> (B,G,C).
+
+    The groups arrive channels-last, (B*G*n, 3); the reference transposes them to (B*G, 3, n) for Conv1d.  A 1x1
+    convolution over (BG, C, n) is a Linear over the BG*n rows and BatchNorm1d's statistics over (BG, n) are its
+    statistics over those rows, so the stack runs on 2-D row-major tensors: four plain GEMMs, no transposes; same
+    modules, parameters and running statistics."""
 
     def __init__(self, encoder_channel):
         super().__init__()
@@ -135,15 +142,19 @@ class Encoder(nn.Module):
         self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
                                          nn.Conv1d(512, self.encoder_channel, 1))
 
+    @staticmethod
+    def _rows(seq, x):
+        for m in seq:
+            x = F.linear(x, m.weight.squeeze(-1), m.bias) if isinstance(m, nn.Conv1d) else m(x)
+        return x
+
     def forward(self, point_groups):
         bs, g, n, _ = point_groups.shape
-        point_groups = point_groups.reshape(bs * g, n, 3)
-        feature = self.first_conv(point_groups.transpose(2, 1))
-        feature_global = torch.max(feature, dim=2, keepdim=True)[0]
-        feature = torch.cat([feature_global.expand(-1, -1, n), feature], dim=1)
-        feature = self.second_conv(feature)
-        feature_global = torch.max(feature, dim=2, keepdim=False)[0]
-        return feature_global.reshape(bs, g, self.encoder_channel)
+        feature = self._rows(self.first_conv, point_groups.reshape(bs * g * n, 3)).view(bs * g, n, -1)
+        feature_global = torch.max(feature, dim=1, keepdim=True)[0]                      # (BG, 1, 256)
+        feature = torch.cat([feature_global.expand(-1, n, -1), feature], dim=2)          # (BG, n, 512)
+        feature = self._rows(self.second_conv, feature.reshape(bs * g * n, -1)).view(bs * g, n, -1)
+        return torch.max(feature, dim=1, keepdim=False)[0].reshape(bs, g, self.encoder_channel)
 
 
 def _knn_idx(coor_q, coor_k, k):
@@ -161,9 +172,10 @@ class DGCNN_Propagation(nn.Module):
         self.k = k
         self.knn = KNN(k=k, transpose_mode=False)
         self.dense = dense
-        self.layer1 = nn.Sequential(nn.Conv2d(768, 512, kernel_size=1, bias=False), nn.GroupNorm(4, 512),
+        self.fused_tail = os.environ.get("GEOT_EDGE_TAIL", "fused") == "fused"
+        self.layer1 = nn.Sequential(PointwiseConv2d(768, 512, kernel_size=1, bias=False), nn.GroupNorm(4, 512),
                                     nn.LeakyReLU(negative_slope=0.2))
-        self.layer2 = nn.Sequential(nn.Conv2d(1024, 384, kernel_size=1, bias=False), nn.GroupNorm(4, 384),
+        self.layer2 = nn.Sequential(PointwiseConv2d(1024, 384, kernel_size=1, bias=False), nn.GroupNorm(4, 384),
                                     nn.LeakyReLU(negative_slope=0.2))
 
     fps_downsample = staticmethod(fps_downsample)
@@ -183,6 +195,9 @@ class DGCNN_Propagation(nn.Module):
             idx = _knn_idx(coor_q, coor_k, self.k)
             p = torch.matmul(w_d, x_k)                                   # (B, Cout, Nk)
             q = torch.matmul(w_q - w_d, x_q)                             # (B, Cout, Nq)
+            if (self.fused_tail and p.is_cuda and isinstance(norm, nn.GroupNorm) and isinstance(act, nn.LeakyReLU)
+                    and edgeconv_tail_eligible(p.shape[0], p.shape[1], q.shape[2], p.shape[2], self.k, norm.num_groups)):
+                return edgeconv_tail(p, q, idx, norm, act.negative_slope)   # gather + GN + LeakyReLU + max, fused
             y = pt_utils.grouping_operation(p.contiguous(), idx) + q.unsqueeze(-1)
         return act(norm(y)).max(dim=-1, keepdim=False)[0]
 
@@ -252,8 +267,8 @@ class PointTransformer_seg_T(nn.Module):
         self.propogation_0 = PointnetFPModule([self.trans_dim + 3 + 2, self.trans_dim * 4, self.trans_dim])
         self.dgcnn_pro_1 = DGCNN_Propagation(k=4, dense=self.dense)
         self.dgcnn_pro_2 = DGCNN_Propagation(k=4, dense=self.dense)
-        self.seg_head = nn.Sequential(nn.Conv1d(self.trans_dim, 128, 1), nn.BatchNorm1d(128), nn.Dropout(0.5),
-                                      nn.Conv1d(128, self.nclasses, 1))
+        self.seg_head = nn.Sequential(PointwiseConv1d(self.trans_dim, 128, 1), nn.BatchNorm1d(128), nn.Dropout(0.5),
+                                      PointwiseConv1d(128, self.nclasses, 1))
         self.apply(self._init_weights)
 
         self.T_revision = nn.Linear(self.nclasses, self.nclasses, False)
@@ -288,6 +303,10 @@ class PointTransformer_seg_T(nn.Module):
         return module(unknown, known, unknow_feats, known_feats)
 
     def forward(self, pts, x=None, cls_label=None, T=None):
+        with pointops.fps_prefix_scope():       # the three pointops.fps targets are prefixes of one FPS run
+            return self._forward(pts, x, cls_label, T)
+
+    def _forward(self, pts, x, cls_label, T):
         B, N, _ = pts.shape
         pts = pts.contiguous()
         # the long FPS (largest target; the shorter ones are prefixes, pointops.fps_indices) beside the encoder

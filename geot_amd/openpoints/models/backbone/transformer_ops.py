@@ -9,6 +9,7 @@ import torch.nn as nn
 from ....pointnet2 import pointnet2_utils as pt_utils
 from ....knn_cuda import KNN
 from ....ext._common import f32, i32, same_device, need, call, ptr, grad_workspace
+from .... import _lib
 
 
 def fps(data, number):
@@ -74,6 +75,59 @@ class _GraphFeatureFn(torch.autograd.Function):
 def graph_feature(x_q, x_k, idx):
     """x_q (B,C,Nq), x_k (B,C,Nk), idx (B,Nq,k) int32 -> (B,2C,Nq,k) = cat(x_k[idx] - x_q, x_q), fused."""
     return _GraphFeatureFn.apply(x_q, x_k, idx)
+
+
+class _EdgeConvTailFn(torch.autograd.Function):
+    """max_j LeakyReLU(GroupNorm(P[:, idx] + Q[..., None])) without the (B,C,Nq,k) tensor (csrc/edgeconv.hip)."""
+
+    @staticmethod
+    def forward(ctx, p, q, idx, gamma, beta, groups, eps, slope):
+        p, q = f32(p.contiguous(), "P", 3), f32(q.contiguous(), "Q", 3)
+        idx = i32(idx.contiguous(), "idx", 3)
+        gamma, beta = f32(gamma.contiguous(), "weight", 1), f32(beta.contiguous(), "bias", 1)
+        dev = same_device(p, q, idx, gamma, beta)
+        b, c, nk = p.shape
+        nq, k = q.shape[2], idx.shape[2]
+        need(tuple(q.shape[:2]) == (b, c) and tuple(idx.shape[:2]) == (b, nq) and gamma.numel() == c and beta.numel() == c,
+             "edgeconv tail shape mismatch")
+        lib = _lib.load()
+        need(lib.geot_edgeconv_eligible(b, c, nq, nk, k, int(groups)) == 1 and slope >= 0,
+             "edgeconv tail: unsupported shape (see include/geot_hip.h)")
+        nbytes = int(lib.geot_edgeconv_ws_bytes(b, c, nq, nk, k))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out, ysel, ysum = torch.empty((3, b, c, nq), dtype=torch.float32, device=dev).unbind(0)
+        jsel = torch.empty((b, c, nq), dtype=torch.uint8, device=dev)
+        stats = torch.empty((b, int(groups), 2), dtype=torch.float32, device=dev)
+        call("geot_edgeconv_gn_max", dev, b, c, nq, nk, k, int(groups), float(eps), float(slope), ptr(p), ptr(q), ptr(idx),
+             ptr(gamma), ptr(beta), ptr(out), ptr(ysel), ptr(ysum), ptr(jsel), ptr(stats), ptr(ws), nbytes)
+        ctx.save_for_backward(p, q, idx, gamma, beta, ysel, ysum, jsel, stats)
+        ctx.consts = (int(groups), float(slope), nbytes)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, q, idx, gamma, beta, ysel, ysum, jsel, stats = ctx.saved_tensors
+        groups, slope, nbytes = ctx.consts
+        b, c, nk = p.shape
+        nq, k = q.shape[2], idx.shape[2]
+        g = g.contiguous()
+        gp, gq = torch.empty_like(p), torch.empty_like(q)
+        gg, gb = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
+        call("geot_edgeconv_gn_max_grad", p.device, b, c, nq, nk, k, groups, slope, ptr(p), ptr(q), ptr(idx), ptr(gamma),
+             ptr(beta), ptr(ysel), ptr(ysum), ptr(jsel), ptr(stats), ptr(g), ptr(gp), ptr(gq), ptr(gg), ptr(gb), ptr(ws),
+             nbytes)
+        return gp, gq, None, gg, gb, None, None, None
+
+
+def edgeconv_tail(p, q, idx, norm, slope):
+    """p (B,C,Nk) = W_d x_k, q (B,C,Nq) = (W_q - W_d) x_q, idx (B,Nq,k) int32, norm = the layer's nn.GroupNorm ->
+    (B,C,Nq) = max_j LeakyReLU(norm(p[:, idx] + q[..., None])), one fused forward / backward."""
+    return _EdgeConvTailFn.apply(p, q, idx, norm.weight, norm.bias, norm.num_groups, norm.eps, slope)
+
+
+def edgeconv_tail_eligible(b, c, nq, nk, k, groups):
+    return _lib.load().geot_edgeconv_eligible(int(b), int(c), int(nq), int(nk), int(k), int(groups)) == 1
 
 
 def get_graph_feature(knn, coor_q, x_q, coor_k, x_k):

@@ -5,7 +5,32 @@ state_dict keys are the reference's (``layer{i}.conv.weight``, ``layer{i}.bn.bn.
 so checkpoints load unchanged; pinned by tests/golden/shared_mlp_ref.npz, which was
 produced by the reference class itself.
 """
+import torch
 import torch.nn as nn
+
+
+def conv1x1(conv, x):
+    """A kernel-size-1 convolution as ONE batched GEMM ``W (Cout,Cin) @ x (B,Cin,L)`` -> rocBLAS / hipBLASLt, for
+    the forward, the data gradient and the weight gradient alike.  MIOpen's convolution path picks Winograd /
+    per-sample solvers for these shapes on gfx950 (10 ms per 1x1 layer at 8 x 24 000 points, measured in
+    profiles/r02_bench_model_v1_*) and spends seconds in its find step; the arithmetic is the same dot products."""
+    shp = x.shape
+    y = torch.matmul(conv.weight.view(conv.out_channels, -1), x.reshape(shp[0], shp[1], -1))
+    if conv.bias is not None:
+        y = y + conv.bias.view(1, -1, 1)
+    return y.view(shp[0], conv.out_channels, *shp[2:])
+
+
+class PointwiseConv1d(nn.Conv1d):
+    """nn.Conv1d(kernel_size=1) with the same parameters / state_dict, evaluated by conv1x1()."""
+
+    def forward(self, x):
+        return conv1x1(self, x)
+
+
+class PointwiseConv2d(nn.Conv2d):
+    def forward(self, x):
+        return conv1x1(self, x)
 
 
 class _BN(nn.Sequential):
@@ -38,12 +63,12 @@ class _ConvStage(nn.Sequential):
 
 class Conv1d(_ConvStage):
     def __init__(self, cin, cout, *, bn=False, activation=nn.ReLU(inplace=True), preact=False):
-        super().__init__(cin, cout, nn.Conv1d, nn.BatchNorm1d, bn, activation, preact)
+        super().__init__(cin, cout, PointwiseConv1d, nn.BatchNorm1d, bn, activation, preact)
 
 
 class Conv2d(_ConvStage):
     def __init__(self, cin, cout, *, bn=False, activation=nn.ReLU(inplace=True), preact=False):
-        super().__init__(cin, cout, nn.Conv2d, nn.BatchNorm2d, bn, activation, preact)
+        super().__init__(cin, cout, PointwiseConv2d, nn.BatchNorm2d, bn, activation, preact)
 
 
 class SharedMLP(nn.Sequential):

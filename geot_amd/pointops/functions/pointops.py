@@ -7,6 +7,9 @@ length with per-element device reads (``offset[i]``, ``.item()``: pointops.py:69
 one host sync per batch entry; here a single ``.tolist()`` of the (b,) offsets does
 both.  Results are identical.
 """
+import contextlib
+import threading
+
 import torch
 from torch.autograd import Function
 
@@ -41,20 +44,34 @@ def knn(x, src, k, transpose=False):
 # The backbone samples the SAME cloud three times (8192 / 4096 / 2048 targets,
 # openpoints/models/backbone/transformer.py:1037-1039).  FPS is greedy from a fixed start and the
 # tie rule depends only on n, so the k-sample result is the first k entries of any longer one
-# (SURVEY.md App. A.1 "prefix property"): keep the longest result for the last tensor seen and
-# slice it.  The entry holds a reference to the tensor (its storage cannot be recycled) and its
-# version counter (in-place edits invalidate it).
-_FPS_CACHE = {"x": None, "version": -1, "idx": None}
+# (SURVEY.md App. A.1 "prefix property").  Inside a `with fps_prefix_scope():` block -- one forward pass of a
+# caller that knows it samples one tensor repeatedly -- the longest result for the last tensor seen is kept and
+# sliced.  Outside a scope nothing is cached: every call runs the kernel.  The entry holds a reference to the
+# tensor (its storage cannot be recycled) and its version counter; an in-place edit through `.data` or a raw
+# pointer inside the scope is not seen (do not do that between two calls of one forward).
+_FPS_SCOPE = threading.local()
+
+
+@contextlib.contextmanager
+def fps_prefix_scope():
+    """Reuse FPS results across calls on the same tensor for the duration of the block (one forward pass)."""
+    outer = getattr(_FPS_SCOPE, "cache", None)
+    _FPS_SCOPE.cache = {"x": None, "version": -1, "idx": None}
+    try:
+        yield
+    finally:
+        _FPS_SCOPE.cache = outer
 
 
 def fps_indices(x, k):
     """x (B,n,3) contiguous -> int64 global indices (B,k) into x.view(-1,3)."""
     b, n, _ = x.shape
-    c = _FPS_CACHE
-    if c["x"] is x and c["version"] == x._version and c["idx"] is not None and c["idx"].shape[1] >= k:
+    c = getattr(_FPS_SCOPE, "cache", None)
+    if c is not None and c["x"] is x and c["version"] == x._version and c["idx"].shape[1] >= k:
         return c["idx"][:, :k]
     idx = furthestsampling_uniform(x.reshape(-1, 3), b, n, k).long().view(b, k)
-    c["x"], c["version"], c["idx"] = x, x._version, idx
+    if c is not None:
+        c["x"], c["version"], c["idx"] = x, x._version, idx
     return idx
 
 

@@ -48,6 +48,10 @@ class BackboneHotPath(torch.nn.Module):
     def forward(self, pts, tokens):
         """pts (B,N,3); tokens (B,384,512) stands for the transformer output at the 512 group centres.
         Returns the (B,384,N) propagated features (sum of the interpolation outputs feeds backward)."""
+        with pointops.fps_prefix_scope():
+            return self._forward(pts, tokens)
+
+    def _forward(self, pts, tokens):
         B, N, _ = pts.shape
         # FPS keeps one CU per cloud busy for milliseconds and leaves the other ~250 idle: the patch-embedding
         # front end (FPS 512 + kNN 32 + gather), which does not depend on the 8192-point FPS, runs beside it on
@@ -83,7 +87,6 @@ class BackboneHotPath(torch.nn.Module):
 def backbone_hotpath_step(model, pts, tokens):
     """forward + backward of the hot-path ops; returns the scalar that was differentiated."""
     tokens = tokens.detach().requires_grad_(True)
-    pts = pts.clone()  # a new batch every step: the FPS prefix cache only helps WITHIN a forward
     f_l0, f_l2, neighborhood = model(pts, tokens)
     loss = f_l0.square().mean() + f_l2.mean() + neighborhood.mean()
     loss.backward()

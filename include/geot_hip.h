@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEOT_ABI_VERSION 1
+#define GEOT_ABI_VERSION 2
 
 /* ABI version / diagnostics. */
 int geot_abi_version(void);
@@ -123,6 +123,28 @@ int geot_knn_sorted_ws(int b, int nq, int nr, int k, const float *query, const f
                        float *dist2, void *workspace, long long ws_bytes, void *stream);
 int geot_three_nn_ws(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                      void *workspace, long long ws_bytes, void *stream);
+
+/* EdgeConv tail = the rest of DGCNN_Propagation's layer behind the (linear) 1x1 convolution
+ * (openpoints/models/backbone/transformer.py:366-379: Conv2d -> GroupNorm(groups) -> LeakyReLU(slope) ->
+ * max over the k neighbours), fused.  With P = W_d x_k (b,c,nk) and Q = (W_q - W_d) x_q (b,c,nq) from the caller's
+ * GEMMs, y[b,:,i,j] = P[b,:,idx[b,i,j]] + Q[b,:,i] is the convolution's output; out (b,c,nq) =
+ * max_j LeakyReLU(GroupNorm(y)).  The (b,c,nq,k) tensor is never materialised.  Saved for the gradient: ysel
+ * (b,c,nq) the selected y, ysum (b,c,nq) = sum_j y, jsel (b,c,nq) uint8 the selected slot, stats (b,groups,2) =
+ * (mean, 1/sqrt(var+eps)).  _grad writes grad_p (b,c,nk), grad_q (b,c,nq), grad_gamma (c), grad_beta (c) in full
+ * (no atomics: deterministic).  workspace: geot_edgeconv_ws_bytes() bytes of scratch, contents irrelevant.
+ * Needs slope >= 0, c % groups == 0, k <= 255 and rows that fit the LDS (nk <= 38400, nq <= 17066):
+ * geot_edgeconv_eligible() tells; callers fall back to the composed ops otherwise. */
+int geot_edgeconv_eligible(int b, int c, int nq, int nk, int k, int groups);
+long long geot_edgeconv_ws_bytes(int b, int c, int nq, int nk, int k);
+int geot_edgeconv_gn_max(int b, int c, int nq, int nk, int k, int groups, float eps, float slope, const float *P,
+                         const float *Q, const int *idx, const float *gamma, const float *beta, float *out,
+                         float *ysel, float *ysum, unsigned char *jsel, float *stats, void *workspace,
+                         long long ws_bytes, void *stream);
+int geot_edgeconv_gn_max_grad(int b, int c, int nq, int nk, int k, int groups, float slope, const float *P,
+                              const float *Q, const int *idx, const float *gamma, const float *beta,
+                              const float *ysel, const float *ysum, const unsigned char *jsel, const float *stats,
+                              const float *grad_out, float *grad_p, float *grad_q, float *grad_gamma,
+                              float *grad_beta, void *workspace, long long ws_bytes, void *stream);
 
 /* EdgeConv graph feature = DGCNN_Propagation.get_graph_feature
  * (openpoints/models/backbone/transformer.py:343-364: transpose + fancy-index gather + permute +

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_ctypes_binding_covers_the_header(built):
     from geot_amd import _lib
     lib = _lib.load()
-    assert lib.geot_abi_version() == 1
+    assert lib.geot_abi_version() == _lib.ABI_VERSION == int(re.search(r"GEOT_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "geot_hip.h")).read()).group(1))
     assert sorted(_lib.exported_symbols()) == _declared()
     assert b"invalid" in lib.geot_error_string(1).lower()
 

@@ -339,11 +339,15 @@ def test_pointops_python_api(ext, oracle):
     want = oracle.fps_offset(xyz.reshape(-1, 3), np.array([1200, 2400]), np.array([300, 600]))
     assert np.array_equal(host(pts), xyz.reshape(-1, 3)[want].reshape(2, 300, 3))
     # the backbone's three calls (8192/4096/2048 in the reference) reuse one run: prefix property
-    a, b2, c2 = pointops.fps(x, 300), pointops.fps(x, 150), pointops.fps(x, 75)
-    assert torch.equal(a[:, :150], b2) and torch.equal(a[:, :75], c2)
-    assert np.array_equal(host(c2), xyz.reshape(-1, 3)[want.reshape(2, 300)[:, :75].reshape(-1)].reshape(2, 75, 3))
-    x.mul_(1.0)  # in-place edit bumps the version: the cache must not be used
-    assert pointops._FPS_CACHE["version"] != x._version
+    with pointops.fps_prefix_scope():
+        a, b2, c2 = pointops.fps(x, 300), pointops.fps(x, 150), pointops.fps(x, 75)
+        assert pointops._FPS_SCOPE.cache["idx"].shape == (2, 300)        # one run served all three
+        assert torch.equal(a[:, :150], b2) and torch.equal(a[:, :75], c2)
+        assert np.array_equal(host(c2), xyz.reshape(-1, 3)[want.reshape(2, 300)[:, :75].reshape(-1)].reshape(2, 75, 3))
+        x.mul_(1.0)  # in-place edit bumps the version: the cache must not be used
+        assert pointops._FPS_SCOPE.cache["version"] != x._version
+    assert pointops._FPS_SCOPE.cache is None                             # nothing is kept outside a scope
+    assert torch.equal(pointops.fps(x, 150), b2)
     idx, dist = pointops.knn(x[:, :100].contiguous(), x, 5)
     wi, wd = oracle.knnquery_heap(5, xyz.reshape(-1, 3), xyz[:, :100].reshape(-1, 3), np.array([1200, 2400]),
                                   np.array([100, 200]))
