@@ -387,7 +387,7 @@ def main():
     fps_flop = B * N_POINTS * fps_rounds * FPS_FLOP_PER_UPDATE
     fps_tf = fps_flop / (fps_ms * 1e-3) / 1e12 if fps_rounds else float("nan")
     tag = {"model": "bench_model", "sa": "bench_sa"}.get(workload, workload)
-    traffic, source = pmc_traffic("fps_pruned_kernel", tag) if B == default_b else (None, None)
+    traffic, source = pmc_traffic("fps_pruned_kernel", tag) if (B == default_b and workload != "model") else (None, None)
     fps_roofline = {
         "kernel": "fps_pruned_kernel", "bound": "valu", "achieved": fps_tf, "peak": FP32_VECTOR_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": fps_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
@@ -413,18 +413,21 @@ def main():
         "roofline": fps_roofline if fps_rounds else None,
     }
     if workload == "model":
-        # the dominant kernel of the step by rocprofv3 time is the widest 1x1-conv GEMM of the decoder
-        # (propogation_0.mlp.layer1: 1536 -> 384 over B*24000 points), a stock rocBLAS/MIOpen launch; the dominant
-        # HAND-WRITTEN kernel (FPS, on the side stream) is reported next to it.
+        # dominant kernel of the step by rocprofv3 time (profiles/r02_bench_model_*_window.csv): the 8192-sample FPS
+        # (one workgroup per cloud, on the side stream beside the encoder).  Next to it the widest library GEMM of the
+        # decoder (propogation_0.mlp.layer1: 1536 -> 384 over B*24000 points), timed from module hooks.
+        t_fps, s_fps = pmc_traffic("fps_pruned_kernel<768, 32, false", tag) if B == default_b else (None, None)
+        fps_roofline.update(kernel="fps_pruned_kernel<768,32,false,8> (pointops.fps 24000 -> 8192, K2 semantics)",
+                            traffic=t_fps, traffic_source=s_fps)
         g_ms = gemm_timer.mean_ms()
         g_flop = 2.0 * 384 * 1536 * B * N_POINTS
         g_tf = g_flop / (g_ms * 1e-3) / 1e12
-        result["roofline"] = {"kernel": "propogation_0.mlp.layer1.conv (1x1 conv 1536->384 = rocBLAS/MIOpen fp32 GEMM)",
-                              "bound": "mfma", "achieved": g_tf, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": g_tf / FP32_MATRIX_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": g_ms,
-                              "note": "algorithmic flop = 2*384*1536*B*N per forward launch; library kernel (dense layers are "
-                                      "out of scope, SURVEY.md 2.1 row 12), timed with HIP events from module hooks"}
-        result["roofline_hot_path"] = fps_roofline
+        result["roofline_secondary"] = {
+            "kernel": "propogation_0.mlp.layer1.conv (1x1 conv 1536->384 = one rocBLAS strided-batched fp32 GEMM)",
+            "bound": "mfma", "achieved": g_tf, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": g_tf / FP32_MATRIX_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": g_ms,
+            "note": "algorithmic flop = 2*384*1536*B*N per forward launch; library kernel (dense layers are stock "
+                    "PyTorch -> rocBLAS, SURVEY.md 2.1 row 12), timed with HIP events from module hooks"}
         att = hot_path_attribution(step)
         hot_ms = sum(att.values())
         top = dict(sorted(att.items(), key=lambda kv: -kv[1])[:8])

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from ....pointops.functions import pointops
 from ....pointnet2.pointnet2_modules import PointnetFPModule
 from ....pointnet2 import pointnet2_utils as pt_utils
-from ....pointnet2.pytorch_utils import PointwiseConv1d, PointwiseConv2d
+from ....pointnet2.pytorch_utils import PointwiseConv1d, PointwiseConv2d, pointwise, batch_norm_nd, shared_mlp_nd
 from ....knn_cuda import KNN, knn_sorted
 from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused,  # noqa: F401
                               edgeconv_tail, edgeconv_tail_eligible)
@@ -193,8 +193,8 @@ class DGCNN_Propagation(nn.Module):
             w = conv.weight.view(conv.out_channels, 2 * c)
             w_d, w_q = w[:, :c], w[:, c:]
             idx = _knn_idx(coor_q, coor_k, self.k)
-            p = torch.matmul(w_d, x_k)                                   # (B, Cout, Nk)
-            q = torch.matmul(w_q - w_d, x_q)                             # (B, Cout, Nq)
+            p = pointwise(w_d, x_k)                                      # (B, Cout, Nk)
+            q = pointwise(w_q - w_d, x_q)                                # (B, Cout, Nq)
             if (self.fused_tail and p.is_cuda and isinstance(norm, nn.GroupNorm) and isinstance(act, nn.LeakyReLU)
                     and edgeconv_tail_eligible(p.shape[0], p.shape[1], q.shape[2], p.shape[2], self.k, norm.num_groups)):
                 return edgeconv_tail(p, q, idx, norm, act.negative_slope)   # gather + GN + LeakyReLU + max, fused
@@ -215,21 +215,18 @@ def _fp_factored(fp, unknown, known, unknow_feats, known_feats):
     conv = first.conv
     c = known_feats.shape[1]
     w = conv.weight.view(conv.out_channels, -1)
-    a = torch.matmul(w[:, :c], known_feats)                              # (B, Cout, m): GEMM on the known points
+    a = pointwise(w[:, :c], known_feats)                                 # (B, Cout, m): GEMM on the known points
     dist, idx = pt_utils.three_nn(unknown, known)
     r = 1.0 / (dist + 1e-8)
-    y = pt_utils.three_interpolate(a.contiguous(), idx, r / torch.sum(r, dim=2, keepdim=True))
+    y = pt_utils.three_interpolate(a, idx, r / torch.sum(r, dim=2, keepdim=True))
     if unknow_feats is not None:
-        y = y + torch.matmul(w[:, c:], unknow_feats)
+        y = y + pointwise(w[:, c:], unknow_feats)
     if conv.bias is not None:
         y = y + conv.bias.view(1, -1, 1)
-    y = y.unsqueeze(-1)
     for name, mod in first.named_children():
         if name != "conv":
-            y = mod(y)
-    for layer in layers[1:]:
-        y = layer(y)
-    return y.squeeze(-1)
+            y = batch_norm_nd(mod.bn, y) if name == "bn" else mod(y)
+    return shared_mlp_nd(layers[1:], y)
 
 
 class PointTransformer_seg_T(nn.Module):

@@ -136,7 +136,7 @@ class PointnetFPModule(nn.Module):
         if known is not None and self.fused_front_end and known.shape[1] > 0:
             # three_nn -> weights -> interpolate -> concat as one op (same values; pointnet2_utils.FPInterpolateConcat)
             new_features = pointnet2_utils.fp_interpolate_concat(unknown, known, unknow_feats, known_feats)
-            return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
+            return pt_utils.shared_mlp_nd(self.mlp.children(), new_features)
         if known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
@@ -145,4 +145,4 @@ class PointnetFPModule(nn.Module):
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         new_features = torch.cat([interpolated, unknow_feats], dim=1) if unknow_feats is not None else interpolated
-        return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
+        return pt_utils.shared_mlp_nd(self.mlp.children(), new_features)

@@ -9,16 +9,53 @@ import torch
 import torch.nn as nn
 
 
+def pointwise(w, x):
+    """w (Cout,Cin) @ x (B,Cin,L) -> (B,Cout,L) as ONE strided-batched GEMM whose output is contiguous.
+    (torch.matmul(2-D, 3-D) folds the batch into the rows instead: it copies x transposed and returns a transposed
+    view, i.e. two strided copies of the largest tensors of the model per layer -- 15 ms of a 73 ms step, measured.)"""
+    return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x)
+
+
 def conv1x1(conv, x):
     """A kernel-size-1 convolution as ONE batched GEMM ``W (Cout,Cin) @ x (B,Cin,L)`` -> rocBLAS / hipBLASLt, for
     the forward, the data gradient and the weight gradient alike.  MIOpen's convolution path picks Winograd /
-    per-sample solvers for these shapes on gfx950 (10 ms per 1x1 layer at 8 x 24 000 points, measured in
-    profiles/r02_bench_model_v1_*) and spends seconds in its find step; the arithmetic is the same dot products."""
+    per-sample solvers for these shapes on gfx950 (10 ms per 1x1 layer at 8 x 24 000 points, measured) and spends
+    seconds in its find step; the arithmetic is the same dot products."""
     shp = x.shape
-    y = torch.matmul(conv.weight.view(conv.out_channels, -1), x.reshape(shp[0], shp[1], -1))
+    y = pointwise(conv.weight.view(conv.out_channels, -1), x.reshape(shp[0], shp[1], -1))
     if conv.bias is not None:
         y = y + conv.bias.view(1, -1, 1)
     return y.view(shp[0], conv.out_channels, *shp[2:])
+
+
+def batch_norm_nd(bn, x):
+    """``bn(x)`` for a BatchNorm1d/2d module on an (B, C, *) tensor of any rank (same statistics, same running
+    buffers as nn.modules.batchnorm._BatchNorm.forward): the (B,C,N,1) view BatchNorm2d insists on makes torch's
+    layout heuristics take strided element-wise paths behind it.  SyncBatchNorm takes any rank itself."""
+    if isinstance(bn, nn.SyncBatchNorm) or not isinstance(bn, nn.modules.batchnorm._BatchNorm):
+        return bn(x)
+    eaf = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            eaf = 1.0 / float(bn.num_batches_tracked)
+    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    keep = not bn.training or bn.track_running_stats
+    return torch.nn.functional.batch_norm(x, bn.running_mean if keep else None, bn.running_var if keep else None,
+                                          bn.weight, bn.bias, use_batch, eaf, bn.eps)
+
+
+def shared_mlp_nd(layers, x):
+    """Run SharedMLP stages (conv -> BatchNorm -> activation, or pre-activation order) on (B, C, L) tensors."""
+    for stage in layers:
+        for name, mod in stage.named_children():
+            if name == "conv":
+                x = conv1x1(mod, x)
+            elif name == "bn":
+                x = batch_norm_nd(mod.bn, x)
+            else:
+                x = mod(x)
+    return x
 
 
 class PointwiseConv1d(nn.Conv1d):

@@ -39,14 +39,15 @@ def test_factored_dense_equals_reference_order():
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(a.abs().max())), float((a - b).abs().max())
     assert set(grads[0]) == set(grads[1])
     for k in grads[0]:
-        if k in ("encoder.first_conv.0.bias", "encoder.second_conv.0.bias", "seg_head.0.bias"):
-            # a bias in front of a BatchNorm has a mathematically zero gradient: what is left is rounding noise
+        if k in ("encoder.first_conv.0.bias", "encoder.first_conv.3.bias", "encoder.second_conv.0.bias", "seg_head.0.bias"):
+            # a bias in front of a BatchNorm has a mathematically zero gradient (first_conv.3's shifts both halves of
+            # the concatenation second_conv.0 -> BatchNorm sees): what is left is rounding noise
             wk = k[:-4] + "weight"
             assert float(grads[0][k].norm()) < 1e-3 * float(grads[0][wk].norm())
             assert float(grads[1][k].norm()) < 1e-3 * float(grads[1][wk].norm())
             continue
         err = float((grads[0][k] - grads[1][k]).norm() / (grads[0][k].norm() + 1e-20))
-        assert err < 2e-3, (k, err)
+        assert err < 5e-3, (k, err)     # fp32 summation order + max ties after normalisation
 
 
 def test_model_sampling_steps_match_oracle_full_size(oracle):
@@ -134,16 +135,18 @@ def test_edgeconv_tail_matches_composed(b, c, nq, nk, k, groups):
         norm.bias.copy_(torch.randn(c, generator=g))
     up = torch.randn(b, c, nq, generator=g).to(dev)
     res = []
-    for fused in (False, True):
-        p, q = p0.clone().requires_grad_(True), q0.clone().requires_grad_(True)
-        norm.zero_grad()
+    for fused in (False, True):         # the composed reference in fp64: in fp32 two slots whose normalised values round
+        dt = torch.float32 if fused else torch.float64   # to the same float tie, and torch's max may then pick the other one
+        p, q = p0.clone().to(dt).requires_grad_(True), q0.clone().to(dt).requires_grad_(True)
+        n2 = torch.nn.GroupNorm(groups, c).to(dev).to(dt)
+        n2.load_state_dict(norm.state_dict())
         if fused:
-            out = edgeconv_tail(p, q, idx, norm, 0.2)
+            out = edgeconv_tail(p, q, idx, n2, 0.2)
         else:
             y = torch.gather(p, 2, idx.long().reshape(b, 1, nq * k).expand(-1, c, -1)).view(b, c, nq, k) + q.unsqueeze(-1)
-            out = torch.nn.functional.leaky_relu(norm(y), 0.2).max(dim=-1)[0]
-        (out * up).sum().backward()
-        res.append([out.detach(), p.grad, q.grad, norm.weight.grad.clone(), norm.bias.grad.clone()])
+            out = torch.nn.functional.leaky_relu(n2(y), 0.2).max(dim=-1)[0]
+        (out * up.to(dt)).sum().backward()
+        res.append([t.double() for t in (out.detach(), p.grad, q.grad, n2.weight.grad, n2.bias.grad)])
     for name, a, f in zip(("out", "dP", "dQ", "dgamma", "dbeta"), *res):
         scale = float(a.abs().max())
-        assert float((a - f).abs().max()) <= 2e-4 * scale, (name, float((a - f).abs().max()), scale)
+        assert float((a - f).abs().max()) <= 2e-5 * scale, (name, float((a - f).abs().max()), scale)
