@@ -395,7 +395,7 @@ GEOT_EXPORT int geot_cloud_sample(int n, int m, int num_classes, const float *po
     if (!selected && m != n) return hipErrorInvalidValue;
     hipStream_t s = (hipStream_t)stream;
     const int nc = labels ? num_classes : 0;
-    hipError_t e = hipMemsetAsync(hist_ws, 0, (size_t)(nc + 1) * sizeof(int), s);
+    hipError_t e = zero_words(hist_ws, (long long)nc + 1, s);
     if (e != hipSuccess) return e;
     if (m == 0) return hipSuccess;
     const int nb = (m + 255) / 256;

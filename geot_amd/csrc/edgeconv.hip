@@ -400,13 +400,7 @@ static bool ec_ok(int b, int c, int nq, int nk, int k, int groups)
 template <typename K>
 static hipError_t ec_allow_lds(K kernel, size_t lds)
 {
-    // raised once per kernel to the most it can ever ask for: nothing is re-configured per call, so the launch is
-    // safe to capture into a hipGraph
-    static bool done = false;
-    if (done || lds <= 64 * 1024) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, EC_LDS_BYTES);
-    if (e == hipSuccess) done = true;
-    return e;
+    return allow_big_lds((const void *)kernel, lds);
 }
 
 } // namespace geot
@@ -481,7 +475,7 @@ GEOT_EXPORT int geot_edgeconv_gn_max_grad(int b, int c, int nq, int nk, int k, i
     int *bsum = off + t + 1;
     int *rank = bsum + scan_blocks(t);
     int *rev = rank + pairs;
-    hipError_t e = hipMemsetAsync(off, 0, (size_t)(t + 1) * sizeof(int), s);
+    hipError_t e = zero_words(off, t + 1, s);
     if (e != hipSuccess) return e;
     const int pb = (int)((pairs + 255) / 256);
     hipLaunchKernelGGL(edge_rix_count_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank);

@@ -496,8 +496,7 @@ static TldsPlan tlds_plan(int b, int c, int m, long long L, int min_ch)
 template <typename K>
 static hipError_t tlds_set_lds(K kernel, size_t lds)
 {
-    if (lds <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return allow_big_lds((const void *)kernel, lds);
 }
 
 template <int NT, bool WEIGHTED>
@@ -669,7 +668,7 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     int *rank = bsum + scan_blocks(t);
     int *rev = rank + pairs;
     float *revw = (float *)(rev + pairs);
-    hipError_t e = hipMemsetAsync(off, 0, (size_t)(t + 1) * sizeof(int), s);
+    hipError_t e = zero_words(off, t + 1, s);
     if (e != hipSuccess) return e;
     const int pb = (int)((pairs + 255) / 256);
     hipLaunchKernelGGL(rix_count_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, Q, rp.partlen, idx,

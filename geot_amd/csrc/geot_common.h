@@ -4,6 +4,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #define GEOT_EXPORT extern "C" __attribute__((visibility("default")))
 #define GEOT_WAVE 64
@@ -188,6 +191,53 @@ static inline void exclusive_scan_i32(int total, int *data, int *bsum, int *also
     hipLaunchKernelGGL(scan_local_kernel, dim3(nblk), dim3(1024), 0, s, total, data, bsum);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, s, nblk, bsum);
     hipLaunchKernelGGL(scan_add_kernel, dim3(nblk), dim3(1024), 0, s, total, data, bsum, also_zero);
+}
+
+// ---- launch-side helpers that keep every entry point capturable into a hipGraph ---------------------------------
+// (1) > 64 KB of dynamic LDS is opt-in per kernel and device.  The opt-in is raised ONCE, to the most the CU has,
+// the first time a kernel needs it -- never re-set per call: a graph node recorded with a large LDS size must not
+// find the function's limit lowered by a later call with a smaller one.  Keyed by the kernel's ADDRESS (two
+// instantiations with the same signature are one C++ type).
+static inline hipError_t allow_big_lds(const void *kernel, size_t lds, int max_bytes = 160 * 1024)
+{
+    if (lds <= 64 * 1024) return hipSuccess;
+    if (lds > (size_t)max_bytes) return hipErrorInvalidValue;
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, int>> done;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> guard(mu);
+    for (const auto &d : done)
+        if (d.first == kernel && d.second == dev) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+    if (e == hipSuccess) done.emplace_back(kernel, dev);
+    return e;
+}
+// (2) scratch counters are cleared by a kernel, not hipMemsetAsync: a plain kernel node replays identically in a
+// graph on every ROCm release; memset nodes of odd sizes in the middle of an allocation have not always.
+static __global__ __launch_bounds__(256) void zero_words_kernel(long long count, uint32_t *__restrict__ dst)
+{
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < count; e += (long long)gridDim.x * 256) dst[e] = 0u;
+}
+static inline hipError_t zero_words(void *dst, long long words, hipStream_t s)
+{
+    if (words <= 0) return hipSuccess;
+    long long blocks = (words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, words, (uint32_t *)dst);
+    return hipGetLastError();
+}
+// (3) CU count of the current device, looked up once per device
+static inline int device_cus()
+{
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] > 0) return cached[dev];
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    cached[dev] = n;
+    return n;
 }
 
 } // namespace geot

@@ -512,7 +512,7 @@ GEOT_EXPORT int geot_knnquery_heap_ws(int b, int n_per, int m_per, int nsample, 
     float *td2 = (float *)(tidx + mt * (nsample + 1));
     int *qlist = (int *)(td2 + mt * (nsample + 1));
     int *qcount = qlist + mt;
-    hipError_t e = hipMemsetAsync(qcount, 0, sizeof(int), s);
+    hipError_t e = zero_words(qcount, 1, s);
     if (e != hipSuccess) return e;
     int rc = geot_knn_sorted_ws(b, m_per, n_per, nsample + 1, new_xyz, xyz, tidx, td2, workspace, gbytes, stream);
     if (rc != 0) return rc;

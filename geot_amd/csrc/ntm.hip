@@ -982,8 +982,7 @@ __global__ __launch_bounds__(256) void ntm_partial_reduce_kernel(int nblk, int l
 template <typename K>
 static hipError_t set_lds(K kernel, size_t lds)
 {
-    if (lds <= 64 * 1024) return hipSuccess;
-    return hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    return allow_big_lds((const void *)kernel, lds);
 }
 
 static inline int ntm_blocks(int total_pts)
@@ -1222,7 +1221,7 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float s
     int *rev = (int *)(wout + (size_t)t * k);
     float *revc = (float *)(rev + (size_t)t * k);
     const float inv2s2 = 1.f / (2.f * sigma * sigma);
-    hipError_t e = hipMemsetAsync(off, 0, (size_t)(t + 1) * sizeof(int), s);
+    hipError_t e = zero_words(off, (long long)t + 1, s);
     if (e != hipSuccess) return e;
     int seg_shift = 0;
     while ((1 << seg_shift) < k) ++seg_shift;
@@ -1284,7 +1283,7 @@ GEOT_EXPORT int geot_ntm_threed_loss_fwd_graph(int b, int n, int c, int k, float
     constexpr int G = 4;
     const long long t = (long long)b * n;
     TlGraph g = tl_graph_views(graph, t, k);
-    hipError_t e = hipMemsetAsync(g.cnt, 0, (size_t)(t + 4) * sizeof(int), (hipStream_t)stream);
+    hipError_t e = zero_words(g.cnt, t + 4, (hipStream_t)stream);
     if (e != hipSuccess) return e;
     int blocks = (int)((t + 4 * G - 1) / (4 * G));
     if (blocks > 16384) blocks = 16384;

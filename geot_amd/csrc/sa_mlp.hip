@@ -436,22 +436,16 @@ GEOT_EXPORT int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int
     while (waves > 4 && ((size_t)d.total + waves * per_wave) * sizeof(float) > 160 * 1024) waves -= 4;
     const size_t lds = ((size_t)d.total + waves * per_wave) * sizeof(float);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    {   // > 64 KB of dynamic LDS is opt-in, per device and per kernel: set it on every call (cheap, and correct
-        // when a process drives more than one GPU)
-        hipError_t e = wide ? hipFuncSetAttribute((const void *)sa_group_mlp_max_kernel<8>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-                            : hipFuncSetAttribute((const void *)sa_group_mlp_max_kernel<4>,
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {   // > 64 KB of dynamic LDS is opt-in, per device and per kernel: raised once (geot_common.h allow_big_lds)
+        hipError_t e = wide ? allow_big_lds((const void *)sa_group_mlp_max_kernel<8>, lds)
+                            : allow_big_lds((const void *)sa_group_mlp_max_kernel<4>, lds);
         if (e != hipSuccess) return e;
     }
     long long nunits = ((long long)b * npoint + gpt - 1) / gpt;
     long long blocks = (nunits + waves - 1) / waves;
     // persistent workgroups: one per CU (the weights + activation tiles fill its LDS), each looping over its
     // share of the tiles, so the 52 KB of weights are staged once per CU and not once per 8 tiles
-    int dev = 0, n_cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus < 1)
-        n_cus = 256;
+    const int n_cus = device_cus();
     if (blocks > n_cus) blocks = n_cus;
     // register-pooled, software-pipelined path (see the kernel): one 32-row tile per group, few feature channels,
     // no padded output columns

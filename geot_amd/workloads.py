@@ -67,9 +67,9 @@ class BackboneHotPath(torch.nn.Module):
         c8192, c4096 = pointops.fps(pts, 8192), pointops.fps(pts, 4096)            # one FPS run (prefix reuse)
         pointops.fps(pts, 2048)                                                    # computed, unused (reference)
         if side is not None:
+            # no record_stream: every side-stream allocation of a forward starts behind `side.wait_stream(main)` of
+            # that forward, i.e. behind every earlier main-stream use of whatever block it gets
             torch.cuda.current_stream(pts.device).wait_stream(side)
-            neighborhood.record_stream(torch.cuda.current_stream(pts.device))
-            center.record_stream(torch.cuda.current_stream(pts.device))
         f_l2 = _fp(c4096, center, tokens)                                          # propogation_2: 512 -> 4096
         f_l1 = _fp(c8192, center, tokens)                                          # propogation_1: 512 -> 8192
         ct, c4t, c8t = (center.transpose(1, 2).contiguous(), c4096.transpose(1, 2).contiguous(),
@@ -131,22 +131,18 @@ class NtmHotPath(torch.nn.Module):
             # ... and the graph loss itself stays on that stream: its forward runs beside the logit correction, and --
             # autograd replays every node on its forward stream -- its L2-bound gradient gather beside the HBM-bound
             # correction backward.  The two meet again in the per-point-matrix backward (sum of both ins_T gradients).
-            self._side.wait_stream(main)                  # ins_t, label_u
-            ins_t.record_stream(self._side)
-            label_u.record_stream(self._side)
+            # ins_t / label_u (allocated on main) are read on the side stream: both outlive the join below (autograd
+            # saves them), so no block of theirs can be recycled under the side stream's kernels -- no record_stream
+            self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 loss3d = self.loss3d(raw_pos, label_u, ins_t, nbr=nbr, order=order) * 0.1
             corr = ntm_mod.correct_logits(pred_strong, ins_t, ema_corr, 0.9)
             main.wait_stream(self._side)
-            loss3d.record_stream(main)
             self.ema_t.copy_(ema_next.detach())
             return corr, loss3d
         corr = ntm_mod.correct_logits(pred_strong, ins_t, ema_corr, 0.9)
         if nbr is not None:
             main.wait_stream(self._side)
-            nbr.record_stream(main)
-            if order is not None:
-                order.record_stream(main)
         loss3d = self.loss3d(raw_pos, label_u, ins_t, nbr=nbr, order=order) * 0.1
         self.ema_t.copy_(ema_next.detach())
         return corr, loss3d
