@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--streams", type=int, default=1, help="sa only: HIP streams the steps are dealt to")
+    ap.add_argument("--graph", action="store_true",
+                    help="sa / ntm: capture one step into a hipGraph (torch.cuda.graph) and time replays -- for the "
+                         "launch-bound small-batch cases (configs[4] runs B_u = 2 clouds per rank)")
     return ap.parse_args()
 
 
@@ -346,6 +349,26 @@ def main():
         def step():
             return wl.ntm_step(nt, xyz, pw, ps)
 
+    graph_note = ""
+    if args.graph:
+        assert workload in ("sa", "ntm"), "--graph: sa / ntm only"
+        eager_step = step
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                eager_step()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        hip_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(hip_graph):
+            graph_out = eager_step()
+
+        def step():
+            hip_graph.replay()
+            return graph_out
+        patch_owner = None          # per-kernel HIP events cannot be recorded inside a replay
+        graph_note = "; one step captured into a hipGraph, replays timed"
     for _ in range(args.warmup):
         step()
     if patch_owner is not None:
@@ -353,7 +376,7 @@ def main():
         setattr(patch_owner, patch_name, fps_timer.wrap(orig_fn))
     if workload == "model":
         unpatch += gemm_timer.hook(model.propogation_0.mlp.layer1.conv)
-    if workload == "sa":
+    if workload == "sa" and not args.graph:
         import geot_amd.sa_fused as sa_fused_mod
         orig_mlp = sa_fused_mod.fused_group_mlp_max
         sa_fused_mod.fused_group_mlp_max = mlp_timer.wrap(orig_mlp)
@@ -375,7 +398,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if patch_owner is not None:
         setattr(patch_owner, patch_name, orig_fn)
-    if workload == "sa":
+    if workload == "sa" and not args.graph:
         sa_fused_mod.fused_group_mlp_max = orig_mlp
     for h in unpatch:
         h.remove()
@@ -409,8 +432,9 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
-        "config": {"workload": desc, "clouds_per_gpu": clouds_per_step, "points": N_POINTS, "parallelism": parallelism},
-        "roofline": fps_roofline if fps_rounds else None,
+        "config": {"workload": desc + graph_note, "clouds_per_gpu": clouds_per_step, "points": N_POINTS,
+                   "parallelism": parallelism},
+        "roofline": fps_roofline if (fps_rounds and not args.graph) else None,
     }
     if workload == "model":
         # dominant kernel of the step by rocprofv3 time (profiles/r02_bench_model_*_window.csv): the 8192-sample FPS

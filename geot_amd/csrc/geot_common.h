@@ -209,7 +209,12 @@ static inline hipError_t allow_big_lds(const void *kernel, size_t lds, int max_b
     std::lock_guard<std::mutex> guard(mu);
     for (const auto &d : done)
         if (d.first == kernel && d.second == dev) return hipSuccess;
-    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, max_bytes);
+    hipFuncAttributes attr;
+    hipError_t e = hipFuncGetAttributes(&attr, kernel);     // the kernel's static LDS counts against the same 160 KB
+    if (e != hipSuccess) return e;
+    const int room = max_bytes - (int)attr.sharedSizeBytes;
+    if ((long long)lds > room) return hipErrorInvalidValue;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, room);
     if (e == hipSuccess) done.emplace_back(kernel, dev);
     return e;
 }

@@ -25,6 +25,12 @@ from .ext._common import f32, i32, same_device, need, call, ptr
 from .knn_cuda import knn_sorted
 
 LABEL_PROJ = [0, 8, 7, 6, 5, 4, 3, 2, 1, 9, 10, 11, 12, 13, 14, 15, 16]  # train.py:48
+NTM_CLASSES = len(LABEL_PROJ)   # = GEOT_NTM_C in include/geot_hip.h: the per-point kernels are built for this count
+
+
+def _need_ntm_classes(c, what):
+    need(c == NTM_CLASSES, "%s: the per-point NTM kernels are built for %d classes (the tooth label set, train.py:48; "
+                           "include/geot_hip.h GEOT_NTM_C), got %d" % (what, NTM_CLASSES, c))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -37,6 +43,7 @@ class _SigTMeanFn(Function):
         dev = same_device(p, cm, W)
         b, c, n = p.shape
         need(tuple(cm.shape) == (c, c) and tuple(W.shape) == (c, c, 2 * c), "sig_t_mean shape mismatch")
+        _need_ntm_classes(c, "sig_t_mean")
         out = torch.empty((b * n, c, c), dtype=torch.float32, device=dev)
         call("geot_ntm_sig_t_mean", dev, b, n, c, ptr(p), ptr(W), ptr(cm), ptr(out))
         ctx.save_for_backward(p, cm, W)
@@ -260,6 +267,7 @@ class _CorrectFn(Function):
         dev = same_device(logits, ins_T, ema_t)
         b, c, n = logits.shape
         need(tuple(ins_T.shape) == (b * n, c, c) and tuple(ema_t.shape) == (c, c), "correct_logits shape mismatch")
+        _need_ntm_classes(c, "correct_logits")
         out = torch.empty_like(logits)
         call("geot_ntm_correct", dev, b, n, c, float(lam), ptr(logits), ptr(ins_T), ptr(ema_t), ptr(out))
         ctx.save_for_backward(logits, ins_T, ema_t)
@@ -301,6 +309,7 @@ class _ThreeDLossFn(Function):
         k = nbr.shape[2]
         need(tuple(ins_T.shape) == (b * n, c, c) and tuple(labels.shape) == (b, n) and tuple(nbr.shape) == (b, n, k),
              "threeD_space_loss shape mismatch")
+        _need_ntm_classes(c, "threeD_space_loss")
         per_point = torch.empty(b * n, dtype=torch.float32, device=dev)
         if order is None:
             order = spatial_order(positions)      # processing order only: neighbour rows then hit L2
@@ -397,6 +406,7 @@ class _FeatureLossFn(Function):
         c, k = ins_T.shape[1], nbr.shape[2]
         need(tuple(ins_T.shape) == (b * n, c, c) and tuple(labels.shape) == (b, n) and tuple(nbr.shape) == (b, n, k),
              "feature_space_loss shape mismatch")
+        _need_ntm_classes(c, "feature_space_loss")
         per_point = torch.empty(b * n, dtype=torch.float32, device=dev)
         call("geot_ntm_feature_loss", dev, b, n, c, k, d, float(sigma), ptr(feats), ptr(labels), ptr(ins_T),
              ptr(nbr), ptr(per_point))

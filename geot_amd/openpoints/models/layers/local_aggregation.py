@@ -128,7 +128,7 @@ class ConvPool(nn.Module):
                 and self.feature_type == 'dp_fj' and self.reduction == 'max' and not self.use_res
                 and isinstance(g, QueryAndGroup) and g.relative_xyz and not g.return_only_idx
                 and not (g.normalize_by_std or g.normalize_by_allstd or g.normalize_by_allstd2)
-                and fused_sa_available(self.convs))
+                and fused_sa_available(self.convs, g.nsample))
 
     def forward(self, query_xyz, support_xyz, features, query_idx=None):
         if self._fused_ok(features):

@@ -68,7 +68,7 @@ class PointnetSAModuleVotes(nn.Module):
         from ..sa_fused import fused_sa_available, fused_group_mlp_max
         if (self.fused_eval and not self.training and not torch.is_grad_enabled() and self.npoint is not None
                 and self.pooling == "max" and self.use_xyz and not self.sample_uniformly
-                and features is not None and fused_sa_available(self.mlp_module)):
+                and features is not None and fused_sa_available(self.mlp_module, self.nsample)):
             idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
             new_features = fused_group_mlp_max(xyz, new_xyz, features.contiguous(), idx, self.mlp_module,
                                                1.0 / self.radius if self.normalize_xyz else 1.0)

@@ -50,7 +50,7 @@ def shared_mlp_nd(layers, x):
     for stage in layers:
         for name, mod in stage.named_children():
             if name == "conv":
-                x = conv1x1(mod, x)
+                x = mod(x) if isinstance(mod, (PointwiseConv1d, PointwiseConv2d)) else conv1x1(mod, x)
             elif name == "bn":
                 x = batch_norm_nd(mod.bn, x)
             else:

@@ -40,7 +40,12 @@ def _stages(mlp):
     return out
 
 
-def fused_sa_available(mlp):
+def fused_sa_available(mlp, nsample=32):
+    """True when the fused kernel supports this stack AND this neighbourhood size (geot_sa_group_mlp_max takes
+    nsample 8, 16 or a multiple of 32: a 32-row MFMA tile holds whole groups or a group holds whole tiles); callers
+    compose grouper + SharedMLP + max otherwise."""
+    if nsample not in (8, 16) and (nsample < 32 or nsample % 32):
+        return False
     st = _stages(mlp)
     if not st or len(st) > _MAX_LAYERS:
         return False

@@ -19,11 +19,10 @@ def pytest_sessionstart(session):
     cross-compiles without a GPU) instead of failing every test on a missing file.  A build error is left for
     the tests to report -- the product itself never falls back to anything."""
     from geot_amd import build as hip_build
-    if not os.path.exists(hip_build.LIB):
-        try:
-            hip_build.build()
-        except Exception as e:  # noqa: BLE001
-            sys.stderr.write("geot_amd: building %s failed: %s\n" % (hip_build.LIB, e))
+    try:
+        hip_build.build()      # mtime-incremental: also refreshes a stale library left by an older checkout
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("geot_amd: building %s failed: %s\n" % (hip_build.LIB, e))
 
 
 @pytest.fixture(scope="session")

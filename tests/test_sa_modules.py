@@ -49,6 +49,9 @@ def test_fused_sa_kernel_matches_reference_shared_mlp(golden):
                                                               (16, [5, 32, 48], 5, True),
                                                               (8, [0, 16], 0, False),
                                                               (64, [3, 64, 64, 128], 3, False),
+                                                              (24, [3, 32, 64], 3, False),      # not a kernel shape:
+                                                              (48, [3, 32, 64], 3, True),       # composed fallback in eval
+
                                                               (32, [13, 100, 40, 70, 200], 13, False)])
 def test_sa_module_fused_equals_unfused(nsample, mlp_spec, c_feat, normalize):
     from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
