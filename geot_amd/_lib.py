@@ -10,7 +10,13 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgeot_hip.so")
+# GEOT_DISTANCE selects the squared-distance arithmetic of every index-producing op (include/geot_hip.h
+# geot_distance_mode): "exact" (default) | "fma" | "fma_xy"; one library per mode, chosen once at load time.
+DISTANCE_MODES = {"exact": (0, "libgeot_hip.so"), "fma": (1, "libgeot_hip_fma.so"), "fma_xy": (2, "libgeot_hip_fma_xy.so")}
+DISTANCE = os.environ.get("GEOT_DISTANCE", "exact")
+if DISTANCE not in DISTANCE_MODES:
+    raise ImportError("GEOT_DISTANCE must be one of %s, got %r" % (sorted(DISTANCE_MODES), DISTANCE))
+LIB_PATH = os.path.join(_HERE, DISTANCE_MODES[DISTANCE][1])
 
 _c_int, _c_float, _c_void_p = ctypes.c_int, ctypes.c_float, ctypes.c_void_p
 _P = ctypes.c_void_p  # device pointers are passed as raw addresses
@@ -117,8 +123,8 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise GeotLibraryError(
-            "geot_amd: %s is missing -- build it with `python -m geot_amd.build` "
-            "(there is no CPU/PyTorch fallback)" % LIB_PATH)
+            "geot_amd: %s is missing -- build it with `python -m geot_amd.build %s` "
+            "(there is no CPU/PyTorch fallback)" % (LIB_PATH, DISTANCE))
     # Make sure the HIP runtime torch already uses is the one the library binds
     # to (same SONAME libamdhip64.so.7 => the loader reuses the loaded copy), so
     # torch's stream handles are valid in our launches.
@@ -140,6 +146,11 @@ def load():
                                "`python -m geot_amd.build`" % (LIB_PATH, lib.geot_abi_version(), ABI_VERSION))
     lib.geot_error_string.restype = ctypes.c_char_p
     lib.geot_error_string.argtypes = [_c_int]
+    lib.geot_distance_mode.restype = _c_int
+    lib.geot_distance_mode.argtypes = []
+    if lib.geot_distance_mode() != DISTANCE_MODES[DISTANCE][0]:
+        raise GeotLibraryError("geot_amd: %s was built with distance mode %d, GEOT_DISTANCE=%s needs %d" %
+                               (LIB_PATH, lib.geot_distance_mode(), DISTANCE, DISTANCE_MODES[DISTANCE][0]))
     for name, argtypes in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = _c_int
@@ -161,4 +172,4 @@ def check(err, what):
 
 def exported_symbols():
     """All C-ABI symbol names the Python side binds."""
-    return ["geot_abi_version", "geot_error_string"] + list(PROTOTYPES) + list(PLAIN)
+    return ["geot_abi_version", "geot_distance_mode", "geot_error_string"] + list(PROTOTYPES) + list(PLAIN)

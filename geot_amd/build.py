@@ -15,6 +15,9 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libgeot_hip.so")
+# squared-distance arithmetic variants (csrc/geot_common.h GEOT_DISTANCE_MODE): name -> (macro value, library)
+VARIANTS = {"exact": (0, LIB), "fma": (1, os.path.join(HERE, "libgeot_hip_fma.so")),
+            "fma_xy": (2, os.path.join(HERE, "libgeot_hip_fma_xy.so"))}
 
 SOURCES = ["fps.hip", "neighbors.hip", "knn_grid.hip", "gather_group.hip", "ntm.hip", "sa_mlp.hip", "dataprep.hip", "edgeconv.hip"]
 HEADERS = ["geot_common.h", os.path.join(ROOT, "include", "geot_hip.h")]
@@ -40,17 +43,21 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    os.makedirs(OBJ, exist_ok=True)
+def build(force=False, verbose=False, variant="exact"):
+    """Compile the library (mtime-incremental).  variant: "exact" (default) | "fma" | "fma_xy" -- see VARIANTS."""
+    mode, lib_path = VARIANTS[variant]
+    obj_dir = OBJ if variant == "exact" else os.path.join(OBJ, variant)
+    flags = FLAGS + ["-DGEOT_DISTANCE_MODE=%d" % mode]
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + hdrs):
-            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:
@@ -60,11 +67,18 @@ def build(force=False, verbose=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in srcs]
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    objs = [os.path.join(obj_dir, s.replace(".hip", ".o")) for s in srcs]
+    if force or jobs or _stale(lib_path, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
+
+
+def build_all(force=False, verbose=False, variants=("exact", "fma")):
+    """The default library and the contracted-distance build the parity tests exercise ("fma_xy" on request)."""
+    return [build(force, verbose, v) for v in variants]
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    which = [a for a in sys.argv[1:] if a in VARIANTS] or ["exact"]
+    for v in which:
+        print(build(force="--force" in sys.argv, verbose=True, variant=v))

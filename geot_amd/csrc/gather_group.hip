@@ -1042,4 +1042,6 @@ GEOT_EXPORT int geot_aggregation_cl_grad(int n, int nsample, int c, int w_c, con
 
 GEOT_EXPORT int geot_abi_version(void) { return GEOT_ABI_VERSION; }
 
+GEOT_EXPORT int geot_distance_mode(void) { return GEOT_DISTANCE_MODE; }
+
 GEOT_EXPORT const char *geot_error_string(int e) { return hipGetErrorString((hipError_t)e); }

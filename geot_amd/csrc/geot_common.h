@@ -13,13 +13,33 @@
 
 namespace geot {
 
+// Squared distance, the ONE expression behind every index-producing comparison of the library.
+// GEOT_DISTANCE_MODE (build-time; geot_amd/build.py variants, selected at load time by GEOT_DISTANCE):
+//   0 "exact"  ((dx*dx) + (dy*dy)) + (dz*dz), every operation rounded -- the source semantics of the reference
+//              kernels (sampling_gpu.cu:106-107, ball_query_gpu.cu:34-35, interpolate_gpu.cu:36, ...) and what a
+//              CPU / numpy restatement computes; the default.
+//   1 "fma"    fma(dz,dz, fma(dy,dy, dx*dx))  -- what nvcc's default -fmad=true most likely made of that source
+//   2 "fma_xy" fma(dz,dz, fma(dx,dx, dy*dy))  -- the other contraction an LLVM-style combiner can choose
+//              (the authors' binaries were built -O2 without --use_fast_math, pointnet2/build/.../build.ninja:8; which
+//              form their compiler picked cannot be observed here: a maintainer holding those binaries picks the
+//              mode whose indices match theirs).  The translation units are compiled with -ffp-contract=off, so
+//              the explicit fmaf below is the only fusion.
+#ifndef GEOT_DISTANCE_MODE
+#define GEOT_DISTANCE_MODE 0
+#endif
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz)
 {
     float dx = ax - bx, dy = ay - by, dz = az - bz;
+#if GEOT_DISTANCE_MODE == 1
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+#elif GEOT_DISTANCE_MODE == 2
+    return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+#else
     float s = dx * dx;
     s = s + dy * dy;
     s = s + dz * dz;
     return s;
+#endif
 }
 
 // fminf without the canonicalising v_max_f32 the compiler puts in front of

@@ -29,6 +29,11 @@ extern "C" {
 
 /* ABI version / diagnostics. */
 int geot_abi_version(void);
+/* Which squared-distance arithmetic this build of the library uses (all index-producing ops):
+ * 0 = un-contracted IEEE fp32 ((dx*dx)+(dy*dy))+(dz*dz) (default, libgeot_hip.so);
+ * 1 = fma(dz,dz,fma(dy,dy,dx*dx)) (libgeot_hip_fma.so); 2 = fma(dz,dz,fma(dx,dx,dy*dy)) (libgeot_hip_fma_xy.so):
+ * the two contractions nvcc -fmad=true may have made of the reference's source. */
+int geot_distance_mode(void);
 const char *geot_error_string(int hip_error);
 
 /* ---- furthest point sampling -------------------------------------------

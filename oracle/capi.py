@@ -11,7 +11,10 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgeot_oracle.so")
+# the oracle follows the same GEOT_DISTANCE switch as the HIP library (exact | fma | fma_xy): one twin per mode
+DISTANCE = os.environ.get("GEOT_DISTANCE", "exact")
+_SO_NAME = {"exact": "libgeot_oracle.so", "fma": "libgeot_oracle_fma.so", "fma_xy": "libgeot_oracle_fma_xy.so"}[DISTANCE]
+_SO = os.path.join(_HERE, _SO_NAME)
 _lib = None
 
 _f = ctypes.POINTER(ctypes.c_float)
@@ -22,7 +25,7 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     src = os.path.join(_HERE, "geot_oracle.c")
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "libgeot_oracle.so"])
+        subprocess.check_call(["make", "-s", "-C", _HERE, _SO_NAME])
     return _SO
 
 
