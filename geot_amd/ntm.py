@@ -341,7 +341,7 @@ class _ThreeDLossFn(Function):
                  ptr(nbr), ptr(order), ptr(graph), graph.numel(), ptr(g))
             return None, None, g, None, None, None
         g = torch.zeros_like(ins_T)
-        scale = float(grad_out.item()) / (b * n) if grad_out.numel() == 1 else 1.0 / (b * n)
+        scale = 1.0 / (b * n)        # the upstream gradient is applied on the device below: no host synchronisation
         if ctx.mode == "atomic":     # the scatter form
             call("geot_ntm_threed_loss_grad", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
                  ptr(labels), ptr(ins_T), ptr(nbr), ptr(g))
@@ -350,7 +350,7 @@ class _ThreeDLossFn(Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=positions.device)
             call("geot_ntm_threed_loss_grad_ws", positions.device, b, n, c, k, ctx.sigma, scale, ptr(positions),
                  ptr(labels), ptr(ins_T), ptr(nbr), ptr(order), ptr(g), ptr(ws), nbytes)
-        return None, None, g, None, None, None
+        return None, None, g * grad_out.reshape(()), None, None, None
 
 
 @torch.no_grad()
@@ -420,9 +420,9 @@ class _FeatureLossFn(Function):
         b, n, d = feats.shape
         c, k = ins_T.shape[1], nbr.shape[2]
         g = torch.zeros_like(ins_T)
-        call("geot_ntm_feature_loss_grad", feats.device, b, n, c, k, d, ctx.sigma, float(grad_out.item()) / (b * n * k),
+        call("geot_ntm_feature_loss_grad", feats.device, b, n, c, k, d, ctx.sigma, 1.0 / (b * n * k),
              ptr(feats), ptr(labels), ptr(ins_T), ptr(nbr), ptr(g))
-        return None, None, g, None, None
+        return None, None, g * grad_out.reshape(()), None, None      # upstream gradient stays on the device
 
 
 class feature_space_loss(nn.Module):

@@ -114,9 +114,14 @@ def index_points(points, idx):
 
 
 def _segments(offset, new_offset):
-    off = offset.tolist()
-    n_max = max(e - s for s, e in zip([0] + off[:-1], off)) if off else 0
-    return n_max, int(new_offset[-1].item()) if new_offset.numel() else 0
+    """(largest segment, total number of samples): the output size depends on device data, as in the reference
+    (pointops.py:69-72 reads b + 1 scalars back one by one); here ONE read-back serves both."""
+    if not offset.numel():
+        return 0, 0
+    vals = torch.cat([offset.reshape(-1), new_offset.reshape(-1)[-1:]]).tolist() if new_offset.numel() else offset.tolist() + [0]
+    off, m_total = vals[:-1], int(vals[-1])
+    n_max = max(e - s for s, e in zip([0] + off[:-1], off))
+    return n_max, m_total
 
 
 class FurthestSampling(Function):

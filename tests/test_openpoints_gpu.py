@@ -300,3 +300,38 @@ def test_group_knn_feature_space_and_dilated():
     dil = DilatedKNN(k=4, dilation=3)(pts)
     _, full = KNN(12)(pts, pts)
     assert torch.equal(dil, full[:, :, ::3])
+
+
+@pytest.mark.gpu
+def test_pseudo_mask_refinement_matches_reference_loops():
+    """utils/pseudo_mask.py:5-53, 55-90, 174-196 transcribed with torch index_select loops over the same pointops.knn
+    neighbours (which are checked against the oracle elsewhere) -- against the mirror's single grouping launch."""
+    from geot_amd.utils import pseudo_mask as pm
+    from geot_amd.pointops.functions import pointops
+    xyz, _ = make_batch(2, 3000, start_index=17)
+    pos = torch.from_numpy(xyz).cuda()
+    pred = torch.softmax(torch.randn(2, 17, 3000, device="cuda"), 1)
+    n = 4
+    nbrs, dist = pm.get_neigbor_tensors(pred, n, pos)
+    idx, d = pointops.knn(pos, pos, n + 1)
+    flat = (idx[:, :, 1:] + torch.arange(2, device="cuda").view(2, 1, 1) * 3000)
+    X = pred.transpose(0, 1).contiguous().view(17, -1)
+    for ii in range(n):
+        want = torch.index_select(X, 1, flat[:, :, ii].reshape(-1)).view(17, 2, 3000).transpose(0, 1)
+        assert torch.equal(nbrs[ii], want)
+    assert torch.equal(dist, d[:, :, 1:])
+    beta = torch.exp(torch.tensor(-0.5)).cuda()
+    k_nb, _ = torch.topk(torch.stack(nbrs), k=1, dim=0)
+    ref = pred + beta * k_nb[0] - (pred * k_nb[0]) * beta
+    mask = pm.pseudo_label_refine(pred, 0.5, pos, n, 1)
+    assert torch.equal(mask, ref.max(1)[0].ge(0.5))
+    m2, margin = pm.pseudo_label_refine_margin(pred, 0.1, pos, n, 1)
+    top2 = torch.topk(ref, 2, dim=1)[0]
+    assert torch.allclose(margin, top2[:, 0] - top2[:, 1]) and torch.equal(m2, margin.ge(0.1))
+    cnt = pm.neigh_acc_count(17)
+    lab = pred.argmax(1)
+    cnt.update(lab, pos)
+    nn1 = idx[0, :, 1]
+    acc = (lab[0] == lab[0][nn1])
+    want = np.stack([[int((lab[0] == kk).sum()), int((acc & (lab[0] == kk)).sum())] for kk in range(17)])
+    assert np.array_equal(cnt.acc_array, want)
