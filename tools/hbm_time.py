@@ -1,0 +1,68 @@
+"""HIP-event timing of the HBM-bound kernels of the path at B clouds (the set tools/hbm_lab.py runs under rocprofv3):
+average launch time over ITER launches and algorithmic bytes / time.  Lab tool."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from geot_amd.synth import make_batch, make_logits  # noqa: E402
+from geot_amd.ext import pointnet2_ext as p2  # noqa: E402
+from geot_amd import ntm  # noqa: E402
+from geot_amd.openpoints.models.backbone.transformer_ops import graph_feature  # noqa: E402
+from geot_amd.knn_cuda import knn_sorted  # noqa: E402
+
+B, N, DEV = int(os.environ.get("B", "8")), 24000, "cuda"
+ITER = int(os.environ.get("ITER", "20"))
+CI = int(os.environ.get("CI", "384"))          # interpolation channels (384 = reference order, 1536 = factored FP)
+xyz_np = make_batch(B, N)[0]
+xyz = torch.from_numpy(xyz_np).to(DEV)
+known = xyz[:, :8192].contiguous()
+_, i3 = p2.three_nn(xyz, known)
+w = torch.rand(B, N, 3, device=DEV); w = w / w.sum(2, keepdim=True)
+fi = torch.randn(B, CI, 8192, device=DEV)
+gi = torch.randn(B, CI, N, device=DEV)
+feats = torch.randn(B, 64, N, device=DEV)
+c6000 = p2.furthest_point_sampling(xyz, 6000)
+new_xyz = p2.gather_points(xyz.transpose(1, 2).contiguous(), c6000).transpose(1, 2).contiguous()
+bq = p2.ball_query(new_xyz, xyz, 0.1, 32)
+go = torch.randn(B, 64, 6000, 32, device=DEV)
+xq = torch.randn(B, 384, 8192, device=DEV)
+_, kidx = knn_sorted(known, known, 4)
+C = 17
+logits = torch.from_numpy(make_logits(xyz_np, 1)).to(DEV)
+prob = torch.softmax(logits, 1)
+cm = torch.softmax(torch.randn(C, C, device=DEV), 1)
+pred = ntm.Ins_T_mean(nclasses=C).to(DEV)
+with torch.no_grad():
+    insT = pred(prob, cm)
+gT = torch.randn_like(insT)
+MB = 1e6
+cases = {
+    "three_interpolate fwd C=%d" % CI: (lambda: p2.three_interpolate(fi, i3, w), 4 * B * (CI * N + CI * 8192) + 24 * B * N),
+    "three_interpolate bwd C=%d" % CI: (lambda: p2.three_interpolate_grad(gi, i3, w, 8192), 4 * B * (CI * N + CI * 8192) + 24 * B * N),
+    "group_points fwd C=64 6000x32": (lambda: p2.group_points(feats, bq), 4 * B * (64 * 192000 + 192000 + 64 * N)),
+    "group_points bwd C=64 6000x32": (lambda: p2.group_points_grad(go, bq, N), 4 * B * (64 * 192000 + 192000 + 64 * N)),
+    "graph_feature fwd C=384 8192x4": (lambda: graph_feature(xq, xq, kidx), 4 * B * (2 * 384 * 8192 * 4 + 2 * 384 * 8192 + 8192 * 4)),
+    "sig_t_mean fwd": (lambda: pred(prob, cm), 4 * B * N * (17 + 289)),
+    "correct_logits fwd": (lambda: ntm.correct_logits(logits, insT, cm, 0.9), 4 * B * N * (17 + 289 + 17)),
+}
+only = os.environ.get("ONLY")
+with torch.no_grad():
+    for name, (fn, nbytes) in cases.items():
+        if only and only not in name:
+            continue
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(ITER):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / ITER * 1e3
+        print("%-36s %8.1f us  %7.1f MB  %6.2f TB/s  %4.1f %% of 8 TB/s" % (name, us, nbytes / MB, nbytes / us / 1e6, nbytes / us / 1e6 / 8 * 100), flush=True)
+# backward of the NTM stream kernels (autograd)
+if not only or "bwd" in only:
+    pass
