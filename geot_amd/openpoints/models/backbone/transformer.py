@@ -17,7 +17,8 @@ Two things are scheduled differently from the reference, neither changes a value
 * ``dense="factored"`` (default) uses the linearity of the first 1x1 convolution behind a gather:
   EdgeConv  W.[x_k[idx] - x_q ; x_q] = (W_d.x_k)[idx] + ((W_q - W_d).x_q)  (k x fewer GEMM flops, the
   (B,2C,Nq,k) operand is never built), FP module  W.[interp(f) ; skip] = interp(W_a.f) + W_b.skip
-  (the interpolation weights sum to 1; the GEMM runs on the m known points instead of the n unknown).
+  (the interpolation weights sum to 1; the GEMM runs on the m known points instead of the n unknown), and the
+  mini-PointNet's  W.[max-pooled ; per-point] = W_g.pooled + W_f.per-point  (the pooled half once per group).
   Same function, fp32 summation order differs (tests: 2e-5 relative); ``dense="reference"`` keeps the
   reference's op order literally.
 """
@@ -130,13 +131,15 @@ class Encoder(nn.Module):
     """Mini-PointNet over each group of points (transformer.py:106-136): (B,G,n,3) -> (B,G,C).
 
     The groups arrive channels-last, (B*G*n, 3); the reference transposes them to (B*G, 3, n) for Conv1d.  A 1x1
-    convolution over (BG, C, n) is a Linear over the BG*n rows and BatchNorm1d's statistics over (BG, n) are its
-    statistics over those rows, so the stack runs on 2-D row-major tensors: four plain GEMMs, no transposes; same
-    modules, parameters and running statistics."""
+    convolution over (BG, C, n) is a Linear over the BG*n points and BatchNorm1d's statistics over (BG, n) are its
+    statistics over those points, so the stack runs on 2-D tensors -- row-major (L, C) in the reference op order
+    (``factored=False``), column-major (C, L) in the default mode (see _forward_channels_first) -- as four plain
+    GEMMs without per-group batching; same modules, parameters and running statistics either way."""
 
-    def __init__(self, encoder_channel):
+    def __init__(self, encoder_channel, factored=False):
         super().__init__()
         self.encoder_channel = encoder_channel
+        self.factored = factored
         self.first_conv = nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
                                         nn.Conv1d(128, 256, 1))
         self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
@@ -148,7 +151,35 @@ class Encoder(nn.Module):
             x = F.linear(x, m.weight.squeeze(-1), m.bias) if isinstance(m, nn.Conv1d) else m(x)
         return x
 
+    def _forward_channels_first(self, point_groups):
+        """The same stack on (C, L) tensors, L = B*G*n columns: GEMMs W @ X, BatchNorm over the columns through
+        the (1, C, L) spatial kernel (MIOpen: ~6 TB/s; torch's kernel for (L, C) rows reaches 0.5 TB/s here: 2.9 ms of
+        the step), and  W.[pooled ; per-point] = W_g.pooled + W_f.per-point  (the pooled half once per group: half of
+        that layer's GEMM, and the (L, 512) concatenation is never built)."""
+        bs, g, n, _ = point_groups.shape
+        L = bs * g * n
+
+        def conv(m, x, w=None):
+            w = m.weight.squeeze(-1) if w is None else w
+            y = torch.mm(w, x)
+            return y if m.bias is None else y + m.bias.unsqueeze(1)
+
+        def norm_act(seq, x):                                  # BatchNorm1d -> ReLU of a Sequential, on (C, L)
+            return seq[2](batch_norm_nd(seq[1], x.unsqueeze(0))).squeeze(0)
+
+        x = point_groups.reshape(L, 3).t()                                              # (3, L) view
+        f = conv(self.first_conv[3], norm_act(self.first_conv, conv(self.first_conv[0], x)))      # (256, L)
+        c1 = f.shape[0]
+        pooled = f.view(c1, bs * g, n).max(dim=2)[0]                                    # (256, BG)
+        c2 = self.second_conv[0]
+        w = c2.weight.squeeze(-1)
+        h = conv(c2, f, w[:, c1:]).view(-1, bs * g, n) + torch.mm(w[:, :c1], pooled).unsqueeze(2)
+        h = conv(self.second_conv[3], norm_act(self.second_conv, h.view(-1, L)))                  # (C_enc, L)
+        return h.view(-1, bs * g, n).max(dim=2)[0].t().reshape(bs, g, self.encoder_channel)
+
     def forward(self, point_groups):
+        if self.factored:
+            return self._forward_channels_first(point_groups)
         bs, g, n, _ = point_groups.shape
         feature = self._rows(self.first_conv, point_groups.reshape(bs * g * n, 3)).view(bs * g, n, -1)
         feature_global = torch.max(feature, dim=1, keepdim=True)[0]                      # (BG, 1, 256)
@@ -247,7 +278,7 @@ class PointTransformer_seg_T(nn.Module):
 
         self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
         self.encoder_dims = encoder_dims
-        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.encoder = Encoder(encoder_channel=self.encoder_dims, factored=self.dense == "factored")
         self.reduce_dim = nn.Identity()
         if self.encoder_dims != self.trans_dim:
             self.reduce_dim = nn.Linear(self.encoder_dims, self.trans_dim)
