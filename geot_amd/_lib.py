@@ -87,6 +87,11 @@ PROTOTYPES.update({
                                    _c_void_p],
 })
 PROTOTYPES.update({
+    "geot_bn_stats": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
+    "geot_bn_apply": [_c_int] * 4 + [_P] * 4 + [_c_void_p],
+    "geot_bn_bwd_reduce": [_c_int] * 4 + [_P] * 7 + [_c_void_p],
+    "geot_bn_bwd_apply": [_c_int] * 4 + [_P] * 10 + [_c_void_p],
+    "geot_fp_front": [_c_int] * 5 + [_P] * 7 + [_c_void_p],
     "geot_edgeconv_gn_max": [_c_int] * 6 + [_c_float, _c_float] + [_P] * 11 + [ctypes.c_longlong, _c_void_p],
     "geot_edgeconv_gn_max_grad": [_c_int] * 6 + [_c_float] + [_P] * 15 + [ctypes.c_longlong, _c_void_p],
 })
@@ -105,9 +110,11 @@ PLAIN = {
     "geot_knn_grid_eligible": ([_c_int, _c_int, _c_int, _c_int], _c_int),
     "geot_ball_grid_eligible": ([_c_int, _c_int, _c_int, _c_float, _c_int], _c_int),
     "geot_edgeconv_eligible": ([_c_int] * 6, _c_int),
+    "geot_bn_slices": ([_c_int] * 3, _c_int),
+    "geot_fp_front_slices": ([_c_int] * 4, _c_int),
     "geot_edgeconv_ws_bytes": ([_c_int] * 5, ctypes.c_longlong),
 }
-ABI_VERSION = 2     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
+ABI_VERSION = 3     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
 
 _lib = None
 

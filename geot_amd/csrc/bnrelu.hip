@@ -1,0 +1,358 @@
+// bnrelu.hip -- BatchNorm (+ ReLU) over channels-first (B, C, L) tensors as HBM-bound streaming kernels, and the
+// PointnetFPModule front end fused with the statistics of the BatchNorm behind it (gfx950 / MI355X).
+//
+// Callers (behaviour, not code): the SharedMLP stages conv1x1 -> BatchNorm -> ReLU of pointnet2/pytorch_utils.py:8-117
+// as PointnetFPModule (pointnet2/pointnet2_modules.py:597-642) and the mini-PointNet Encoder
+// (openpoints/models/backbone/transformer.py:106-136) run them in training mode.  Stock PyTorch makes 5 passes over
+// the tensor forward (statistics; normalise read + write; ReLU read + write) and 8 backward; at 8 clouds x 24 000
+// points x 1536 channels one pass is 1.18 GB.  Here: forward = statistics pass (free when the producer is the FP
+// front-end kernel below) + ONE apply pass (scale/shift/ReLU); backward = ONE reduce pass + ONE apply pass, the ReLU
+// mask recomputed from x instead of stored.  The per-channel arithmetic between the passes (mean, variance, running
+// statistics, SyncBatchNorm's all-reduce) is O(C) and stays in the Python wrapper (geot_amd/fused_norm.py).
+//
+// Algorithmic bytes: apply 8 B/element; backward reduce 8 B, backward apply 12 B; FP front end 4 (C n + C m) + 24 n + 4 Cs n.
+#include "geot_common.h"
+#include "geot_hip.h"
+
+namespace geot {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_SLICES = 32;
+
+__device__ __forceinline__ float bn_wave_sum(float v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+// two block-wide sums, written by thread 0 / 1 to dst[0], dst[1] (fixed order: deterministic)
+__device__ __forceinline__ void bn_block_store2(float a, float b, float *__restrict__ dst)
+{
+    __shared__ float red[BN_THREADS / 64][2];
+    a = bn_wave_sum(a);
+    b = bn_wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < BN_THREADS / 64; ++w) t += red[w][threadIdx.x];
+        dst[threadIdx.x] = t;
+    }
+}
+
+// grid (slices, C, B): partial[((b * C + c) * slices + s) * 2 + {0, 1}] = sum x, sum x^2 over the slice
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int c, int l, const float *__restrict__ x,
+                                                              float *__restrict__ partial)
+{
+    const int bi = blockIdx.z, cc = blockIdx.y;
+    const float *row = x + ((size_t)bi * c + cc) * l;
+    const int per = (((l + gridDim.x - 1) / gridDim.x) + 3) & ~3;
+    const int e0 = blockIdx.x * per, e1 = min(l, e0 + per);
+    float s = 0.f, ss = 0.f;
+    if (e0 >= e1) {
+        // empty slice (short rows): contributes zeros
+    } else if ((((uintptr_t)row) & 15) == 0) {
+        const int v0 = e0 >> 2, v1 = e1 >> 2;
+        for (int v = v0 + threadIdx.x; v < v1; v += BN_THREADS) {
+            const float4 q = reinterpret_cast<const float4 *>(row)[v];
+            s += (q.x + q.y) + (q.z + q.w);
+            ss = fmaf(q.x, q.x, fmaf(q.y, q.y, fmaf(q.z, q.z, fmaf(q.w, q.w, ss))));
+        }
+        for (int e = (v1 << 2) + threadIdx.x; e < e1; e += BN_THREADS) { s += row[e]; ss = fmaf(row[e], row[e], ss); }
+    } else {
+        for (int e = e0 + threadIdx.x; e < e1; e += BN_THREADS) { s += row[e]; ss = fmaf(row[e], row[e], ss); }
+    }
+    bn_block_store2(s, ss, partial + (((size_t)bi * c + cc) * gridDim.x + blockIdx.x) * 2);
+}
+
+// out = x * scale[c] + shift[c], clamped at 0 when relu; grid (gx, C, B)
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(int c, int l, int relu, const float *__restrict__ x,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, float *__restrict__ out)
+{
+    const int bi = blockIdx.z, cc = blockIdx.y;
+    const size_t base = ((size_t)bi * c + cc) * l;
+    const float a = scale[cc], b = shift[cc];
+    const float lo = relu ? 0.f : -INFINITY;
+    if ((((uintptr_t)(x + base) | (uintptr_t)(out + base)) & 15) == 0) {
+        const int vec = l >> 2;
+        for (int v = blockIdx.x * BN_THREADS + threadIdx.x; v < vec; v += gridDim.x * BN_THREADS) {
+            float4 q = reinterpret_cast<const float4 *>(x + base)[v];
+            q.x = fmaxf(fmaf(q.x, a, b), lo);
+            q.y = fmaxf(fmaf(q.y, a, b), lo);
+            q.z = fmaxf(fmaf(q.z, a, b), lo);
+            q.w = fmaxf(fmaf(q.w, a, b), lo);
+            reinterpret_cast<float4 *>(out + base)[v] = q;
+        }
+        for (int e = (vec << 2) + blockIdx.x * BN_THREADS + threadIdx.x; e < l; e += gridDim.x * BN_THREADS)
+            out[base + e] = fmaxf(fmaf(x[base + e], a, b), lo);
+    } else {
+        for (int e = blockIdx.x * BN_THREADS + threadIdx.x; e < l; e += gridDim.x * BN_THREADS)
+            out[base + e] = fmaxf(fmaf(x[base + e], a, b), lo);
+    }
+}
+
+// backward reduce: g = dz * [x*scale + shift > 0 or !relu];  partial = (sum g, sum g * xhat),  xhat = (x - mean) rstd
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_reduce_kernel(int c, int l, int relu, const float *__restrict__ x,
+                                                                   const float *__restrict__ dz,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift,
+                                                                   const float *__restrict__ mean,
+                                                                   const float *__restrict__ rstd,
+                                                                   float *__restrict__ partial)
+{
+    const int bi = blockIdx.z, cc = blockIdx.y;
+    const size_t base = ((size_t)bi * c + cc) * l;
+    const float a = scale[cc], b = shift[cc], mu = mean[cc], r = rstd[cc];
+    const int per = (((l + gridDim.x - 1) / gridDim.x) + 3) & ~3;
+    const int e0 = blockIdx.x * per, e1 = min(l, e0 + per);
+    float s = 0.f, sx = 0.f;
+    auto one = [&](float xv, float gv) {
+        const float g = (!relu || fmaf(xv, a, b) > 0.f) ? gv : 0.f;
+        s += g;
+        sx = fmaf(g, (xv - mu) * r, sx);
+    };
+    if (e0 >= e1) {
+        // empty slice
+    } else if ((((uintptr_t)(x + base) | (uintptr_t)(dz + base)) & 15) == 0) {
+        const int v0 = e0 >> 2, v1 = e1 >> 2;
+        for (int v = v0 + threadIdx.x; v < v1; v += BN_THREADS) {
+            const float4 q = reinterpret_cast<const float4 *>(x + base)[v];
+            const float4 g = reinterpret_cast<const float4 *>(dz + base)[v];
+            one(q.x, g.x); one(q.y, g.y); one(q.z, g.z); one(q.w, g.w);
+        }
+        for (int e = (v1 << 2) + threadIdx.x; e < e1; e += BN_THREADS) one(x[base + e], dz[base + e]);
+    } else {
+        for (int e = e0 + threadIdx.x; e < e1; e += BN_THREADS) one(x[base + e], dz[base + e]);
+    }
+    bn_block_store2(s, sx, partial + (((size_t)bi * c + cc) * gridDim.x + blockIdx.x) * 2);
+}
+
+// backward apply: dx = k0[c] * (g - c1[c] - xhat * c2[c])   (training: k0 = gamma rstd, c1 = mean(g), c2 = mean(g xhat);
+//                                                           eval: k0 = gamma rstd_running, c1 = c2 = 0)
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(int c, int l, int relu, const float *__restrict__ x,
+                                                                  const float *__restrict__ dz,
+                                                                  const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift,
+                                                                  const float *__restrict__ mean,
+                                                                  const float *__restrict__ rstd,
+                                                                  const float *__restrict__ k0,
+                                                                  const float *__restrict__ c1,
+                                                                  const float *__restrict__ c2, float *__restrict__ dx)
+{
+    const int bi = blockIdx.z, cc = blockIdx.y;
+    const size_t base = ((size_t)bi * c + cc) * l;
+    const float a = scale[cc], b = shift[cc], mu = mean[cc], r = rstd[cc], kk = k0[cc], m1 = c1[cc], m2 = c2[cc];
+    auto one = [&](float xv, float gv) {
+        const float g = (!relu || fmaf(xv, a, b) > 0.f) ? gv : 0.f;
+        return kk * (g - m1 - (xv - mu) * r * m2);
+    };
+    if ((((uintptr_t)(x + base) | (uintptr_t)(dz + base) | (uintptr_t)(dx + base)) & 15) == 0) {
+        const int vec = l >> 2;
+        for (int v = blockIdx.x * BN_THREADS + threadIdx.x; v < vec; v += gridDim.x * BN_THREADS) {
+            const float4 q = reinterpret_cast<const float4 *>(x + base)[v];
+            const float4 g = reinterpret_cast<const float4 *>(dz + base)[v];
+            reinterpret_cast<float4 *>(dx + base)[v] = make_float4(one(q.x, g.x), one(q.y, g.y), one(q.z, g.z), one(q.w, g.w));
+        }
+        for (int e = (vec << 2) + blockIdx.x * BN_THREADS + threadIdx.x; e < l; e += gridDim.x * BN_THREADS)
+            dx[base + e] = one(x[base + e], dz[base + e]);
+    } else {
+        for (int e = blockIdx.x * BN_THREADS + threadIdx.x; e < l; e += gridDim.x * BN_THREADS)
+            dx[base + e] = one(x[base + e], dz[base + e]);
+    }
+}
+
+// ---- FP front end: y[b,c,e] = sum_t w[e,t] A[b,c,idx[e,t]] + sum_k Wb[c,k] skip[b,k,e], + its BatchNorm sums -----
+// (the first SharedMLP stage of a PointnetFPModule with the 1x1 convolution moved in front of the interpolation:
+// A = W_a known_feats; pointnet2_modules.py:619-640).  CH rows of A in LDS, queries streamed, 2 elements per thread in
+// flight; per-(b, c, slice) partial sums of y and y^2 leave with the result, so the BatchNorm needs no pass of its own.
+constexpr int FP_THREADS = 1024;
+constexpr int FP_LDS_BYTES = 144 * 1024;
+constexpr int FP_MAX_SKIP = 8;
+
+template <int CH>
+__global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int n, int cs, const float *__restrict__ A,
+                                                              const int *__restrict__ idx, const float *__restrict__ w,
+                                                              const float *__restrict__ skip, const float *__restrict__ Wb,
+                                                              float *__restrict__ y, float *__restrict__ partial)
+{
+    extern __shared__ float fp_rows[]; // [CH][m]
+    __shared__ float wb[CH][FP_MAX_SKIP];
+    __shared__ float red[FP_THREADS / 64][CH][2];
+    const int bi = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, c - c0);
+    {
+        const float *src = A + ((size_t)bi * c + c0) * m;
+        const int count = nch * m;
+        if ((((uintptr_t)src) & 15) == 0) {
+            const int vec = count >> 2;
+            for (int v = threadIdx.x; v < vec; v += FP_THREADS) reinterpret_cast<float4 *>(fp_rows)[v] = reinterpret_cast<const float4 *>(src)[v];
+            for (int e = (vec << 2) + threadIdx.x; e < count; e += FP_THREADS) fp_rows[e] = src[e];
+        } else {
+            for (int e = threadIdx.x; e < count; e += FP_THREADS) fp_rows[e] = src[e];
+        }
+    }
+    if (threadIdx.x < CH * FP_MAX_SKIP) {
+        const int l = threadIdx.x / FP_MAX_SKIP, k = threadIdx.x % FP_MAX_SKIP;
+        wb[l][k] = (l < nch && k < cs) ? Wb[(size_t)(c0 + l) * cs + k] : 0.f;
+    }
+    __syncthreads();
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int e0 = blockIdx.x * per, e1 = min(n, e0 + per);
+    float s[CH], ss[CH];
+#pragma unroll
+    for (int l = 0; l < CH; ++l) s[l] = ss[l] = 0.f;
+    constexpr int U = 2;
+    for (int eb = e0 + threadIdx.x; eb < e1; eb += U * FP_THREADS) {
+        int ii[U][3];
+        float ww[U][3], sk[U][FP_MAX_SKIP];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = eb + u * FP_THREADS;
+            const bool ok = e < e1;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                ii[u][t] = ok ? idx[((size_t)bi * n + e) * 3 + t] : 0;
+                ww[u][t] = ok ? w[((size_t)bi * n + e) * 3 + t] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < FP_MAX_SKIP; ++k) sk[u][k] = (ok && k < cs) ? skip[((size_t)bi * cs + k) * n + e] : 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l < CH; ++l) {
+            if (l < nch) {
+                const float *R = fp_rows + (size_t)l * m;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int e = eb + u * FP_THREADS;
+                    float v = R[ii[u][0]] * ww[u][0];
+                    v = v + R[ii[u][1]] * ww[u][1];
+                    v = v + R[ii[u][2]] * ww[u][2];           // ((p0 w0 + p1 w1) + p2 w2): three_interpolate's order
+#pragma unroll
+                    for (int k = 0; k < FP_MAX_SKIP; ++k) v = fmaf(wb[l][k], sk[u][k], v);
+                    if (e < e1) {
+                        y[((size_t)bi * c + c0 + l) * n + e] = v;
+                        s[l] += v;
+                        ss[l] = fmaf(v, v, ss[l]);
+                    }
+                }
+            }
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int l = 0; l < CH; ++l) {
+        const float a = bn_wave_sum(s[l]), b = bn_wave_sum(ss[l]);
+        if (lane == 0) { red[wave][l][0] = a; red[wave][l][1] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * CH) {
+        const int l = threadIdx.x >> 1, q = threadIdx.x & 1;
+        if (l < nch) {
+            float t = 0.f;
+            for (int v = 0; v < FP_THREADS / 64; ++v) t += red[v][l][q];
+            partial[(((size_t)bi * c + c0 + l) * gridDim.x + blockIdx.x) * 2 + q] = t;
+        }
+    }
+}
+
+static int bn_slices_for(int b, int c, int l)
+{
+    long long rows = (long long)b * c;
+    long long sl = (1024 + rows - 1) / rows;       // >= 1024 workgroups when the rows alone do not give them
+    const long long maxs = l / 4096;
+    if (sl > maxs) sl = maxs;
+    if (sl < 1) sl = 1;
+    if (sl > BN_MAX_SLICES) sl = BN_MAX_SLICES;
+    return (int)sl;
+}
+static int fp_ch_for(int m)
+{
+    const int fit = FP_LDS_BYTES / ((int)sizeof(float) * m);
+    return fit >= 8 ? 8 : (fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0)));
+}
+static int fp_slices_for(int b, int c, int ch, int n)
+{
+    const long long chunks = ((long long)c + ch - 1) / ch * b;
+    long long sl = (512 + chunks - 1) / chunks;
+    const long long maxs = n / 4096;
+    if (sl > maxs) sl = maxs;
+    if (sl < 1) sl = 1;
+    if (sl > BN_MAX_SLICES) sl = BN_MAX_SLICES;
+    return (int)sl;
+}
+static bool bn_dims_ok(int b, int c, int l) { return b >= 1 && c >= 1 && l >= 1 && b <= 65535 && c <= 65535; }
+static int bn_gx(int l)
+{
+    int gx = (l / 4 + BN_THREADS * 4 - 1) / (BN_THREADS * 4);
+    return gx < 1 ? 1 : (gx > 64 ? 64 : gx);
+}
+
+} // namespace geot
+
+using namespace geot;
+
+GEOT_EXPORT int geot_bn_slices(int b, int c, int l) { return bn_dims_ok(b, c, l) ? bn_slices_for(b, c, l) : -1; }
+
+GEOT_EXPORT int geot_bn_stats(int b, int c, int l, const float *x, float *partial, void *stream)
+{
+    if (!bn_dims_ok(b, c, l)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(bn_slices_for(b, c, l), c, b), dim3(BN_THREADS), 0, (hipStream_t)stream, c, l, x, partial);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_apply(int b, int c, int l, int relu, const float *x, const float *scale, const float *shift,
+                              float *out, void *stream)
+{
+    if (!bn_dims_ok(b, c, l)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(bn_gx(l), c, b), dim3(BN_THREADS), 0, (hipStream_t)stream, c, l, relu, x, scale, shift, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_bwd_reduce(int b, int c, int l, int relu, const float *x, const float *dz, const float *scale,
+                                   const float *shift, const float *mean, const float *rstd, float *partial, void *stream)
+{
+    if (!bn_dims_ok(b, c, l)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(bn_slices_for(b, c, l), c, b), dim3(BN_THREADS), 0, (hipStream_t)stream, c, l,
+                       relu, x, dz, scale, shift, mean, rstd, partial);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_bwd_apply(int b, int c, int l, int relu, const float *x, const float *dz, const float *scale,
+                                  const float *shift, const float *mean, const float *rstd, const float *k0,
+                                  const float *c1, const float *c2, float *dx, void *stream)
+{
+    if (!bn_dims_ok(b, c, l)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_gx(l), c, b), dim3(BN_THREADS), 0, (hipStream_t)stream, c, l, relu, x, dz,
+                       scale, shift, mean, rstd, k0, c1, c2, dx);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_fp_front_slices(int b, int c, int m, int n)
+{
+    const int ch = fp_ch_for(m);
+    return (bn_dims_ok(b, c, n) && m >= 1 && ch >= 1) ? fp_slices_for(b, c, ch, n) : -1;
+}
+
+GEOT_EXPORT int geot_fp_front(int b, int c, int m, int n, int cs, const float *A, const int *idx, const float *weight,
+                              const float *skip, const float *Wb, float *y, float *partial, void *stream)
+{
+    const int ch = fp_ch_for(m);
+    if (!bn_dims_ok(b, c, n) || m < 1 || ch < 1 || cs < 0 || cs > FP_MAX_SKIP || (cs > 0 && (!skip || !Wb)))
+        return hipErrorInvalidValue;
+    const int slices = fp_slices_for(b, c, ch, n);
+    const size_t lds = (size_t)ch * m * sizeof(float);
+    const dim3 grid(slices, (c + ch - 1) / ch, b);
+    hipError_t e = hipSuccess;
+#define GEOT_FP_LAUNCH(CHV)                                                                                       \
+    {                                                                                                             \
+        e = allow_big_lds((const void *)fp_front_kernel<CHV>, lds);                                               \
+        if (e != hipSuccess) return e;                                                                            \
+        hipLaunchKernelGGL((fp_front_kernel<CHV>), grid, dim3(FP_THREADS), lds, (hipStream_t)stream, c, m, n, cs, A, \
+                           idx, weight, skip, Wb, y, partial);                                                    \
+    }
+    if (ch == 8) GEOT_FP_LAUNCH(8) else if (ch == 4) GEOT_FP_LAUNCH(4) else if (ch == 2) GEOT_FP_LAUNCH(2) else GEOT_FP_LAUNCH(1)
+#undef GEOT_FP_LAUNCH
+    return hipGetLastError();
+}

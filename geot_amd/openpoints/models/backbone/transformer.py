@@ -36,6 +36,7 @@ from ....knn_cuda import KNN, knn_sorted
 from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused,  # noqa: F401
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
+from ....fused_norm import bn_act, fp_front, fp_front_eligible
 
 
 class DropPath(nn.Module):
@@ -165,7 +166,7 @@ class Encoder(nn.Module):
             return y if m.bias is None else y + m.bias.unsqueeze(1)
 
         def norm_act(seq, x):                                  # BatchNorm1d -> ReLU of a Sequential, on (C, L)
-            return seq[2](batch_norm_nd(seq[1], x.unsqueeze(0))).squeeze(0)
+            return bn_act(seq[1], x.unsqueeze(0), relu=True).squeeze(0)
 
         x = point_groups.reshape(L, 3).t()                                              # (3, L) view
         f = conv(self.first_conv[3], norm_act(self.first_conv, conv(self.first_conv[0], x)))      # (256, L)
@@ -247,13 +248,28 @@ def _fp_factored(fp, unknown, known, unknow_feats, known_feats):
     c = known_feats.shape[1]
     w = conv.weight.view(conv.out_channels, -1)
     a = pointwise(w[:, :c], known_feats)                                 # (B, Cout, m): GEMM on the known points
-    dist, idx = pt_utils.three_nn(unknown, known)
-    r = 1.0 / (dist + 1e-8)
-    y = pt_utils.three_interpolate(a, idx, r / torch.sum(r, dim=2, keepdim=True))
+    dist2, idx = pt_utils._ext.three_nn(unknown.contiguous(), known.contiguous())
+    has_bn = any(name == "bn" for name, _ in first.named_children())
+    post_act = next(iter(first.named_children()))[0] == "conv"            # conv -> BatchNorm -> ReLU order
+    if conv.bias is None and has_bn and post_act and fp_front_eligible(a, unknow_feats):
+        # interpolation + skip channels + the BatchNorm sums in one kernel, then BatchNorm + ReLU in one pass
+        weight = pt_utils._ext.fp_weights(dist2)
+        y, partial = fp_front(a, idx, weight, unknow_feats, None if unknow_feats is None else w[:, c:])
+        relu = any(isinstance(mod, nn.ReLU) for _, mod in first.named_children())
+        y = bn_act(first.bn.bn, y, relu=relu, partial=partial)
+        for name, mod in first.named_children():
+            if name not in ("conv", "bn") and not isinstance(mod, nn.ReLU):
+                y = mod(y)
+        return shared_mlp_nd(layers[1:], y)
+    y = pt_utils.three_interpolate(a, idx, pt_utils._ext.fp_weights(dist2))
     if unknow_feats is not None:
         y = y + pointwise(w[:, c:], unknow_feats)
     if conv.bias is not None:
         y = y + conv.bias.view(1, -1, 1)
+    return _rest_of_stage(first, layers, y)
+
+
+def _rest_of_stage(first, layers, y):
     for name, mod in first.named_children():
         if name != "conv":
             y = batch_norm_nd(mod.bn, y) if name == "bn" else mod(y)

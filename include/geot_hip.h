@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEOT_ABI_VERSION 2
+#define GEOT_ABI_VERSION 3
 
 /* ABI version / diagnostics. */
 int geot_abi_version(void);
@@ -128,6 +128,33 @@ int geot_knn_sorted_ws(int b, int nq, int nr, int k, const float *query, const f
                        float *dist2, void *workspace, long long ws_bytes, void *stream);
 int geot_three_nn_ws(int b, int n, int m, const float *unknown, const float *known, float *dist2, int *idx,
                      void *workspace, long long ws_bytes, void *stream);
+
+/* BatchNorm (+ ReLU) on channels-first (b, c, l) tensors as streaming passes -- the conv1x1 -> BatchNorm -> ReLU
+ * stages of SharedMLP (pointnet2/pytorch_utils.py:8-117) and of the mini-PointNet Encoder (transformer.py:106-136) in
+ * training mode.  The O(c) arithmetic between the passes (mean / variance / running statistics / SyncBatchNorm's
+ * all-reduce) is the caller's (geot_amd/fused_norm.py).
+ *   geot_bn_slices      S = number of slices a row is cut into for the partial sums (<= 32)
+ *   geot_bn_stats       partial (b,c,S,2) = per-slice (sum x, sum x^2)
+ *   geot_bn_apply       out = x * scale[c] + shift[c], clamped at 0 when relu
+ *   geot_bn_bwd_reduce  partial (b,c,S,2) = (sum g, sum g xhat), g = dz masked by [x*scale+shift > 0] when relu,
+ *                       xhat = (x - mean[c]) * rstd[c]
+ *   geot_bn_bwd_apply   dx = k0[c] * (g - c1[c] - xhat * c2[c])
+ * and the PointnetFPModule front end (pointnet2_modules.py:619-640) with the first 1x1 convolution moved in front of
+ * the interpolation:  y (b,c,n) = sum_t weight[.,t] A[:, idx[.,t]] + Wb (c,cs) skip (b,cs,n),  A (b,c,m) = W_a
+ * known_feats from the caller's GEMM, cs <= 8; partial (b,c,S',2) = per-slice (sum y, sum y^2) for the BatchNorm
+ * behind it (S' = geot_fp_front_slices).  Rows of A must fit the LDS (m <= 36864). */
+int geot_bn_slices(int b, int c, int l);
+int geot_bn_stats(int b, int c, int l, const float *x, float *partial, void *stream);
+int geot_bn_apply(int b, int c, int l, int relu, const float *x, const float *scale, const float *shift, float *out,
+                  void *stream);
+int geot_bn_bwd_reduce(int b, int c, int l, int relu, const float *x, const float *dz, const float *scale,
+                       const float *shift, const float *mean, const float *rstd, float *partial, void *stream);
+int geot_bn_bwd_apply(int b, int c, int l, int relu, const float *x, const float *dz, const float *scale,
+                      const float *shift, const float *mean, const float *rstd, const float *k0, const float *c1,
+                      const float *c2, float *dx, void *stream);
+int geot_fp_front_slices(int b, int c, int m, int n);
+int geot_fp_front(int b, int c, int m, int n, int cs, const float *A, const int *idx, const float *weight,
+                  const float *skip, const float *Wb, float *y, float *partial, void *stream);
 
 /* EdgeConv tail = the rest of DGCNN_Propagation's layer behind the (linear) 1x1 convolution
  * (openpoints/models/backbone/transformer.py:366-379: Conv2d -> GroupNorm(groups) -> LeakyReLU(slope) ->

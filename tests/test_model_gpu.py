@@ -150,3 +150,62 @@ def test_edgeconv_tail_matches_composed(b, c, nq, nk, k, groups):
     for name, a, f in zip(("out", "dP", "dQ", "dgamma", "dbeta"), *res):
         scale = float(a.abs().max())
         assert float((a - f).abs().max()) <= 2e-5 * scale, (name, float((a - f).abs().max()), scale)
+
+
+@pytest.mark.parametrize("b,c,l,relu,training", [(2, 37, 1000, True, True), (3, 8, 4099, False, True), (1, 64, 24000, True, True),
+                                                 (2, 16, 513, True, False)])
+def test_bn_act_equals_torch_batchnorm_relu(b, c, l, relu, training):
+    """fused_norm.bn_act vs nn.BatchNorm1d (+ ReLU): outputs, every gradient, running statistics, eval mode."""
+    from geot_amd.fused_norm import bn_act
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(b * 100 + c)
+    x0 = (torch.randn(b, c, l, generator=g) * 2 + 0.5).to(dev)
+    up = torch.randn(b, c, l, generator=g).to(dev)
+    ref, ours = torch.nn.BatchNorm1d(c).to(dev), torch.nn.BatchNorm1d(c).to(dev)
+    with torch.no_grad():
+        ref.weight.copy_(torch.randn(c, generator=g)); ref.bias.copy_(torch.randn(c, generator=g))
+        ref.running_mean.uniform_(-0.5, 0.5); ref.running_var.uniform_(0.5, 2.0)
+    ours.load_state_dict(ref.state_dict())
+    ref.train(training); ours.train(training)
+    res = []
+    for mod, fused in ((ref, False), (ours, True)):
+        x = x0.clone().requires_grad_(True)
+        for _ in range(2):                                   # two steps: the running statistics move twice
+            y = bn_act(mod, x, relu=relu) if fused else (torch.relu(mod(x)) if relu else mod(x))
+        (y * up).sum().backward()
+        res.append((y.detach(), x.grad, mod.weight.grad, mod.bias.grad, mod.running_mean.clone(), mod.running_var.clone(),
+                    mod.num_batches_tracked.clone()))
+    for name, a, f in zip(("out", "dx", "dgamma", "dbeta", "running_mean", "running_var"), *[r[:6] for r in res]):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - f).abs().max()) <= 2e-5 * scale + 1e-6, (name, float((a - f).abs().max()), scale)
+    assert int(res[0][6]) == int(res[1][6])
+
+
+def test_fp_front_equals_interpolate_plus_skip_conv():
+    """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
+    from geot_amd.fused_norm import fp_front
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    dev = torch.device("cuda:0")
+    _, pos, _ = _batch(2, 6000, dev)
+    known = pos[:, :1500].contiguous()
+    dist2, idx = pu._ext.three_nn(pos, known)
+    weight = pu._ext.fp_weights(dist2)
+    torch.manual_seed(0)
+    a0 = torch.randn(2, 70, 1500, device=dev)
+    skip = torch.randn(2, 5, 6000, device=dev)
+    wb0 = torch.randn(70, 5, device=dev)
+    up = torch.randn(2, 70, 6000, device=dev)
+    res = []
+    for fused in (False, True):
+        a, wb = a0.clone().requires_grad_(True), wb0.clone().requires_grad_(True)
+        if fused:
+            y, partial = fp_front(a, idx, weight, skip, wb)
+        else:
+            y = pu.three_interpolate(a, idx, weight) + torch.bmm(wb.unsqueeze(0).expand(2, -1, -1), skip)
+        (y * up).sum().backward()
+        res.append((y.detach(), a.grad, wb.grad))
+    for name, x, f in zip(("y", "dA", "dWb"), *res):
+        assert float((x - f).abs().max()) <= 2e-5 * float(x.abs().max()), name
+    sums = partial.sum((0, 2), dtype=torch.float64)
+    assert torch.allclose(sums[:, 0], res[1][0].double().sum((0, 2)), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(sums[:, 1], res[1][0].double().square().sum((0, 2)), rtol=1e-6)
