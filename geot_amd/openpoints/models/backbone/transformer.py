@@ -387,7 +387,8 @@ class PointTransformer_seg_T(nn.Module):
         f_l1 = self.dgcnn_pro_1(center_pts_trans[1], f_l2, center_pts_trans[0], f_l1)
         f_l0 = self._fp(self.propogation_0, center_original, center_pts[0], f_l0, f_l1)
 
-        logit = self.seg_head(f_l0)
+        head = self.seg_head                     # conv -> BatchNorm1d -> Dropout -> conv; the BatchNorm as one fused op
+        logit = head[3](head[2](bn_act(head[1], head[0](f_l0), relu=False)))
         correction = self.T_linear(T) if T is not None else None
         return logit, correction, self.sigma, f_l0
 
