@@ -209,3 +209,48 @@ def test_fp_front_equals_interpolate_plus_skip_conv():
     sums = partial.sum((0, 2), dtype=torch.float64)
     assert torch.allclose(sums[:, 0], res[1][0].double().sum((0, 2)), rtol=1e-6, atol=1e-3)
     assert torch.allclose(sums[:, 1], res[1][0].double().square().sum((0, 2)), rtol=1e-6)
+
+
+def _sync_bn_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from geot_amd.fused_norm import bn_act
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    x_all = (torch.randn(4, 12, 3000, generator=g) * 1.5 + 0.3)
+    up_all = torch.randn(4, 12, 3000, generator=g)
+    lo, hi = (0, 1) if rank == 0 else (1, 4)                 # uneven shards: the element counts differ per rank
+    res = []
+    for fused in (False, True):
+        torch.manual_seed(1)
+        bn = torch.nn.SyncBatchNorm(12).to(dev)
+        with torch.no_grad():
+            bn.weight.uniform_(-1, 1); bn.bias.uniform_(-1, 1)
+        x = x_all[lo:hi].to(dev).requires_grad_(True)
+        y = bn_act(bn, x, relu=True) if fused else torch.relu(bn(x))
+        (y * up_all[lo:hi].to(dev)).sum().backward()
+        res.append([t.detach().cpu() for t in (y, x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)])
+    ok = all(torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(a.abs().max()) + 1e-6) for a, b in zip(*res))
+    q.put((rank, ok, [float((a - b).abs().max()) for a, b in zip(*res)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bn_act_under_sync_batchnorm_two_ranks():
+    """fused_norm.bn_act with an nn.SyncBatchNorm module, 2 ranks sharing the GPU over gloo, uneven shards: output,
+    gradients and running statistics equal torch's own SyncBatchNorm + ReLU."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sync_bn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in out), out
