@@ -78,14 +78,21 @@ class Attention(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
+        self.fused = os.environ.get("GEOT_ATTN", "manual") == "sdpa"   # measured in the full step: sdpa 46.0 ms, manual 45.3
 
     def forward(self, x):
         B, N, C = x.shape
         qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
-        attn = (q @ k.transpose(-2, -1)) * self.scale
-        attn = self.attn_drop(attn.softmax(dim=-1))
-        x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+        if self.fused and x.is_cuda and (self.attn_drop.p == 0.0 or not self.training):
+            # softmax(q k^T scale) v as one kernel (torch's memory-efficient attention runs fp32 on gfx950): same
+            # function (1e-6 apart); 425 -> 348 us per block fwd + bwd in isolation, but slower inside the step: opt-in
+            x = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+        else:
+            attn = (q @ k.transpose(-2, -1)) * self.scale
+            attn = self.attn_drop(attn.softmax(dim=-1))
+            x = attn @ v
+        x = x.transpose(1, 2).reshape(B, N, C)
         return self.proj_drop(self.proj(x))
 
 
