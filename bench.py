@@ -54,6 +54,11 @@ def parse():
     ap.add_argument("--workload", choices=["model", "sa", "backbone_ops", "ntm", "fixmatch"], default="model")
     ap.add_argument("--dense", choices=["factored", "reference"], default=None,
                     help="model: how the first 1x1 conv behind a gather is evaluated (see transformer.py)")
+    ap.add_argument("--no-tuned-gemm", action="store_true",
+                    help="model / fixmatch: leave the rocBLAS / hipBLASLt solution choice of the dense layers to the "
+                         "library defaults instead of the recorded TunableOp selection (geot_amd/tuning)")
+    ap.add_argument("--tune-gemm", default=None, metavar="CSV",
+                    help="model / fixmatch: let TunableOp time every GEMM solution during warm-up and write CSV (minutes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--streams", type=int, default=1, help="sa only: HIP streams the steps are dealt to")
@@ -253,6 +258,10 @@ def main():
     _lib.load()
 
     workload = args.workload
+    gemm_file = None
+    if workload in ("model", "fixmatch") and not args.no_tuned_gemm:
+        from geot_amd import tuning
+        gemm_file = tuning.enable(tune=args.tune_gemm is not None, path=args.tune_gemm)
     default_b = {"sa": 1, "fixmatch": 2}.get(workload, 8)
     B = args.clouds if args.clouds is not None else default_b
     clouds_per_step = B
@@ -468,6 +477,8 @@ def main():
                            "knn_Mqueries_per_s": B * (512 + 4096 * 2 + 8192 * 2) / (k_ms * 1e-3) / 1e6,
                            "note": "kNN: k=32 512x24000 + k=4 {512->4096, 4096^2, 4096->8192, 8192^2} per cloud per step"}
         result["dense"] = {"mode": dense_mode,
+                           "gemm_selection": ("PyTorch TunableOp, recorded: " + os.path.relpath(gemm_file, ROOT)) if gemm_file
+                           else "library defaults",
                            "reference_gflop_fwd_per_cloud": DENSE_GFLOP_FWD_REFERENCE,
                            "note": "factored: first 1x1 conv behind a gather evaluated before the gather (same function, "
                                    "fewer flops); reference: the reference's op order"}

@@ -1,0 +1,33 @@
+"""GEMM solution selection for the model's dense layers (stock rocBLAS / hipBLASLt kernels behind torch.bmm / Linear).
+
+The hot path of this package is hand-written HIP; the dense layers of ``PointTransformer_seg_T`` are library GEMMs,
+half of the step's kernel time.  PyTorch's TunableOp times every rocBLAS / hipBLASLt solution for a GEMM shape once and
+remembers the fastest; ``tunableop_gfx950.csv`` holds that choice for the shapes of BASELINE configs[2] / [4] (8 and
+6 + 2 clouds of 24 000 points), recorded on MI355X with the ROCm 7.2 image (the file's ``Validator`` rows pin PyTorch,
+HIP, rocBLAS, hipBLASLt and ``gfx950``: on any other stack TunableOp ignores the file and the default solutions run).
+Same fp32 arithmetic, different tiling: 45.0 -> 41.0 ms per configs[2] step.
+
+``enable()`` switches TunableOp on with these results and tuning OFF (no timing runs at start-up; unknown shapes use the
+library default); ``enable(tune=True, path=...)`` records a new file (minutes)."""
+import os
+
+DEFAULT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+
+
+def enable(tune=False, path=None):
+    """-> the results file in use, or None when TunableOp is unavailable."""
+    import torch
+    try:
+        import torch.cuda.tunable as tunable
+    except ImportError:
+        return None
+    path = path or DEFAULT
+    tunable.enable(True)
+    tunable.tuning_enable(bool(tune))
+    tunable.set_filename(path, insert_device_ordinal=False)     # one file for every rank: the shapes are per rank
+    if os.path.exists(path):
+        try:
+            tunable.read_file(path)
+        except Exception:                                       # noqa: BLE001  (validator mismatch: library defaults)
+            return None
+    return path
