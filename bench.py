@@ -83,8 +83,18 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     worst = 0
     try:
-        for p in procs:
-            worst = max(worst, abs(p.wait()))
+        live = list(procs)
+        while live:                              # a rank that dies would leave the others waiting in a collective:
+            for p in list(live):                 # poll, and take the rest down with it
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                worst = max(worst, abs(rc))
+                if rc != 0:
+                    for q in live:
+                        q.terminate()
+            time.sleep(0.2)
     finally:
         for p in procs:
             if p.poll() is None:
