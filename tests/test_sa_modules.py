@@ -130,3 +130,35 @@ def test_sa_and_fp_modules_train_mode_backward():
     msg = PointnetSAModuleMSG(npoint=64, radii=[0.1, 0.3], nsamples=[8, 16], mlps=[[6, 16], [6, 24]]).cuda()
     nx, nf2 = msg(xyz, feats)
     assert nf2.shape == (2, 40, 64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsample,mlp_spec,c_feat,normalize", [(32, [3, 64, 64, 128], 3, False), (24, [5, 32, 48], 5, True)])
+def test_sa_module_factored_training_equals_composed(nsample, mlp_spec, c_feat, normalize):
+    """Training mode (batch-statistics BatchNorm): the factored body (first conv per point, then gathered; fused
+    BatchNorm + ReLU) against the reference composition -- output, input gradient, every parameter gradient and the
+    running statistics."""
+    from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
+    xyz_np, _ = make_batch(2, 3000, start_index=9)
+    xyz = torch.from_numpy(xyz_np).cuda()
+    f0 = torch.randn(2, c_feat, 3000, device="cuda:0")
+    res = []
+    for factored in (False, True):
+        torch.manual_seed(11)
+        sa = PointnetSAModuleVotes(mlp=list(mlp_spec), npoint=500, radius=0.15, nsample=nsample, normalize_xyz=normalize).cuda()
+        sa.factored_train = factored
+        sa.train()
+        feats = f0.clone().requires_grad_(True)
+        _, out, inds = sa(xyz, feats)
+        up = torch.linspace(-1, 1, out.numel(), device="cuda:0").view_as(out)
+        (out * up).sum().backward()
+        res.append((out.detach(), feats.grad, {n: p.grad.clone() for n, p in sa.named_parameters()},
+                    {n: b.clone() for n, b in sa.named_buffers() if "running" in n}))
+    a, b = res
+    assert float((a[0] - b[0]).abs().max()) <= 2e-4 * float(a[0].abs().max())
+    assert float((a[1] - b[1]).abs().max()) <= 1e-3 * float(a[1].abs().max())
+    for n in a[2]:
+        err = float((a[2][n] - b[2][n]).norm() / (a[2][n].norm() + 1e-12))
+        assert err < 2e-3, (n, err)
+    for n in a[3]:
+        assert torch.allclose(a[3][n], b[3][n], rtol=1e-4, atol=1e-6), n
