@@ -71,7 +71,7 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (children of a parent that has NOT touched the
-    GPU), rank r -> GPU r, rendezvous on 127.0.0.1; rank 0 prints the JSON line; exit with the worst code."""
+    GPU), rank r -> GPU r, rendezvous on 127.0.0.1; rank 0 prints the JSON line; exit with the first failing rank's code."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -81,7 +81,7 @@ def spawn_ranks(args):
                    MASTER_PORT=str(port), GEOT_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    worst = 0
+    failed = 0                                   # exit code of the FIRST rank that failed (not of the ranks we stop)
     try:
         live = list(procs)
         while live:                              # a rank that dies would leave the others waiting in a collective:
@@ -90,8 +90,8 @@ def spawn_ranks(args):
                 if rc is None:
                     continue
                 live.remove(p)
-                worst = max(worst, abs(rc))
-                if rc != 0:
+                if rc != 0 and not failed:
+                    failed = abs(rc)
                     for q in live:
                         q.terminate()
             time.sleep(0.2)
@@ -99,7 +99,7 @@ def spawn_ranks(args):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    return worst
+    return failed
 
 
 class EventTimer:

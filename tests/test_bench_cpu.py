@@ -1,0 +1,98 @@
+"""CPU tests of the measurement plumbing: the N-rank self-launcher of bench.py (no GPU needed: the children are a
+stub), the steady-state window tool, the PMC-traffic lookup and the GEMM-selection switch."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("geot_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_imports_and_parses_without_a_gpu():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--workload" in r.stdout
+
+
+def test_spawn_ranks_sets_the_rendezvous_and_reports_the_worst_exit(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` without a launcher: N children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    started by a parent that has not touched the GPU; a failing rank takes the others down and its code is returned."""
+    bench = _load_bench()
+    stub = tmp_path / "stub.py"
+    stub.write_text(textwrap.dedent("""
+        import json, os, sys, time
+        rank = int(os.environ["RANK"])
+        rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+        open(os.path.join(os.path.dirname(__file__), "rank%d.json" % rank), "w").write(json.dumps(rec))
+        if "--fail" in sys.argv and rank == 1:
+            sys.exit(7)
+        if "--fail" in sys.argv:
+            time.sleep(60)          # would hang in a collective: the launcher must terminate it
+    """))
+    monkeypatch.setattr(bench, "__file__", str(stub))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3"])
+
+    class A:
+        gpus = 3
+    assert bench.spawn_ranks(A) == 0
+    recs = [json.loads((tmp_path / ("rank%d.json" % r)).read_text()) for r in range(3)]
+    assert [r["RANK"] for r in recs] == ["0", "1", "2"] and [r["LOCAL_RANK"] for r in recs] == ["0", "1", "2"]
+    assert all(r["WORLD_SIZE"] == "3" and r["MASTER_ADDR"] == "127.0.0.1" for r in recs)
+    assert len({r["MASTER_PORT"] for r in recs}) == 1 and recs[0]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3", "--fail"])
+    import time
+    t0 = time.time()
+    assert bench.spawn_ranks(A) == 7          # the failing rank's code, not the SIGTERM of the ranks it took down
+    assert time.time() - t0 < 30
+
+
+def test_trace_window_summarises_only_the_steady_state(tmp_path):
+    rows = ["Kind,Agent_Id,Queue_Id,Stream_Id,Thread_Id,Dispatch_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,End_Timestamp"]
+    t = 0
+    for step in range(6):                                     # warm-up steps carry a slow tuning kernel
+        rows.append("K,0,0,0,0,0,0,void geot::fps_pruned_kernel<768>,0,%d,%d" % (t, t + 4_000_000))
+        if step < 2:
+            rows.append("K,0,0,0,0,0,0,tuning_kernel,0,%d,%d" % (t + 5_000_000, t + 50_000_000))
+        rows.append("K,0,0,0,0,0,0,gemm,0,%d,%d" % (t + 60_000_000, t + 62_000_000))
+        t += 100_000_000
+    trace = tmp_path / "kt.csv"
+    trace.write_text("\n".join(rows) + "\n")
+    out = tmp_path / "w.csv"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "trace_window.py"), str(trace), "--skip", "2", "--steps", "3",
+                        "-o", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    text = out.read_text()
+    assert "tuning_kernel" not in text and "fps_pruned_kernel" in text and "gemm" in text
+    assert "wall 100.000 ms/step" in text and "summed kernel time 6.000 ms/step" in text
+
+
+def test_pmc_traffic_lookup_reports_its_source(tmp_path, monkeypatch):
+    bench = _load_bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for v, traffic in ((1, 111), (2, 222)):
+        (prof / ("r02_bench_model_v%d_pmc_traffic.json" % v)).write_text(json.dumps(
+            {"commit": "abc%d" % v, "kernels": {"geot::fps_pruned_kernel<768, 32, false, 8>": {"traffic_bytes": traffic}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    t, src = bench.pmc_traffic("fps_pruned_kernel<768, 32, false", "bench_model")
+    assert t == 222 and src == {"file": os.path.join("profiles", "r02_bench_model_v2_pmc_traffic.json"), "commit": "abc2"}
+    assert bench.pmc_traffic("no_such_kernel", "bench_model") == (None, None)
+
+
+def test_recorded_gemm_selection_is_a_wellformed_tunableop_file():
+    from geot_amd import tuning
+    lines = open(tuning.DEFAULT).read().strip().splitlines()
+    validators = [l for l in lines if l.startswith("Validator,")]
+    assert any("GCN_ARCH_NAME,gfx950" in l for l in validators) and any("ROCBLAS_VERSION" in l for l in validators)
+    entries = [l.split(",") for l in lines if l.startswith("GemmTunableOp") or "TunableOp_float" in l.split(",")[0]]
+    assert len(entries) > 50 and all(len(e) >= 3 for e in entries)
+    assert all("float" in e[0] for e in entries)              # fp32 GEMMs only: the selection never changes precision
