@@ -234,7 +234,7 @@ class DGCNN_Propagation(nn.Module):
             idx = _knn_idx(coor_q, coor_k, self.k)
             p = pointwise(w_d, x_k)                                      # (B, Cout, Nk)
             q = pointwise(w_q - w_d, x_q)                                # (B, Cout, Nq)
-            if (self.fused_tail and p.is_cuda and isinstance(norm, nn.GroupNorm) and isinstance(act, nn.LeakyReLU)
+            if (self.fused_tail and p.is_cuda and isinstance(norm, nn.GroupNorm) and norm.affine and isinstance(act, nn.LeakyReLU)
                     and edgeconv_tail_eligible(p.shape[0], p.shape[1], q.shape[2], p.shape[2], self.k, norm.num_groups)):
                 return edgeconv_tail(p, q, idx, norm, act.negative_slope)   # gather + GN + LeakyReLU + max, fused
             y = pt_utils.grouping_operation(p.contiguous(), idx) + q.unsqueeze(-1)

@@ -22,12 +22,23 @@ def enable(tune=False, path=None):
     except ImportError:
         return None
     path = path or DEFAULT
+    work = path
+    if not tune:
+        # TunableOp owns the file it is pointed at (it may rewrite it): every process works on a private copy, so N
+        # ranks never write one file and the recorded selection in the tree stays byte-identical
+        import shutil
+        import tempfile
+        work = os.path.join(tempfile.gettempdir(), "geot_tunableop_%d.csv" % os.getpid())
+        try:
+            shutil.copyfile(path, work)
+        except OSError:
+            return None
     tunable.enable(True)
     tunable.tuning_enable(bool(tune))
-    tunable.set_filename(path, insert_device_ordinal=False)     # one file for every rank: the shapes are per rank
-    if os.path.exists(path):
+    tunable.set_filename(work, insert_device_ordinal=False)     # one selection for every rank: the shapes are per rank
+    if os.path.exists(work):
         try:
-            tunable.read_file(path)
+            tunable.read_file(work)
         except Exception:                                       # noqa: BLE001  (validator mismatch: library defaults)
             return None
     return path
