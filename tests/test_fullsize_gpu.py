@@ -197,3 +197,35 @@ def test_grid_soak_grid_search_equals_brute_force_on_adversarial_clouds():
                 assert torch.equal(a, p2.ball_query(q, ref, r, ns)), (trial, r, ns)
     finally:
         os.environ.pop("GEOT_NN_IMPL", None)
+
+
+def test_gather_gradients_of_the_model_are_bit_reproducible():
+    """The gradients the configured backbone takes through the hot path -- three_interpolate at prop0's shape (source
+    rows cut into parts: the reverse-index gather loops them inside the workgroup, one writer per output) and the
+    EdgeConv tail -- are identical from run to run (no float atomics on these paths)."""
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    from geot_amd.openpoints.models.backbone.transformer_ops import edgeconv_tail
+    xyz = make_batch(2, 24000, start_index=3)[0]
+    pos = torch.from_numpy(xyz).to(DEV)
+    known = pos[:, :8192].contiguous()
+    dist, idx = pu.three_nn(pos, known)
+    w = 1.0 / (dist + 1e-8)
+    w = w / w.sum(2, keepdim=True)
+    up = torch.randn(2, 24, 24000, device=DEV)
+    grads = []
+    for _ in range(3):
+        f = torch.randn(2, 24, 8192, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1), requires_grad=True)
+        (pu.three_interpolate(f, idx, w) * up).sum().backward()
+        grads.append(f.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    norm = torch.nn.GroupNorm(4, 64).to(DEV)
+    nbr = torch.randint(0, 4096, (2, 8192, 4), device=DEV, dtype=torch.int32)
+    outs = []
+    for _ in range(2):
+        g = torch.Generator(device=DEV).manual_seed(2)
+        p = torch.randn(2, 64, 4096, device=DEV, generator=g, requires_grad=True)
+        q = torch.randn(2, 64, 8192, device=DEV, generator=g, requires_grad=True)
+        edgeconv_tail(p, q, nbr, norm, 0.2).square().sum().backward()
+        outs.append((p.grad.clone(), q.grad.clone(), norm.weight.grad.clone()))
+        norm.zero_grad()
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
