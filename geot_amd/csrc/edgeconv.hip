@@ -300,6 +300,19 @@ __global__ __launch_bounds__(256) void edge_rix_fill_kernel(long long total, lon
     const int bi = (int)(x / per_batch);
     rev[off[(size_t)bi * nk + idx[x]] + rank[x]] = (int)(x - (long long)bi * per_batch); // pair id i*k + j within the batch
 }
+// reproducible order: the pair ids of a target ascending (geot_common.h rix_sorted_position); tmp = the first fill
+__global__ __launch_bounds__(256) void edge_rix_place_kernel(long long total, long long per_batch, int nk,
+                                                             const int *__restrict__ idx, const int *__restrict__ off,
+                                                             const int *__restrict__ rank, const int *__restrict__ tmp,
+                                                             int *__restrict__ rev)
+{
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= total) return;
+    const int bi = (int)(x / per_batch);
+    const size_t tgt = (size_t)bi * nk + idx[x];
+    const int a = off[tgt], z = off[tgt + 1], mine = (int)(x - (long long)bi * per_batch);
+    rev[a + rix_sorted_position(tmp, a, z, mine, rank[x])] = mine;
+}
 
 // ---- backward 4: d/dP[b,c,n] = sum over the pairs (i,j) with idx[b,i,j] == n of dy_ij ---------------------------
 //   = rstd ( sum_pairs ( a_i [j == jsel_i] + u_i ) - cnt_n (s1 + s2 rstd (P_n - mean)) ),
@@ -417,7 +430,7 @@ GEOT_EXPORT long long geot_edgeconv_ws_bytes(int b, int c, int nq, int nk, int k
 {
     const long long part = (long long)b * c * 32 * 2 * (long long)sizeof(float);
     const long long t = (long long)b * nk, pairs = (long long)b * nq * k;
-    const long long rix = ((t + 1) + scan_blocks(t) + 2 * pairs + 8) * (long long)sizeof(int);
+    const long long rix = ((t + 1) + scan_blocks(t) + 3 * pairs + 8) * (long long)sizeof(int);   // counts, scan, rank, rev, pair ids
     return part + rix + 256;
 }
 
@@ -480,7 +493,13 @@ GEOT_EXPORT int geot_edgeconv_gn_max_grad(int b, int c, int nq, int nk, int k, i
     const int pb = (int)((pairs + 255) / 256);
     hipLaunchKernelGGL(edge_rix_count_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank);
     exclusive_scan_i32((int)t, off, bsum, nullptr, s);
-    hipLaunchKernelGGL(edge_rix_fill_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank, rev);
+    if (rix_reproducible()) {   // fill pair ids in arrival order, then place them in ascending order: fixed summation order
+        int *tmp = rev + pairs;
+        hipLaunchKernelGGL(edge_rix_fill_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank, tmp);
+        hipLaunchKernelGGL(edge_rix_place_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank, tmp, rev);
+    } else {
+        hipLaunchKernelGGL(edge_rix_fill_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank, rev);
+    }
 
     hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3(slices, c, b), dim3(256), 0, s, c, nq, groups, slope, ysel, gamma, beta,
                        stats, grad_out, bpart);

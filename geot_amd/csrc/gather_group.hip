@@ -534,14 +534,33 @@ __global__ __launch_bounds__(256) void rix_fill_kernel(long long total, long lon
                                                        int partlen, const int *__restrict__ idx,
                                                        const float *__restrict__ weight, const int *__restrict__ off,
                                                        const int *__restrict__ rank, int *__restrict__ rev,
-                                                       float *__restrict__ revw)
+                                                       float *__restrict__ revw, int *__restrict__ tmp)
 {
     const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
     if (x >= total) return;
     const int bi = (int)(x / per_batch);
     const int e = (int)((x - (long long)bi * per_batch) / nt), part = e / partlen;
     const int pos = off[((size_t)bi * Q + part) * m + idx[x]] + rank[x];
+    if (tmp) { tmp[pos] = (int)x; return; } // reproducible build: pair ids first, placed by rix_place_kernel
     rev[pos] = e - part * partlen; // source element within its part
+    if (WEIGHTED) revw[pos] = weight[x];
+}
+// second phase of the reproducible build: pair x goes to its position in ascending pair-id order within its list
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void rix_place_kernel(long long total, long long per_batch, int m, int nt, int Q,
+                                                        int partlen, const int *__restrict__ idx,
+                                                        const float *__restrict__ weight, const int *__restrict__ off,
+                                                        const int *__restrict__ rank, const int *__restrict__ tmp,
+                                                        int *__restrict__ rev, float *__restrict__ revw)
+{
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= total) return;
+    const int bi = (int)(x / per_batch);
+    const int e = (int)((x - (long long)bi * per_batch) / nt), part = e / partlen;
+    const size_t tgt = ((size_t)bi * Q + part) * m + idx[x];
+    const int a = off[tgt], z = off[tgt + 1];
+    const int pos = a + rix_sorted_position(tmp, a, z, (int)x, rank[x]);
+    rev[pos] = e - part * partlen;
     if (WEIGHTED) revw[pos] = weight[x];
 }
 
@@ -717,7 +736,7 @@ static RixPlan rix_plan(int c, long long L)
 static inline long long rix_ws_ints(int b, int c, int m, long long L, int nt)
 {
     const long long t = (long long)b * rix_plan(c, L).Q * m, pairs = (long long)b * L * nt;
-    return (t + 1) + scan_blocks(t) + 3 * pairs + 8;
+    return (t + 1) + scan_blocks(t) + 4 * pairs + 8;   // counts, scan scratch, rank, rev, revw, pair ids
 }
 
 static bool csr_applies(int b, int c, int m, long long L, int nt, long long ws_floats)
@@ -749,8 +768,12 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     hipLaunchKernelGGL(rix_count_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, Q, rp.partlen, idx,
                        off, rank);
     exclusive_scan_i32((int)t, off, bsum, nullptr, s);
+    int *tmp = rix_reproducible() ? (int *)(revw + pairs) : nullptr;
     hipLaunchKernelGGL((rix_fill_kernel<WEIGHTED>), dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, Q,
-                       rp.partlen, idx, weight, off, rank, rev, revw);
+                       rp.partlen, idx, weight, off, rank, rev, revw, tmp);
+    if (tmp)   // fixed list order = fixed summation order: reproducible gradients
+        hipLaunchKernelGGL((rix_place_kernel<WEIGHTED>), dim3(pb), dim3(256), 0, s, pairs, (long long)L * NT, m, NT, Q,
+                           rp.partlen, idx, weight, off, rank, tmp, rev, revw);
     const size_t lds = (size_t)ch * rp.partlen * sizeof(float);
     const int chunks = (c + ch - 1) / ch;
     const char *impl = getenv("GEOT_GATHER_IMPL");           // "atomic": the per-part kernel + float atomics (A/B runs)

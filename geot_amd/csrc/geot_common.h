@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -251,6 +252,24 @@ static inline hipError_t zero_words(void *dst, long long words, hipStream_t s)
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, s, words, (uint32_t *)dst);
     return hipGetLastError();
+}
+// (2b) The reverse indices (CSR by target) are first filled through atomically handed-out ranks, so the order of a
+// target's entries differs from run to run -- and with it the fp32 summation order of every gather over them.  The
+// entry-parallel helper below gives every pair its position in the ascending-pair-id order of its list (a count over
+// the list, L2-resident), so the final lists -- and the gathers -- are bit-reproducible.  Lists longer than
+// RIX_SORT_MAX (degenerate hubs) keep the arbitrary order: still correct, only not reproducible.
+constexpr int RIX_SORT_MAX = 4096;
+__device__ __forceinline__ int rix_sorted_position(const int *__restrict__ tmp, int a, int z, int mine, int fallback)
+{
+    if (z - a > RIX_SORT_MAX) return fallback;
+    int r = 0;
+    for (int q = a; q < z; ++q) r += tmp[q] < mine ? 1 : 0;
+    return r;
+}
+static inline bool rix_reproducible()
+{
+    const char *e = getenv("GEOT_REPRODUCIBLE");      // "0": keep the arbitrary (atomic) list order (A/B runs)
+    return !(e && e[0] == '0');
 }
 // (3) CU count of the current device, looked up once per device
 static inline int device_cus()
