@@ -163,3 +163,32 @@ def fp_front(a, idx, weight, skip, wb):
     or None, wb (C,Cs) -> (y (B,C,n), partial): the first conv of a PointnetFPModule's SharedMLP, ready for bn_act."""
     return _FpFrontFn.apply(a.contiguous(), idx.contiguous(), weight.contiguous(),
                             None if skip is None else skip.contiguous().float(), wb)
+
+
+class _SegmentMaxFn(Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        rows = x.numel() // n
+        out = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+        arg = torch.empty(x.shape[:-1], dtype=torch.uint8, device=x.device)
+        call("geot_segment_max", x.device, rows, n, ptr(x), ptr(out), ptr(arg))
+        ctx.save_for_backward(arg)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        arg, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty(tuple(arg.shape) + (ctx.n,), dtype=torch.float32, device=dy.device)
+        call("geot_segment_max_grad", dy.device, arg.numel(), ctx.n, ptr(dy), ptr(arg), ptr(dx))
+        return dx, None
+
+
+def max_last(x):
+    """x.max(dim=-1)[0] for a contiguous float32 GPU tensor whose last dimension is a multiple of 4 and <= 256 (the
+    group / nsample axis): one streaming kernel each way instead of torch's generic reduction + index scatter."""
+    n = x.shape[-1]
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and 4 <= n <= 256 and n % 4 == 0 and x.numel() > 0):
+        return x.max(dim=-1)[0]
+    return _SegmentMaxFn.apply(x, n)

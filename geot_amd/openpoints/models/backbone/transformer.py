@@ -36,7 +36,7 @@ from ....knn_cuda import KNN, knn_sorted
 from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused,  # noqa: F401
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
-from ....fused_norm import bn_act, fp_front, fp_front_eligible
+from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last
 
 
 class DropPath(nn.Module):
@@ -178,12 +178,12 @@ class Encoder(nn.Module):
         x = point_groups.reshape(L, 3).t()                                              # (3, L) view
         f = conv(self.first_conv[3], norm_act(self.first_conv, conv(self.first_conv[0], x)))      # (256, L)
         c1 = f.shape[0]
-        pooled = f.view(c1, bs * g, n).max(dim=2)[0]                                    # (256, BG)
+        pooled = max_last(f.view(c1, bs * g, n))                                        # (256, BG)
         c2 = self.second_conv[0]
         w = c2.weight.squeeze(-1)
         h = conv(c2, f, w[:, c1:]).view(-1, bs * g, n) + torch.mm(w[:, :c1], pooled).unsqueeze(2)
         h = conv(self.second_conv[3], norm_act(self.second_conv, h.view(-1, L)))                  # (C_enc, L)
-        return h.view(-1, bs * g, n).max(dim=2)[0].t().reshape(bs, g, self.encoder_channel)
+        return max_last(h.view(-1, bs * g, n)).t().reshape(bs, g, self.encoder_channel)
 
     def forward(self, point_groups):
         if self.factored:

@@ -152,6 +152,11 @@ int geot_bn_bwd_reduce(int b, int c, int l, int relu, const float *x, const floa
 int geot_bn_bwd_apply(int b, int c, int l, int relu, const float *x, const float *dz, const float *scale,
                       const float *shift, const float *mean, const float *rstd, const float *k0, const float *c1,
                       const float *c2, float *dx, void *stream);
+/* max over the n innermost elements of every row, x (rows, n) contiguous and 16-byte aligned, n a multiple of 4, <= 256:
+ * out (rows), arg (rows) uint8 = the first maximum's slot (torch.max semantics); _grad writes dx (rows, n) in full.
+ * (Encoder's max over a group's points, transformer.py:127-134; max over nsample of the SA modules.) */
+int geot_segment_max(long long rows, int n, const float *x, float *out, unsigned char *arg, void *stream);
+int geot_segment_max_grad(long long rows, int n, const float *dy, const unsigned char *arg, float *dx, void *stream);
 int geot_fp_front_slices(int b, int c, int m, int n);
 int geot_fp_front(int b, int c, int m, int n, int cs, const float *A, const int *idx, const float *weight,
                   const float *skip, const float *Wb, float *y, float *partial, void *stream);

@@ -279,3 +279,21 @@ def test_full_config_factored_tracks_reference_order_over_training_steps():
     for a, b in zip(losses["reference"], losses["factored"]):
         assert abs(a - b) <= 2e-3 * abs(a), losses
     assert losses["factored"][-1] < losses["factored"][0]
+
+
+@pytest.mark.parametrize("shape", [(256, 4096, 32), (3, 5, 7, 16), (10, 64), (1000, 8), (33, 4), (2, 128, 500, 24)])
+def test_max_last_equals_torch_max(shape):
+    from geot_amd.fused_norm import max_last
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(sum(shape))
+    x0 = torch.randn(*shape, generator=g)
+    x0[..., 1] = x0[..., 0]                       # exact ties: the first maximum must win, as in torch
+    x0 = x0.to(dev)
+    up = torch.randn(*shape[:-1], generator=g).to(dev)
+    res = []
+    for fused in (False, True):
+        x = x0.clone().requires_grad_(True)
+        y = max_last(x) if fused else x.max(dim=-1)[0]
+        (y * up).sum().backward()
+        res.append((y.detach(), x.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
