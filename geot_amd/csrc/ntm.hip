@@ -151,39 +151,52 @@ struct SigMfma {
     static constexpr int NCT = (CC + 31) / 32;     // 10 column tiles
     static constexpr int CP = NCT * 32;            // 320
     static constexpr int AT_STRIDE = KP + 1;       // 19 (odd)
-    static constexpr int LDS_FLOATS = KP * CP + SM_PTS * CC + SM_PTS * AT_STRIDE + 64;
+    // the tile (+ the A^T copy and the slack its padded-column reads run into, backward only); the weights live in
+    // registers, so four forward blocks (37 KB each) share a CU's 160 KB
+    static constexpr int LDS_FLOATS_FWD = SM_PTS * CC;
+    static constexpr int LDS_FLOATS_BWD = 2 * SM_PTS * CC + SM_PTS * AT_STRIDE + 64; // + the tile of incoming gradients
     static_assert(KP % 2 == 0, "K must be even for the 32x32x2 MFMA");
 };
 
 template <int C, bool BACKWARD>
-__global__ __launch_bounds__(256) void sig_t_mean_mfma_kernel(
+__global__ __launch_bounds__(256, BACKWARD ? 2 : 4) void sig_t_mean_mfma_kernel(
     int total_pts, int n, const float *__restrict__ p, const float *__restrict__ W,
     const float *__restrict__ cm, const float *__restrict__ grad_out, float *__restrict__ out,
     float *__restrict__ partial)
 {
     using S = SigMfma<C>;
-    constexpr int CC = S::CC, KP = S::KP, CP = S::CP, NCT = S::NCT, ATS = S::AT_STRIDE;
+    constexpr int CC = S::CC, KP = S::KP, NCT = S::NCT, ATS = S::AT_STRIDE;
     constexpr int MYCT = (NCT + 3) / 4; // column tiles per wave (3, 3, 2, 2)
     extern __shared__ float ntm_lds[];
-    float *Wt = ntm_lds;              // [KP][CP]
-    float *tile = Wt + KP * CP;       // [SM_PTS][CC]  (contiguous = the global layout of the block)
-    float *At = tile + SM_PTS * CC;   // [SM_PTS][ATS] (+ slack: the padded columns of the last row read past `tile`)
+    float *tile = ntm_lds;            // [SM_PTS][CC]  (contiguous = the global layout of the block)
+    float *At = tile + SM_PTS * CC;   // [SM_PTS][ATS] (+ slack: the padded columns of the last row read past `tile`); BACKWARD only
+    float *gtile = At + SM_PTS * ATS + 64; // [SM_PTS][CC] incoming gradients of the tile, copied as 16-byte vectors; BACKWARD only
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int e = tid; e < KP * CP; e += 256) {
-        const int k = e / CP, col = e - k * CP;
-        float v = 0.f;
-        if (col < CC) {
-            if (k < C) v = W[(size_t)col * 2 * C + k];
-            else {
-                const int kk = col / C;
-                for (int j = 0; j < C; ++j) v += cm[kk * C + j] * W[(size_t)col * 2 * C + C + j];
+    // B fragments of this wave's column tiles, once per block: lane (r, h) holds Wt[2*ks + h][ct*32 + r]
+    float bw[KP / 2][MYCT];
+#pragma unroll
+    for (int t = 0; t < MYCT; ++t) {
+        const int col = (wave + 4 * t) * 32 + r;
+        const bool live = wave + 4 * t < NCT && col < CC;
+#pragma unroll
+        for (int ks = 0; ks < KP / 2; ++ks) {
+            const int k = 2 * ks + h;
+            float v = 0.f;
+            if (live) {
+                if (k < C) v = W[(size_t)col * 2 * C + k];
+                else {
+                    const int kk = col / C;
+                    for (int j = 0; j < C; ++j) v += cm[kk * C + j] * W[(size_t)col * 2 * C + C + j];
+                }
             }
+            bw[ks][t] = v;
         }
-        Wt[e] = v;
     }
-    for (int e = tid; e < SM_PTS * ATS + 64; e += 256) At[e] = 0.f;
+    if (BACKWARD) {
+        for (int e = tid; e < SM_PTS * ATS + 64; e += 256) At[e] = 0.f;
+    }
     ntm_f32x16 gacc[MYCT];
 #pragma unroll
     for (int t = 0; t < MYCT; ++t)
@@ -193,6 +206,14 @@ __global__ __launch_bounds__(256) void sig_t_mean_mfma_kernel(
 
     for (int i0 = blockIdx.x * SM_PTS; i0 < total_pts; i0 += gridDim.x * SM_PTS) {
         const int cnt = min(SM_PTS, total_pts - i0);
+        if (BACKWARD) {
+            // (17 scalar loads per (point, row) thread straight from global touched 32 cache lines per instruction)
+            const float *src = grad_out + (size_t)i0 * CC; // 16-byte aligned: i0 is a multiple of 32
+            const int total = cnt * CC, vec = total >> 2;
+            for (int e = tid; e < vec; e += 256)
+                reinterpret_cast<float4 *>(gtile)[e] = reinterpret_cast<const float4 *>(src)[e];
+            for (int e = (vec << 2) + tid; e < total; e += 256) gtile[e] = src[e];
+        }
         // A fragment: lane (r = point, h) holds A[r][2*ks + h]
         float a[KP / 2];
         {
@@ -217,10 +238,7 @@ __global__ __launch_bounds__(256) void sig_t_mean_mfma_kernel(
 #pragma unroll
             for (int t = 0; t < MYCT; ++t) {
                 const int ct = wave + 4 * t;
-                if (ct < NCT) {
-                    const float bv = Wt[(2 * ks + h) * CP + ct * 32 + r];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], bv, acc[t], 0, 0, 0);
-                }
+                if (ct < NCT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], bw[ks][t], acc[t], 0, 0, 0);
             }
         }
         // D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
@@ -245,20 +263,23 @@ __global__ __launch_bounds__(256) void sig_t_mean_mfma_kernel(
             }
             const float den = fmaxf(s, 1e-12f);
             if (!BACKWARD) {
+                // one division per row: 17 IEEE divisions were as many VALU cycles as the tile's HBM time (1 ulp apart)
+                const float rden = 1.f / den;
 #pragma unroll
-                for (int o = 0; o < C; ++o) row[o] = fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) / den;
+                for (int o = 0; o < C; ++o) row[o] = fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) * rden;
             } else if (pt < cnt) {
-                const float *g = grad_out + ((size_t)(i0 + pt) * C + kk) * C;
+                const float *g = gtile + pt * CC + kk * C;
+                const float rden = 1.f / den;
                 float gv[C], dot = 0.f;
 #pragma unroll
                 for (int o = 0; o < C; ++o) {
                     gv[o] = g[o];
-                    dot += gv[o] * (fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) / den);
+                    dot += gv[o] * (fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) * rden);
                 }
 #pragma unroll
                 for (int o = 0; o < C; ++o) {
                     const bool inside = raw[o] >= 1e-5f && raw[o] <= 1.f - 1e-5f;
-                    row[o] = inside ? (gv[o] - dot) / den : 0.f;
+                    row[o] = inside ? (gv[o] - dot) * rden : 0.f;
                 }
             } else {
 #pragma unroll
@@ -330,24 +351,22 @@ __global__ __launch_bounds__(256) void sig_t_mean_wgrad_reduce_kernel(int nblk, 
 
 // ---- logit correction ----------------------------------------------------------------------
 // v = lam*E + (1-lam)*T_i; tn = v / max(sum_c |v|, eps); out[c] = sum_r logit[r] * tn[r][c].
-template <int C, bool BACKWARD>
-__global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
+// Backward: thread = (point, row group); rows grp, grp + 8, grp + 16 of the point's T_i (LDS tile, overwritten in
+// place by d T_i and streamed back out), one reciprocal per row.
+template <int C>
+__global__ __launch_bounds__(NTM_THREADS, 4) void ntm_correct_bwd_kernel(
     int total_pts, int n, float lam, const float *__restrict__ logits, const float *__restrict__ insT,
-    const float *__restrict__ E, const float *__restrict__ grad_out, float *__restrict__ out,
-    float *__restrict__ grad_logits, float *__restrict__ grad_insT, float *__restrict__ grad_E,
-    float *__restrict__ grad_E_partial)
+    const float *__restrict__ E, const float *__restrict__ grad_out, float *__restrict__ grad_logits,
+    float *__restrict__ grad_insT, float *__restrict__ grad_E, float *__restrict__ grad_E_partial)
 {
     constexpr int CC = C * C, STRIDE = NtmLds<C>::STRIDE;
     extern __shared__ float ntm_lds[];
     float *El = ntm_lds;                         // [CC]
-    float *accE = El + CC;                       // [CC] block partial of grad_E (backward)
-    float *part = accE + CC;                     // [NTM_GROUPS][NTM_TILE][C] partial outputs per row group
-    float *tile = ntm_lds + ((2 * CC + NTM_GROUPS * NTM_TILE * C + 3) & ~3); // [NTM_TILE][STRIDE], 16-byte aligned
-    for (int e = threadIdx.x; e < CC; e += NTM_THREADS) { El[e] = E[e]; accE[e] = 0.f; }
-    __syncthreads();
+    float *tile = ntm_lds + ((CC + 3) & ~3);     // [NTM_TILE][STRIDE], 16-byte aligned
+    for (int e = threadIdx.x; e < CC; e += NTM_THREADS) El[e] = E[e];
     const int pt = threadIdx.x & (NTM_TILE - 1), grp = threadIdx.x >> NTM_TILE_SHIFT;
-    // backward: this thread's share of grad_E (rows grp, grp + 8, grp + 16) stays in registers over all its
-    // tiles; 289 x points LDS atomics on 289 addresses were the whole cost of the first version
+    // this thread's share of grad_E (rows grp, grp + 8, grp + 16) stays in registers over all its tiles; 289 x points
+    // LDS atomics on 289 addresses were the whole cost of the first version
     constexpr int ROWS_PT = (C + NTM_GROUPS - 1) / NTM_GROUPS;
     float eacc[ROWS_PT][C];
 #pragma unroll
@@ -358,16 +377,11 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
         const int cnt = min(NTM_TILE, total_pts - i0);
         ntm_tile_copy<C, true>(const_cast<float *>(insT) + (size_t)i0 * CC, tile, cnt);
         __syncthreads();
-        const int i = i0 + pt, b = pt < cnt ? i / n : 0, ni = pt < cnt ? i - b * n : 0;
-        float acc[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[c] = 0.f;
         if (pt < cnt) {
+            const int i = i0 + pt, b = i / n, ni = i - b * n;
             float go[C];
-            if (BACKWARD) {
 #pragma unroll
-                for (int c = 0; c < C; ++c) go[c] = grad_out[((size_t)b * C + c) * n + ni];
-            }
+            for (int c = 0; c < C; ++c) go[c] = grad_out[((size_t)b * C + c) * n + ni];
 #pragma unroll
             for (int q = 0; q < ROWS_PT; ++q) {
                 const int r = grp + q * NTM_GROUPS;
@@ -380,63 +394,109 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_kernel(
                     v[c] = lam * El[r * C + c] + (1.f - lam) * row[c];
                     s += fabsf(v[c]);
                 }
-                const float den = fmaxf(s, 1e-12f);
-                if (!BACKWARD) {
+                const float rden = 1.f / fmaxf(s, 1e-12f);
+                float gl = 0.f;
 #pragma unroll
-                    for (int c = 0; c < C; ++c) acc[c] = fmaf(l, v[c] / den, acc[c]);
-                } else {
-                    float gl = 0.f;
+                for (int c = 0; c < C; ++c) gl += (v[c] * rden) * go[c];
+                grad_logits[((size_t)b * C + r) * n + ni] = gl;
+                const float dot = l * gl; // sum_c dtn*tn with dtn = l*go
 #pragma unroll
-                    for (int c = 0; c < C; ++c) gl += (v[c] / den) * go[c];
-                    grad_logits[((size_t)b * C + r) * n + ni] = gl;
-                    const float dot = l * gl; // sum_c dtn*tn with dtn = l*go
-#pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        float sg = v[c] > 0.f ? 1.f : (v[c] < 0.f ? -1.f : 0.f);
-                        float dv = s > 1e-12f ? (l * go[c] - sg * dot) / den : l * go[c] / den;
-                        row[c] = (1.f - lam) * dv;
-                        eacc[q][c] = fmaf(lam, dv, eacc[q][c]);
-                    }
+                for (int c = 0; c < C; ++c) {
+                    float sg = v[c] > 0.f ? 1.f : (v[c] < 0.f ? -1.f : 0.f);
+                    float dv = s > 1e-12f ? (l * go[c] - sg * dot) * rden : l * go[c] * rden;
+                    row[c] = (1.f - lam) * dv;
+                    eacc[q][c] = fmaf(lam, dv, eacc[q][c]);
                 }
             }
         }
-        if (!BACKWARD) {
-#pragma unroll
-            for (int c = 0; c < C; ++c) part[(grp * NTM_TILE + pt) * C + c] = acc[c];
-        }
         __syncthreads();
-        if (!BACKWARD) {
-            for (int e = threadIdx.x; e < cnt * C; e += NTM_THREADS) {
-                int c = e / cnt, q = e - c * cnt; // q fastest: coalesced along the point dimension
-                float v = 0.f;
-#pragma unroll
-                for (int gq = 0; gq < NTM_GROUPS; ++gq) v += part[(gq * NTM_TILE + q) * C + c];
-                int gi = i0 + q, gb = gi / n, gn = gi - gb * n;
-                out[((size_t)gb * C + c) * n + gn] = v;
-            }
-        } else {
-            ntm_tile_copy<C, false>(grad_insT + (size_t)i0 * CC, tile, cnt);
-        }
+        ntm_tile_copy<C, false>(grad_insT + (size_t)i0 * CC, tile, cnt);
         __syncthreads();
     }
-    if (BACKWARD) {
-        // sum over the 32 points of the half-wave (one row group per half-wave), then one atomic per entry
+    // sum over the 32 points of the half-wave (one row group per half-wave), then one atomic per entry
 #pragma unroll
-        for (int q = 0; q < ROWS_PT; ++q) {
-            const int r = grp + q * NTM_GROUPS;
+    for (int q = 0; q < ROWS_PT; ++q) {
+        const int r = grp + q * NTM_GROUPS;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                float v = eacc[q][c];
+        for (int c = 0; c < C; ++c) {
+            float v = eacc[q][c];
 #pragma unroll
-                for (int o = NTM_TILE / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-                if (pt == 0 && r < C) {
-                    // per-block partials when the caller gave a workspace: 289 addresses shared by a thousand
-                    // blocks serialise in one or two L2 channels otherwise
-                    if (grad_E_partial) grad_E_partial[(size_t)blockIdx.x * CC + r * C + c] = v;
-                    else atomicAdd(grad_E + r * C + c, v);
-                }
+            for (int o = NTM_TILE / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+            if (pt == 0 && r < C) {
+                // per-block partials when the caller gave a workspace: 289 addresses shared by a thousand
+                // blocks serialise in one or two L2 channels otherwise
+                if (grad_E_partial) grad_E_partial[(size_t)blockIdx.x * CC + r * C + c] = v;
+                else atomicAdd(grad_E + r * C + c, v);
             }
         }
+    }
+}
+
+// Forward-only variant: 8 adjacent lanes per point (row group = lane & 7), the 8 partial outputs of a point are
+// summed with DPP inside the wave -- no [groups][points][C] LDS buffer, so a block is the 37 KB tile + E and four of
+// them share a CU (the two-block version stalled at 3.1 TB/s: the tile load of one block overlapped with the row
+// arithmetic of only one other) -- and one division per row instead of 17 (the 17 IEEE divisions were as many
+// VALU cycles as the tile's HBM time; scale = l / den, out += scale * v is 1 ulp from l * (v / den)).
+template <int C>
+__global__ __launch_bounds__(NTM_THREADS) void ntm_correct_fwd_kernel(
+    int total_pts, int n, float lam, const float *__restrict__ logits, const float *__restrict__ insT,
+    const float *__restrict__ E, float *__restrict__ out)
+{
+    constexpr int CC = C * C, STRIDE = NtmLds<C>::STRIDE;
+    constexpr int LPP = NTM_THREADS / NTM_TILE;  // 8 lanes per point
+    constexpr int ROWS_PT = (C + LPP - 1) / LPP; // rows grp, grp + 8, grp + 16
+    static_assert(LPP == 8, "the DPP sum below covers 8 adjacent lanes");
+    extern __shared__ float ntm_lds[];
+    float *El = ntm_lds;                       // [CC]
+    float *tile = ntm_lds + ((CC + 3) & ~3);   // [NTM_TILE][STRIDE], 16-byte aligned
+    for (int e = threadIdx.x; e < CC; e += NTM_THREADS) El[e] = E[e];
+    const int grp = threadIdx.x & (LPP - 1), pt = threadIdx.x / LPP;
+    for (int i0 = blockIdx.x * NTM_TILE; i0 < total_pts; i0 += gridDim.x * NTM_TILE) {
+        const int cnt = min(NTM_TILE, total_pts - i0);
+        ntm_tile_copy<C, true>(const_cast<float *>(insT) + (size_t)i0 * CC, tile, cnt);
+        __syncthreads();
+        const int i = i0 + pt, b = pt < cnt ? i / n : 0, ni = pt < cnt ? i - b * n : 0;
+        float acc[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        if (pt < cnt) {
+            float l[ROWS_PT];
+#pragma unroll
+            for (int q = 0; q < ROWS_PT; ++q) {
+                const int r = grp + q * LPP;
+                l[q] = r < C ? logits[((size_t)b * C + r) * n + ni] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < ROWS_PT; ++q) {
+                const int r = grp + q * LPP;
+                if (r >= C) continue;
+                const float *row = tile + pt * STRIDE + r * C;
+                float v[C], s = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    v[c] = lam * El[r * C + c] + (1.f - lam) * row[c];
+                    s += fabsf(v[c]);
+                }
+                const float scale = l[q] / fmaxf(s, 1e-12f);
+#pragma unroll
+                for (int c = 0; c < C; ++c) acc[c] = fmaf(scale, v[c], acc[c]);
+            }
+        }
+        // sum over the 8 lanes of a point (all lanes take part: idle points carry zeros)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float v = acc[c];
+            v += __uint_as_float(dpp_mov<DPP_QUAD_XOR1>(__float_as_uint(v)));
+            v += __uint_as_float(dpp_mov<DPP_QUAD_XOR2>(__float_as_uint(v)));
+            v += __uint_as_float(dpp_mov<DPP_ROW_HALF_MIRROR>(__float_as_uint(v)));
+            acc[c] = v;
+        }
+        if (pt < cnt) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+                if ((c & (LPP - 1)) == grp) out[((size_t)b * C + c) * n + ni] = acc[c];
+        }
+        __syncthreads(); // the tile is overwritten by the next copy
     }
 }
 
@@ -997,11 +1057,12 @@ using namespace geot;
 
 #define GEOT_NTM_C 17 /* the reference's num_classes (cfgs/tooth_semi/default.yaml:29) */
 
-static inline int sig_mfma_blocks(long long total_pts)
+static inline int sig_mfma_blocks(long long total_pts, int per_cu)
 {
-    long long tiles = (total_pts + SM_PTS - 1) / SM_PTS;
-    return (int)(tiles < 1 ? 1 : (tiles > 512 ? 512 : tiles)); // 2 blocks per CU x 256 CUs
+    long long tiles = (total_pts + SM_PTS - 1) / SM_PTS, cap = (long long)per_cu * 256; // blocks per CU x 256 CUs
+    return (int)(tiles < 1 ? 1 : (tiles > cap ? cap : tiles));
 }
+constexpr int SIG_FWD_PER_CU = 4, SIG_BWD_PER_CU = 2; // forward: 37 KB of LDS, <= 128 registers; backward: 236 registers
 
 GEOT_EXPORT int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const float *W, const float *cm,
                                     float *ins_T, void *stream)
@@ -1009,10 +1070,10 @@ GEOT_EXPORT int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const f
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)SigMfma<C>::LDS_FLOATS * sizeof(float);
+    size_t lds = (size_t)SigMfma<C>::LDS_FLOATS_FWD * sizeof(float);
     hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, false>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, false>), dim3(sig_mfma_blocks((long long)b * n)), dim3(256), lds,
+    hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, false>), dim3(sig_mfma_blocks((long long)b * n, SIG_FWD_PER_CU)), dim3(256), lds,
                        (hipStream_t)stream, b * n, n, p, W, cm, nullptr, ins_T, nullptr);
     return hipGetLastError();
 }
@@ -1020,7 +1081,7 @@ GEOT_EXPORT int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const f
 GEOT_EXPORT long long geot_ntm_sig_t_mean_ws_floats(int b, int n)
 {
     if (b < 0 || n < 0) return -1;
-    return (long long)sig_mfma_blocks((long long)b * n) * (GEOT_NTM_C + 1) * GEOT_NTM_C * GEOT_NTM_C;
+    return (long long)sig_mfma_blocks((long long)b * n, SIG_BWD_PER_CU) * (GEOT_NTM_C + 1) * GEOT_NTM_C * GEOT_NTM_C;
 }
 
 GEOT_EXPORT int geot_ntm_sig_t_mean_grad_w(int b, int n, int c, const float *p, const float *W, const float *cm,
@@ -1030,10 +1091,10 @@ GEOT_EXPORT int geot_ntm_sig_t_mean_grad_w(int b, int n, int c, const float *p, 
     if (c != GEOT_NTM_C || b < 0 || n < 0 || !workspace) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)SigMfma<C>::LDS_FLOATS * sizeof(float);
+    size_t lds = (size_t)SigMfma<C>::LDS_FLOATS_BWD * sizeof(float);
     hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, true>, lds);
     if (e != hipSuccess) return e;
-    const int nblk = sig_mfma_blocks((long long)b * n);
+    const int nblk = sig_mfma_blocks((long long)b * n, SIG_BWD_PER_CU);
     hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, true>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, b * n, n,
                        p, W, cm, grad_ins_T, nullptr, workspace);
     hipLaunchKernelGGL((sig_t_mean_wgrad_reduce_kernel<C>), dim3(((C + 1) * C * C + 255) / 256, (nblk + 31) / 32), dim3(256), 0,
@@ -1062,12 +1123,11 @@ GEOT_EXPORT int geot_ntm_correct(int b, int n, int c, float lam, const float *lo
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
-    hipError_t e = set_lds(ntm_correct_kernel<C, false>, lds);
+    size_t lds = (size_t)(C * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    hipError_t e = set_lds(ntm_correct_fwd_kernel<C>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ntm_correct_kernel<C, false>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
-                       (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, nullptr, out, nullptr,
-                       nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((ntm_correct_fwd_kernel<C>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
+                       (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, out);
     return hipGetLastError();
 }
 
@@ -1079,11 +1139,11 @@ GEOT_EXPORT int geot_ntm_correct_grad(int b, int n, int c, float lam, const floa
     if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
-    hipError_t e = set_lds(ntm_correct_kernel<C, true>, lds);
+    size_t lds = (size_t)(C * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    hipError_t e = set_lds(ntm_correct_bwd_kernel<C>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((ntm_correct_kernel<C, true>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
-                       (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, grad_out, nullptr,
+    hipLaunchKernelGGL((ntm_correct_bwd_kernel<C>), dim3(ntm_blocks(b * n)), dim3(NTM_THREADS), lds,
+                       (hipStream_t)stream, b * n, n, lam, logits, ins_T, ema_t, grad_out,
                        grad_logits, grad_ins_T, grad_ema_t, nullptr);
     return hipGetLastError();
 }
@@ -1137,12 +1197,12 @@ GEOT_EXPORT int geot_ntm_correct_grad_ws(int b, int n, int c, float lam, const f
         return geot_ntm_correct_grad(b, n, c, lam, logits, ins_T, ema_t, grad_out, grad_logits, grad_ins_T, grad_ema_t,
                                      stream);
     constexpr int C = GEOT_NTM_C;
-    size_t lds = (size_t)(2 * C * C + NTM_GROUPS * NTM_TILE * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
-    hipError_t e = set_lds(ntm_correct_kernel<C, true>, lds);
+    size_t lds = (size_t)(C * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
+    hipError_t e = set_lds(ntm_correct_bwd_kernel<C>, lds);
     if (e != hipSuccess) return e;
     const int nblk = ntm_blocks(b * n);
-    hipLaunchKernelGGL((ntm_correct_kernel<C, true>), dim3(nblk), dim3(NTM_THREADS), lds, (hipStream_t)stream, b * n,
-                       n, lam, logits, ins_T, ema_t, grad_out, nullptr, grad_logits, grad_ins_T, grad_ema_t, workspace);
+    hipLaunchKernelGGL((ntm_correct_bwd_kernel<C>), dim3(nblk), dim3(NTM_THREADS), lds, (hipStream_t)stream, b * n,
+                       n, lam, logits, ins_T, ema_t, grad_out, grad_logits, grad_ins_T, grad_ema_t, workspace);
     hipLaunchKernelGGL(ntm_partial_reduce_kernel, dim3((C * C + 255) / 256, (nblk + 31) / 32), dim3(256), 0,
                        (hipStream_t)stream, nblk, C * C, workspace, grad_ema_t);
     return hipGetLastError();

@@ -38,6 +38,14 @@ with torch.no_grad():
     insT = pred(prob, cm)
 gT = torch.randn_like(insT)
 MB = 1e6
+from geot_amd import _lib  # noqa: E402
+from geot_amd.ext._common import call, ptr  # noqa: E402
+Wh = torch.stack([l.weight for l in pred.T_predictor.fc]).detach().contiguous()
+gW = torch.zeros_like(Wh)
+ws_sig = torch.empty(int(_lib.load().geot_ntm_sig_t_mean_ws_floats(B, N)), device=DEV)
+ws_cor = torch.empty(int(_lib.load().geot_ntm_correct_ws_floats(B, N)), device=DEV)
+gl, gI, gE, gout = torch.empty_like(logits), torch.empty_like(insT), torch.zeros(C, C, device=DEV), torch.randn_like(logits)
+probc = prob.contiguous()
 cases = {
     "three_interpolate fwd C=%d" % CI: (lambda: p2.three_interpolate(fi, i3, w), 4 * B * (CI * N + CI * 8192) + 24 * B * N),
     "three_interpolate bwd C=%d" % CI: (lambda: p2.three_interpolate_grad(gi, i3, w, 8192), 4 * B * (CI * N + CI * 8192) + 24 * B * N),
@@ -46,6 +54,10 @@ cases = {
     "graph_feature fwd C=384 8192x4": (lambda: graph_feature(xq, xq, kidx), 4 * B * (2 * 384 * 8192 * 4 + 2 * 384 * 8192 + 8192 * 4)),
     "sig_t_mean fwd": (lambda: pred(prob, cm), 4 * B * N * (17 + 289)),
     "correct_logits fwd": (lambda: ntm.correct_logits(logits, insT, cm, 0.9), 4 * B * N * (17 + 289 + 17)),
+    "sig_t_mean bwd (grad W)": (lambda: call("geot_ntm_sig_t_mean_grad_w", xyz.device, B, N, C, ptr(probc), ptr(Wh), ptr(cm), ptr(gT),
+                                             ptr(gW), ptr(ws_sig)), 4 * B * N * (17 + 289)),
+    "correct_logits bwd": (lambda: call("geot_ntm_correct_grad_ws", xyz.device, B, N, C, 0.9, ptr(logits), ptr(insT), ptr(cm), ptr(gout),
+                                        ptr(gl), ptr(gI), ptr(gE), ptr(ws_cor)), 4 * B * N * (17 * 3 + 2 * 289)),
 }
 only = os.environ.get("ONLY")
 with torch.no_grad():
@@ -63,6 +75,3 @@ with torch.no_grad():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / ITER * 1e3
         print("%-36s %8.1f us  %7.1f MB  %6.2f TB/s  %4.1f %% of 8 TB/s" % (name, us, nbytes / MB, nbytes / us / 1e6, nbytes / us / 1e6 / 8 * 100), flush=True)
-# backward of the NTM stream kernels (autograd)
-if not only or "bwd" in only:
-    pass
