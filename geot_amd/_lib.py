@@ -50,6 +50,7 @@ PROTOTYPES = {
 PROTOTYPES.update({
     "geot_group_points_grad_ws": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_three_interpolate_grad_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_three_interpolate_grad_out": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_fp_weights": [_c_int, _c_int, _P, _P, _c_void_p],
     "geot_three_interpolate_into": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, ctypes.c_longlong, _c_void_p],
     "geot_three_interpolate_grad_from": [_c_int, _c_int, _c_int, _c_int, _P, ctypes.c_longlong, _P, _P, _P, _P, _c_void_p],

@@ -47,7 +47,7 @@ def build(force=False, verbose=False, variant="exact"):
     """Compile the library (mtime-incremental).  variant: "exact" (default) | "fma" | "fma_xy" -- see VARIANTS."""
     mode, lib_path = VARIANTS[variant]
     obj_dir = OBJ if variant == "exact" else os.path.join(OBJ, variant)
-    flags = FLAGS + ["-DGEOT_DISTANCE_MODE=%d" % mode]
+    flags = FLAGS + ["-DGEOT_DISTANCE_MODE=%d" % mode] + os.environ.get("GEOT_EXTRA_HIPCC_FLAGS", "").split()   # (lab sweeps)
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

@@ -568,7 +568,7 @@ template <bool WEIGHTED, int CH>
 __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
     int c, int m, int L, int Q, int partlen, const float *__restrict__ grad_out, size_t src_bstride,
     const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw,
-    float *__restrict__ grad_table)
+    float *__restrict__ grad_table, int set)
 {
     extern __shared__ float tlds_rows[]; // [CH][plen] this part of CH rows of grad_out
     const int bq = blockIdx.z, bi = bq / Q, part = bq - bi * Q;
@@ -623,12 +623,13 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
             const int j = jb + p * TLDS_THREADS;
-            if (j < j1 && z[p] > a[p]) { // untouched targets keep what they had (the buffer is accumulated into)
+            if (j < j1 && (set || z[p] > a[p])) { // untouched targets keep what they had (the buffer is accumulated into)
 #pragma unroll
                 for (int l = 0; l < CH; ++l) {
                     if (l < nch) {
                         float *dst = grad_table + ((size_t)bi * c + c0 + l) * m + j;
-                        if (Q == 1) *dst += acc[p][l];   // sole writer of this element
+                        if (set) *dst = acc[p][l];       // (Q == 1 only) sole writer, nothing to keep
+                        else if (Q == 1) *dst += acc[p][l];   // sole writer of this element
                         else atomicAdd(dst, acc[p][l]);  // one contribution per part; lanes = consecutive targets
                     }
                 }
@@ -647,7 +648,7 @@ template <bool WEIGHTED, int CH, int TPT>
 __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
     int c, int m, int L, int Q, int partlen, const float *__restrict__ grad_out, size_t src_bstride,
     const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw,
-    float *__restrict__ grad_table)
+    float *__restrict__ grad_table, int set)
 {
     extern __shared__ float tlds_rows[]; // [CH][partlen]
     const int bi = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, c - c0);
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
     for (int p = 0; p < TPT; ++p)
 #pragma unroll
         for (int l = 0; l < CH; ++l) acc[p][l] = 0.f;
-    constexpr int RU = 2, TP = 4;
+    constexpr int RU = 4, TP = 4; // RU 2 -> 4: 1229 -> 1181 us at (8, 1536, 24000 -> 8192); 8: 1269 (registers)
     for (int part = 0; part < Q; ++part) {
         const int p0 = part * partlen, plen = min(partlen, L - p0);
         if (part) __syncthreads(); // the previous part's rows have been read by everyone
@@ -707,7 +708,10 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
         if (j < j1) {
 #pragma unroll
             for (int l = 0; l < CH; ++l)
-                if (l < nch) grad_table[((size_t)bi * c + c0 + l) * m + j] += acc[p][l]; // sole writer (the buffer is accumulated into)
+                if (l < nch) { // sole writer; the buffer is accumulated into unless the caller asked for a plain store
+                    float *dst = grad_table + ((size_t)bi * c + c0 + l) * m + j;
+                    *dst = set ? acc[p][l] : *dst + acc[p][l];
+                }
         }
     }
 }
@@ -751,8 +755,10 @@ static bool csr_applies(int b, int c, int m, long long L, int nt, long long ws_f
 template <int NT, bool WEIGHTED>
 static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride, const float *grad_out,
                                   const int *idx, const float *weight, float *grad_table, float *workspace,
-                                  long long ws_floats, hipStream_t s)
+                                  long long ws_floats, hipStream_t s, bool overwrite = false)
 {
+    // overwrite: grad_table arrives uninitialised.  The one-writer-per-element forms store instead of adding (no
+    // zero-fill, no read of the old value); every other form gets the buffer cleared first.
     if (!csr_applies(b, c, m, L, NT, ws_floats)) return hipErrorNotSupported;
     const RixPlan rp = rix_plan(c, L);
     const int ch = rp.ch, Q = rp.Q;
@@ -777,7 +783,13 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     const size_t lds = (size_t)ch * rp.partlen * sizeof(float);
     const int chunks = (c + ch - 1) / ch;
     const char *impl = getenv("GEOT_GATHER_IMPL");           // "atomic": the per-part kernel + float atomics (A/B runs)
-    if (Q > 1 && m <= 16 * TLDS_THREADS && b <= 65535 && !(impl && impl[0] == 'a')) {
+    const bool parts_inside = Q > 1 && m <= 16 * TLDS_THREADS && b <= 65535 && !(impl && impl[0] == 'a');
+    const int set = overwrite && (parts_inside || Q == 1) ? 1 : 0;
+    if (overwrite && !set) {
+        e = zero_words(grad_table, (long long)b * c * m, s);
+        if (e != hipSuccess) return e;
+    }
+    if (parts_inside) {
         // parts looped inside the workgroup: one writer per output, no atomics, reproducible
         const int tpt = m <= 8 * TLDS_THREADS ? 8 : 16;
         const dim3 grid(1, chunks, b);
@@ -786,7 +798,7 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
         e = tlds_set_lds(table_gather_csr_parts_kernel<WEIGHTED, CHV, TPTV>, lds);                                  \
         if (e != hipSuccess) return e;                                                                              \
         hipLaunchKernelGGL((table_gather_csr_parts_kernel<WEIGHTED, CHV, TPTV>), grid, dim3(TLDS_THREADS), lds, s, c, m, \
-                           L, Q, rp.partlen, grad_out, src_bstride, off, rev, revw, grad_table);                    \
+                           L, Q, rp.partlen, grad_out, src_bstride, off, rev, revw, grad_table, set);               \
     }
         if (tpt == 8) {
             if (ch == 8) GEOT_PARTS_LAUNCH(8, 8) else if (ch == 4) GEOT_PARTS_LAUNCH(4, 8) else if (ch == 2) GEOT_PARTS_LAUNCH(2, 8) else GEOT_PARTS_LAUNCH(1, 8)
@@ -806,7 +818,7 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
         e = tlds_set_lds(table_gather_csr_lds_kernel<WEIGHTED, CHV>, lds);                                       \
         if (e != hipSuccess) return e;                                                                           \
         hipLaunchKernelGGL((table_gather_csr_lds_kernel<WEIGHTED, CHV>), grid, dim3(TLDS_THREADS), lds, s, c, m, L, \
-                           Q, rp.partlen, grad_out, src_bstride, off, rev, revw, grad_table);                    \
+                           Q, rp.partlen, grad_out, src_bstride, off, rev, revw, grad_table, set);               \
     }
     if (ch == 8) GEOT_CSR_LAUNCH(8) else if (ch == 4) GEOT_CSR_LAUNCH(4) else if (ch == 2) GEOT_CSR_LAUNCH(2) else GEOT_CSR_LAUNCH(1)
 #undef GEOT_CSR_LAUNCH
@@ -962,15 +974,21 @@ GEOT_EXPORT int geot_grad_ws_needs_zero(int b, int c, int m, long long L, int nt
 
 static int three_interpolate_grad_launch(int b, int c, int n, int m, const float *grad_out, size_t grad_bstride,
                                          const int *idx, const float *weight, float *grad_points, float *workspace,
-                                         hipStream_t s)
+                                         hipStream_t s, bool overwrite = false)
 {
     if (b < 0 || c < 0 || n < 0 || m < 0 || !workspace || grad_bstride < (size_t)c * n) return hipErrorInvalidValue;
-    if (b == 0 || c == 0 || n == 0 || m == 0) return hipSuccess;
+    if (b == 0 || c == 0 || m == 0) return hipSuccess;
+    if (n == 0) return overwrite ? (int)zero_words(grad_points, (long long)b * c * m, s) : (int)hipSuccess;
     if (b > 65535) return hipErrorInvalidValue;
     {
         hipError_t e = scatter_via_csr<3, true>(b, c, m, n, grad_bstride, grad_out, idx, weight, grad_points, workspace,
-                                                (long long)b * m * c, s);
+                                                (long long)b * m * c, s, overwrite);
         if (e != hipErrorNotSupported) return e;
+    }
+    if (overwrite) {   // the channels-last scatter accumulates in the workspace and adds into grad_points
+        hipError_t e = zero_words(grad_points, (long long)b * c * m, s);
+        if (e == hipSuccess) e = zero_words(workspace, (long long)b * c * m, s);
+        if (e != hipSuccess) return e;
     }
     dim3 g1((n + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);
     hipLaunchKernelGGL((scatter_rows_cl_kernel<3, true>), g1, dim3(256), 0, s, c, n, m, grad_out, grad_bstride, idx, weight,
@@ -986,6 +1004,14 @@ GEOT_EXPORT int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const
 {
     return three_interpolate_grad_launch(b, c, n, m, grad_out, (size_t)(c > 0 ? c : 0) * (n > 0 ? n : 0), idx, weight,
                                          grad_points, workspace, (hipStream_t)stream);
+}
+
+// as _grad_ws, but grad_points and the workspace arrive UNINITIALISED and every element of grad_points is written
+GEOT_EXPORT int geot_three_interpolate_grad_out(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                                const float *weight, float *grad_points, float *workspace, void *stream)
+{
+    return three_interpolate_grad_launch(b, c, n, m, grad_out, (size_t)(c > 0 ? c : 0) * (n > 0 ? n : 0), idx, weight,
+                                         grad_points, workspace, (hipStream_t)stream, true);
 }
 
 // as _grad_ws with grad_out being the first c channels of a wider (B, c + c_skip, n) gradient

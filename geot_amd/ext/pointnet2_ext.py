@@ -82,12 +82,13 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     dev = same_device(grad_out, idx, weight)
     b, c, n = grad_out.shape
     need(tuple(idx.shape) == (b, n, 3) and tuple(weight.shape) == (b, n, 3), "idx/weight must be (B, n, 3)")
-    out = torch.zeros((b, c, int(m)), dtype=torch.float32, device=dev)
     if c < 16:   # too few channels to fill a wave's 256-B atomic row: direct scatter
+        out = torch.zeros((b, c, int(m)), dtype=torch.float32, device=dev)
         call("geot_three_interpolate_grad", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out))
         return out
-    ws = grad_workspace(dev, b, c, int(m), n, 3)
-    call("geot_three_interpolate_grad_ws", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out),
+    out = torch.empty((b, c, int(m)), dtype=torch.float32, device=dev)      # every element is written by the call
+    ws = torch.empty(b * c * int(m), dtype=torch.float32, device=dev)
+    call("geot_three_interpolate_grad_out", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out),
          ptr(ws))
     return out
 

@@ -99,6 +99,12 @@ int geot_grad_ws_needs_zero(int b, int c, int m_targets, long long n_sources, in
 int geot_three_interpolate_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
                                    const float *weight, float *grad_points, float *workspace,
                                    void *stream);
+/* As geot_three_interpolate_grad_ws, for a grad_points (and a workspace) that arrive UNINITIALISED: every element
+ * of grad_points is written.  Where one thread owns an output element (the reverse-index gather) the result is
+ * stored instead of added: no zero-fill pass and no read of the old value, 12 % of the op at (8, 1536, 24000 ->
+ * 8192).  Replaces the torch.zeros + accumulate of pointnet2_utils.py:147-165's backward. */
+int geot_three_interpolate_grad_out(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                    const float *weight, float *grad_points, float *workspace, void *stream);
 /* PointnetFPModule front end (pointnet2/pointnet2_modules.py:619-626; openpoints' three_interpolation is the same
  * chain) without its temporaries.  geot_fp_weights: the inverse-distance weights from three_nn's SQUARED
  * distances, weight = r / ((r0 + r1) + r2), r = 1 / (sqrt(d2) + 1e-8), in one launch.  _into / _grad_from: the

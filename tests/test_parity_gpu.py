@@ -268,6 +268,27 @@ def test_three_interpolate_fwd_bwd(ext, oracle):
     np.testing.assert_allclose(host(g2), host(g), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("b,c,m,n", [(2, 64, 2048, 6000),      # reverse index, whole rows in LDS (one part)
+                                      (2, 32, 4096, 24000),     # reverse index, source parts looped in the workgroup
+                                      (1, 40, 50, 300),         # too small for the reverse index: channels-last scatter
+                                      (1, 24, 70, 0)])          # nothing to scatter: zeros
+def test_three_interpolate_grad_out_overwrites_uninitialised_buffers(ext, oracle, b, c, m, n):
+    """geot_three_interpolate_grad_out: grad_points and the workspace arrive full of NaNs; every element is written
+    (targets no unknown point refers to become 0) and the result equals the accumulate-into-zeros entry point."""
+    from geot_amd.ext._common import call, ptr
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, max(m - 7, 1), (b, n, 3)).astype(np.int32)          # the last targets stay untouched
+    w = rng.random((b, n, 3)).astype(np.float32)
+    go = rng.standard_normal((b, c, n)).astype(np.float32)
+    out = torch.full((b, c, m), float("nan"), device=DEV)
+    ws = torch.full((b * c * m,), float("nan"), device=DEV)
+    d_go, d_idx, d_w = dev(go), dev(idx), dev(w)          # named: the raw pointers below do not keep them alive
+    call("geot_three_interpolate_grad_out", out.device, b, c, n, m, ptr(d_go), ptr(d_idx), ptr(d_w), ptr(out), ptr(ws))
+    want = oracle.three_interpolate_grad(go, idx, w, m) if n else np.zeros((b, c, m), np.float32)
+    np.testing.assert_allclose(host(out), want, rtol=1e-4, atol=1e-5)
+    assert (host(out)[:, :, m - 7:] == 0).all()
+
+
 def test_reference_gradcheck_vector_on_gpu(ext):
     """pointnet2/pointnet2_test.py:15-27 through the autograd wrapper."""
     from geot_amd.pointnet2 import pointnet2_utils as pu

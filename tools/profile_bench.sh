@@ -13,7 +13,7 @@ python3 bench.py "$@" > $OUT/$TAG.json 2> $OUT/$TAG.err || { echo "bench failed"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o kt -- python3 $ROOT/bench.py "$@" --steps 3 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1
 cp $OUT/prof_$TAG/kt_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
-python3 $ROOT/tools/trace_window.py $OUT/prof_$TAG/kt_kernel_trace.csv --skip 2 --steps 3 -o $OUT/${TAG}_window.csv > $OUT/${TAG}_window.txt 2>&1
+python3 $ROOT/tools/trace_window.py $OUT/prof_$TAG/kt_kernel_trace.csv --skip 2 --steps 3 -o $OUT/${TAG}_window.csv --per-launch $OUT/${TAG}_launches.csv > $OUT/${TAG}_window.txt 2>&1
 rm -rf $OUT/prof_$TAG
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$CTR -o pmc -- python3 $ROOT/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$CTR.log 2>&1

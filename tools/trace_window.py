@@ -22,12 +22,17 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("-o", "--out", default=None)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--per-launch", default=None, help="also write every launch of the first window step, in start order")
     a = ap.parse_args()
     rows = []
     with open(a.trace) as f:
         for r in csv.DictReader(f):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"],
+                         r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")),
+                         r.get("LDS_Block_Size", ""), r.get("Stream_Id", r.get("Queue_Id", ""))))
     rows.sort()
+    full = rows
+    rows = [r[:3] for r in rows]
     anchors = [s for s, e, n in rows if a.anchor in n and (e - s) >= a.min_us * 1e3]
     assert len(anchors) > a.skip + a.steps, "only %d anchor launches" % len(anchors)
     t0, t1 = anchors[a.skip], anchors[a.skip + a.steps]
@@ -45,6 +50,13 @@ def main():
           (a.steps, wall, busy / a.steps / 1e6, sum(v[0] for v in agg.values()) / a.steps))
     for r in out[:a.top + 1]:
         print("%-100s %8s %10s %10s %8s" % (r[0][:100], r[1], r[2], r[3], r[4]))
+    if a.per_launch:
+        with open(a.per_launch, "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(("start_us", "dur_us", "grid_x", "wg_x", "lds", "stream", "kernel"))
+            for s, e, n, g, wg, lds, st in full:
+                if t0 <= s < anchors[a.skip + 1]:
+                    w.writerow(("%.1f" % ((s - t0) / 1e3), "%.1f" % ((e - s) / 1e3), g, wg, lds, st, n[:110]))
     if a.out:
         with open(a.out, "w", newline="") as f:
             f.write("# steady-state window of %d steps: wall %.3f ms/step, summed kernel time %.3f ms/step\n" %
