@@ -348,6 +348,75 @@ static int bn_gx(int l)
     return gx < 1 ? 1 : (gx > 64 ? 64 : gx);
 }
 
+// ---- the O(c) arithmetic between the passes --------------------------------------------------------------------
+// One wave per channel sums the (b x S) partial pairs in fp64, lanes striding over them, then a fixed butterfly:
+// the same order on every run.
+__global__ __launch_bounds__(64) void bn_sums_kernel(int b, int c, int s, const float *__restrict__ partial,
+                                                     double *__restrict__ sums)
+{
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (int t = lane; t < b * s; t += 64) {
+        const int bi = t / s, sl = t - bi * s;
+        const float2 v = reinterpret_cast<const float2 *>(partial)[((size_t)bi * c + ch) * s + sl];
+        a0 += (double)v.x;
+        a1 += (double)v.y;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+    }
+    if (lane == 0) {
+        sums[2 * ch] = a0;
+        sums[2 * ch + 1] = a1;
+    }
+}
+
+// mean / biased variance from (sum x, sum x^2) and the element count, everything BatchNorm derives from them:
+// rstd, the affine pair of the apply pass, the running statistics (unbiased variance, factor eaf).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(int c, const double *__restrict__ sums, double count,
+                                                          const double *__restrict__ count_dev, double eps, double eaf,
+                                                          const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                          float *__restrict__ mean, float *__restrict__ rstd,
+                                                          float *__restrict__ scale, float *__restrict__ shift)
+{
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    const double n = count_dev ? *count_dev : count;
+    const double m64 = sums[2 * ch] / n;
+    double v64 = sums[2 * ch + 1] / n - m64 * m64;
+    v64 = v64 > 0.0 ? v64 : 0.0;
+    const float m = (float)m64, r = (float)(1.0 / sqrt(v64 + eps));
+    const float sc = (gamma ? gamma[ch] : 1.f) * r;
+    mean[ch] = m;
+    rstd[ch] = r;
+    scale[ch] = sc;
+    shift[ch] = (beta ? beta[ch] : 0.f) - m * sc;
+    if (running_mean) running_mean[ch] = running_mean[ch] * (float)(1.0 - eaf) + (float)eaf * m;
+    if (running_var) {
+        const double unbiased = v64 * (n / (n - 1.0 > 1.0 ? n - 1.0 : 1.0));
+        running_var[ch] = running_var[ch] * (float)(1.0 - eaf) + (float)eaf * (float)unbiased;
+    }
+}
+
+// backward: the parameter gradients from this rank's sums, the two means of the input gradient from the (all-reduced)
+// sums; count == 0 (running statistics were used: constants) gives c1 = c2 = 0
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(int c, const double *__restrict__ local, const double *__restrict__ sums,
+                                                          double count, const double *__restrict__ count_dev,
+                                                          float *__restrict__ g_gamma, float *__restrict__ g_beta,
+                                                          float *__restrict__ c1, float *__restrict__ c2)
+{
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= c) return;
+    const double n = count_dev ? *count_dev : count;
+    g_beta[ch] = (float)local[2 * ch];
+    g_gamma[ch] = (float)local[2 * ch + 1];
+    c1[ch] = n > 0.0 ? (float)(sums[2 * ch] / n) : 0.f;
+    c2[ch] = n > 0.0 ? (float)(sums[2 * ch + 1] / n) : 0.f;
+}
+
 } // namespace geot
 
 using namespace geot;
@@ -385,6 +454,32 @@ GEOT_EXPORT int geot_bn_bwd_apply(int b, int c, int l, int relu, const float *x,
     if (!bn_dims_ok(b, c, l)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_gx(l), c, b), dim3(BN_THREADS), 0, (hipStream_t)stream, c, l, relu, x, dz,
                        scale, shift, mean, rstd, k0, c1, c2, dx);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_sums(int b, int c, int s, const float *partial, double *sums, void *stream)
+{
+    if (b < 1 || c < 1 || s < 1 || !partial || !sums) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_sums_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, b, c, s, partial, sums);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_finalize(int c, const double *sums, double count, const double *count_dev, double eps, double eaf,
+                                 const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                 float *mean, float *rstd, float *scale, float *shift, void *stream)
+{
+    if (c < 1 || !sums || !mean || !rstd || !scale || !shift || (!count_dev && !(count > 0.0))) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, sums, count, count_dev,
+                       eps, eaf, gamma, beta, running_mean, running_var, mean, rstd, scale, shift);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_bwd_coef(int c, const double *local_sums, const double *sums, double count, const double *count_dev,
+                                 float *g_gamma, float *g_beta, float *c1, float *c2, void *stream)
+{
+    if (c < 1 || !local_sums || !sums || !g_gamma || !g_beta || !c1 || !c2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, local_sums, sums, count,
+                       count_dev, g_gamma, g_beta, c1, c2);
     return hipGetLastError();
 }
 

@@ -31,14 +31,15 @@ class _BnActFn(Function):
     `count` > 0: training mode; `count` = number of elements per channel over all ranks)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean, rstd, relu, count, group):
+    def forward(ctx, x, gamma, beta, mean, rstd, scale, shift, relu, count, group):
         b, c, l = x.shape
-        scale = (gamma * rstd).contiguous()
-        shift = (beta - mean * scale).contiguous()
+        if scale is None:
+            scale = (gamma * rstd).contiguous()
+            shift = (beta - mean * scale).contiguous()
         out = torch.empty_like(x)
         call("geot_bn_apply", x.device, b, c, l, int(relu), ptr(x), ptr(scale), ptr(shift), ptr(out))
         ctx.save_for_backward(x, gamma, scale, shift, mean, rstd)
-        ctx.cfg = (bool(relu), count, group)      # count: python float, or a 0-dim device tensor under SyncBatchNorm
+        ctx.cfg = (bool(relu), count, group)      # count: python float, or a 1-element device double under SyncBatchNorm
         return out
 
     @staticmethod
@@ -46,25 +47,27 @@ class _BnActFn(Function):
         x, gamma, scale, shift, mean, rstd = ctx.saved_tensors
         relu, count, group = ctx.cfg
         b, c, l = x.shape
+        dev = x.device
         dz = dz.contiguous()
         slices = int(_lib.load().geot_bn_slices(b, c, l))
-        partial = torch.empty((b, c, slices, 2), dtype=torch.float32, device=x.device)
-        call("geot_bn_bwd_reduce", x.device, b, c, l, int(relu), ptr(x), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
+        partial = torch.empty((b, c, slices, 2), dtype=torch.float32, device=dev)
+        call("geot_bn_bwd_reduce", dev, b, c, l, int(relu), ptr(x), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
              ptr(rstd), ptr(partial))
-        sums = partial.sum(dim=(0, 2), dtype=torch.float64)                  # (C, 2): sum g, sum g * xhat (this rank)
-        g_beta, g_gamma = sums[:, 0].float(), sums[:, 1].float()
-        if torch.is_tensor(count) or count > 0:                              # batch statistics: they depend on x
-            if group is not None:
-                import torch.distributed as dist
-                sums = sums.clone()
-                dist.all_reduce(sums, group=group)                           # SyncBatchNorm: the means are over all ranks
-            c1, c2 = (sums[:, 0] / count).float(), (sums[:, 1] / count).float()
-        else:                                                                # running statistics: constants
-            c1 = c2 = torch.zeros(c, dtype=torch.float32, device=x.device)
+        local = torch.empty((c, 2), dtype=torch.float64, device=dev)         # sum g, sum g * xhat (this rank)
+        call("geot_bn_sums", dev, b, c, slices, ptr(partial), ptr(local))
+        sums = local
+        if group is not None:
+            import torch.distributed as dist
+            sums = local.clone()
+            dist.all_reduce(sums, group=group)                               # SyncBatchNorm: the means are over all ranks
+        coef = torch.empty((4, c), dtype=torch.float32, device=dev)          # g_gamma, g_beta, c1, c2
+        on_dev = torch.is_tensor(count)                                      # batch statistics: they depend on x (count > 0)
+        call("geot_bn_bwd_coef", dev, c, ptr(local), ptr(sums), 0.0 if on_dev else float(count), ptr(count) if on_dev else None,
+             ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]))
         dx = torch.empty_like(x)
-        call("geot_bn_bwd_apply", x.device, b, c, l, int(relu), ptr(x), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
-             ptr(rstd), ptr(scale), ptr(c1.contiguous()), ptr(c2.contiguous()), ptr(dx))
-        return dx, g_gamma, g_beta, None, None, None, None, None
+        call("geot_bn_bwd_apply", dev, b, c, l, int(relu), ptr(x), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
+             ptr(rstd), ptr(scale), ptr(coef[2]), ptr(coef[3]), ptr(dx))
+        return dx, coef[0], coef[1], None, None, None, None, None, None, None
 
 
 def _covered(bn, x):
@@ -89,33 +92,48 @@ def bn_act(bn, x, relu=True, partial=None):
         with torch.no_grad():
             mean = bn.running_mean.float()
             rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
-        return _BnActFn.apply(x, gamma, beta, mean, rstd, relu, 0.0, None)
+        return _BnActFn.apply(x, gamma, beta, mean, rstd, None, None, relu, 0.0, None)
     group = _sync_group(bn)
     with torch.no_grad():
         if partial is None:
             slices = int(_lib.load().geot_bn_slices(b, c, l))
             partial = torch.empty((b, c, slices, 2), dtype=torch.float32, device=dev)
             call("geot_bn_stats", dev, b, c, l, ptr(x), ptr(partial))
-        sums = partial.sum(dim=(0, 2), dtype=torch.float64)                  # (C, 2)
+        slices = partial.shape[2]
+        # everything between the two passes in two launches (csrc/bnrelu.hip; ~13 torch launches per layer otherwise)
+        sums = torch.empty((c, 2), dtype=torch.float64, device=dev)
+        call("geot_bn_sums", dev, b, c, slices, ptr(partial), ptr(sums))
         count = float(b * l)
+        count_dev = None
         if group is not None:                  # SyncBatchNorm: sums and element counts of all ranks (counts may differ);
             import torch.distributed as dist   # the total stays on the device: no host synchronisation
             pack = torch.cat([sums.reshape(-1), torch.tensor([count], dtype=torch.float64, device=dev)])
             dist.all_reduce(pack, group=group)
-            sums, count = pack[:-1].view(c, 2), pack[-1]
-        mean64 = sums[:, 0] / count
-        var64 = (sums[:, 1] / count - mean64 * mean64).clamp_min_(0.0)
-        mean, rstd = mean64.float(), torch.rsqrt(var64 + bn.eps).float()
-        if bn.training and bn.track_running_stats and bn.running_mean is not None:
+            sums, count_dev = pack[:-1], pack[-1:]
+            count = count_dev
+        track = bn.training and bn.track_running_stats and bn.running_mean is not None
+        eaf = 0.0
+        if track:
             eaf = 0.0 if bn.momentum is None else bn.momentum
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked.add_(1)
                 if bn.momentum is None:
                     eaf = 1.0 / float(bn.num_batches_tracked)
-            unbiased = var64 * (count / (count - 1.0)) if torch.is_tensor(count) else var64 * (count / max(count - 1.0, 1.0))
+        f32_running = track and bn.running_mean.dtype == torch.float32 and bn.running_var.dtype == torch.float32
+        stats = torch.empty((4, c), dtype=torch.float32, device=dev)         # mean, rstd, scale, shift
+        g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()   # named: raw pointers below
+        call("geot_bn_finalize", dev, c, ptr(sums), 0.0 if count_dev is not None else count,
+             ptr(count_dev) if count_dev is not None else None, float(bn.eps), float(eaf), ptr(g32), ptr(b32),
+             ptr(bn.running_mean) if f32_running else None, ptr(bn.running_var) if f32_running else None,
+             ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]))
+        if track and not f32_running:          # buffers in another precision: the O(c) update in torch
+            n = count_dev[0] if count_dev is not None else count
+            mean64 = sums.view(c, 2)[:, 0] / n
+            var64 = (sums.view(c, 2)[:, 1] / n - mean64 * mean64).clamp_min_(0.0)
+            unbiased = var64 * (n / (n - 1.0)) if torch.is_tensor(n) else var64 * (n / max(n - 1.0, 1.0))
             bn.running_mean.mul_(1.0 - eaf).add_(mean64.to(bn.running_mean.dtype), alpha=eaf)
             bn.running_var.mul_(1.0 - eaf).add_(unbiased.to(bn.running_var.dtype), alpha=eaf)
-    return _BnActFn.apply(x, gamma, beta, mean, rstd, relu, count, group)
+    return _BnActFn.apply(x, gamma, beta, stats[0], stats[1], stats[2], stats[3], relu, count, group)
 
 
 class _FpFrontFn(Function):

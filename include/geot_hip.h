@@ -149,6 +149,20 @@ int geot_three_nn_ws(int b, int n, int m, const float *unknown, const float *kno
  * the interpolation:  y (b,c,n) = sum_t weight[.,t] A[:, idx[.,t]] + Wb (c,cs) skip (b,cs,n),  A (b,c,m) = W_a
  * known_feats from the caller's GEMM, cs <= 8; partial (b,c,S',2) = per-slice (sum y, sum y^2) for the BatchNorm
  * behind it (S' = geot_fp_front_slices).  Rows of A must fit the LDS (m <= 36864). */
+/* The O(c) arithmetic between the passes as launches of its own (13 and 7 torch launches per layer otherwise:
+ * 2.5 % of the configs[2] step), split where SyncBatchNorm all-reduces:
+ *   geot_bn_sums      sums (c,2) fp64 = sum over b and S of partial (b,c,S,2), fixed order
+ *   geot_bn_finalize  n = count_dev ? *count_dev (device double: the all-reduced element count) : count;
+ *                     mean = sums0/n, var = max(sums1/n - mean^2, 0) in fp64; mean, rstd = 1/sqrt(var+eps) as fp32;
+ *                     scale = gamma*rstd, shift = beta - mean*scale (gamma / beta NULL: 1 / 0); running_mean / _var
+ *                     (NULL: not tracked) <- (1-eaf)*old + eaf*(mean | var*n/max(n-1,1))  (torch batch_norm semantics)
+ *   geot_bn_bwd_coef  g_beta, g_gamma = fp32 of local_sums (this rank's sum g, sum g xhat); c1, c2 = sums/n (0 if n == 0) */
+int geot_bn_sums(int b, int c, int s, const float *partial, double *sums, void *stream);
+int geot_bn_finalize(int c, const double *sums, double count, const double *count_dev, double eps, double eaf,
+                     const float *gamma, const float *beta, float *running_mean, float *running_var, float *mean,
+                     float *rstd, float *scale, float *shift, void *stream);
+int geot_bn_bwd_coef(int c, const double *local_sums, const double *sums, double count, const double *count_dev,
+                     float *g_gamma, float *g_beta, float *c1, float *c2, void *stream);
 int geot_bn_slices(int b, int c, int l);
 int geot_bn_stats(int b, int c, int l, const float *x, float *partial, void *stream);
 int geot_bn_apply(int b, int c, int l, int relu, const float *x, const float *scale, const float *shift, float *out,
