@@ -46,12 +46,22 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
 
-    def forward(self, x):
+    def scale(self, x):
+        """The per-sample factor (B, 1, ...): Bernoulli(keep) / keep, or None when nothing is dropped."""
         if self.drop_prob == 0.0 or not self.training:
-            return x
+            return None
         keep = 1.0 - self.drop_prob
-        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-        return x * mask.div_(keep)
+        return x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep).div_(keep)
+
+    def forward(self, x):
+        mask = self.scale(x)
+        return x if mask is None else x * mask
+
+
+def _residual(x, branch, drop_path):
+    """x + drop_path(branch) with the mask multiply and the add as one launch (torch.addcmul)."""
+    mask = drop_path.scale(branch) if isinstance(drop_path, DropPath) else None
+    return x + branch if mask is None else torch.addcmul(x, branch, mask)
 
 
 class Mlp(nn.Module):
@@ -79,10 +89,22 @@ class Attention(nn.Module):
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
         self.fused = os.environ.get("GEOT_ATTN", "manual") == "sdpa"   # measured in the full step: sdpa 46.0 ms, manual 45.3
+        self.lean = False            # set by PointTransformer_seg_T when dense != "reference"
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        H, d = self.num_heads, C // self.num_heads
+        if self.lean and (self.attn_drop.p == 0.0 or not self.training):
+            # The same function in fewer launches (26 -> 12 per block forward + backward at 512 tokens, where every
+            # launch is ~5 us of a 40 us GEMM neighbourhood): q, k, v leave ONE permuted copy of the projection as
+            # contiguous (B*H, N, d) views (their gradients come back through one stack instead of three
+            # zero-fill + copy + add chains), and the 1/sqrt(d) rides in the GEMM (baddbmm's alpha) instead of an
+            # element-wise pass over the (B, H, N, N) scores each way.
+            q, k, v = self.qkv(x).view(B, N, 3, H, d).permute(2, 0, 3, 1, 4).contiguous().view(3, B * H, N, d).unbind(0)
+            attn = torch.baddbmm(q.new_empty(()), q, k.transpose(1, 2), beta=0.0, alpha=self.scale).softmax(dim=-1)
+            x = torch.bmm(attn, v).view(B, H, N, d).transpose(1, 2).reshape(B, N, C)
+            return self.proj_drop(self.proj(x))
+        qkv = self.qkv(x).reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         if self.fused and x.is_cuda and (self.attn_drop.p == 0.0 or not self.training):
             # softmax(q k^T scale) v as one kernel (torch's memory-efficient attention runs fp32 on gfx950): same
@@ -108,6 +130,9 @@ class Block(nn.Module):
                               proj_drop=drop)
 
     def forward(self, x):
+        if self.attn.lean:
+            x = _residual(x, self.attn(self.norm1(x)), self.drop_path)
+            return _residual(x, self.mlp(self.norm2(x)), self.drop_path)
         x = x + self.drop_path(self.attn(self.norm1(x)))
         return x + self.drop_path(self.mlp(self.norm2(x)))
 
@@ -312,6 +337,8 @@ class PointTransformer_seg_T(nn.Module):
                                            num_heads=self.num_heads, finetune=True,
                                            extract_layers=self.extract_layers)
         self.norm = nn.LayerNorm(self.trans_dim)
+        for blk in self.blocks.blocks:
+            blk.attn.lean = self.dense != "reference"
 
         self.propogation_2 = PointnetFPModule([self.trans_dim + 3, self.trans_dim * 4, self.trans_dim])
         self.propogation_1 = PointnetFPModule([self.trans_dim + 3, self.trans_dim * 4, self.trans_dim])

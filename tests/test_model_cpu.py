@@ -161,3 +161,22 @@ def test_ddp_gradients_equal_single_process():
         assert np.array_equal(res[0][k], res[1][k]), k                       # every rank holds the same average
         err = np.linalg.norm(res[0][k] - w.numpy()) / (float(w.norm()) + 1e-12)
         assert err <= 1e-3, (k, err)                 # fp32: the GEMM blocking differs with the batch size
+
+
+def test_lean_transformer_block_is_the_same_function():
+    """dense != "reference" runs the transformer blocks through fewer launches (one permuted copy of the qkv
+    projection + unbind, the 1/sqrt(d) inside baddbmm, addcmul for drop-path + residual): the same function and the
+    same random draws, checked in fp64 with and without stochastic depth."""
+    from geot_amd.openpoints.models.backbone.transformer import Block
+    torch.manual_seed(0)
+    x = torch.randn(3, 50, 96, dtype=torch.double, requires_grad=True)
+    for dp in (0.0, 0.3):
+        blk = Block(96, 4, drop_path=dp).double().train()
+        outs = []
+        for lean in (False, True):
+            blk.attn.lean = lean
+            torch.manual_seed(7)
+            y = blk(x)
+            outs.append([y] + list(torch.autograd.grad(y.square().sum(), [x] + list(blk.parameters()))))
+        for a, b in zip(*outs):
+            assert float((a - b).abs().max()) < 1e-12
