@@ -89,7 +89,7 @@ PROTOTYPES.update({
 })
 PROTOTYPES.update({
     "geot_bn_sums": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
-    "geot_bn_finalize": [_c_int, _P, ctypes.c_double, _P, ctypes.c_double, ctypes.c_double] + [_P] * 8 + [_c_void_p],
+    "geot_bn_finalize": [_c_int, _P, ctypes.c_double, _P, ctypes.c_double, ctypes.c_double] + [_P] * 9 + [_c_void_p],
     "geot_bn_bwd_coef": [_c_int, _P, _P, ctypes.c_double, _P] + [_P] * 4 + [_c_void_p],
     "geot_bn_stats": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
     "geot_bn_apply": [_c_int] * 4 + [_P] * 4 + [_c_void_p],

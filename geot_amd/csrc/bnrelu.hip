@@ -378,6 +378,7 @@ __global__ __launch_bounds__(64) void bn_sums_kernel(int b, int c, int s, const 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(int c, const double *__restrict__ sums, double count,
                                                           const double *__restrict__ count_dev, double eps, double eaf,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                          const float *__restrict__ pre_bias,
                                                           float *__restrict__ running_mean, float *__restrict__ running_var,
                                                           float *__restrict__ mean, float *__restrict__ rstd,
                                                           float *__restrict__ scale, float *__restrict__ shift)
@@ -394,7 +395,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(int c, const double *_
     rstd[ch] = r;
     scale[ch] = sc;
     shift[ch] = (beta ? beta[ch] : 0.f) - m * sc;
-    if (running_mean) running_mean[ch] = running_mean[ch] * (float)(1.0 - eaf) + (float)eaf * m;
+    // pre_bias: the statistics are of y, the layer normalises y + pre_bias (same output; the running mean sees the bias)
+    if (running_mean)
+        running_mean[ch] = running_mean[ch] * (float)(1.0 - eaf) + (float)eaf * (pre_bias ? (float)(m64 + (double)pre_bias[ch]) : m);
     if (running_var) {
         const double unbiased = v64 * (n / (n - 1.0 > 1.0 ? n - 1.0 : 1.0));
         running_var[ch] = running_var[ch] * (float)(1.0 - eaf) + (float)eaf * (float)unbiased;
@@ -465,12 +468,12 @@ GEOT_EXPORT int geot_bn_sums(int b, int c, int s, const float *partial, double *
 }
 
 GEOT_EXPORT int geot_bn_finalize(int c, const double *sums, double count, const double *count_dev, double eps, double eaf,
-                                 const float *gamma, const float *beta, float *running_mean, float *running_var,
-                                 float *mean, float *rstd, float *scale, float *shift, void *stream)
+                                 const float *gamma, const float *beta, const float *pre_bias, float *running_mean,
+                                 float *running_var, float *mean, float *rstd, float *scale, float *shift, void *stream)
 {
     if (c < 1 || !sums || !mean || !rstd || !scale || !shift || (!count_dev && !(count > 0.0))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, sums, count, count_dev,
-                       eps, eaf, gamma, beta, running_mean, running_var, mean, rstd, scale, shift);
+                       eps, eaf, gamma, beta, pre_bias, running_mean, running_var, mean, rstd, scale, shift);
     return hipGetLastError();
 }
 

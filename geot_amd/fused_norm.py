@@ -31,7 +31,7 @@ class _BnActFn(Function):
     `count` > 0: training mode; `count` = number of elements per channel over all ranks)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, mean, rstd, scale, shift, relu, count, group):
+    def forward(ctx, x, gamma, beta, mean, rstd, scale, shift, relu, count, group, pre_bias=None):
         b, c, l = x.shape
         if scale is None:
             scale = (gamma * rstd).contiguous()
@@ -40,6 +40,7 @@ class _BnActFn(Function):
         call("geot_bn_apply", x.device, b, c, l, int(relu), ptr(x), ptr(scale), ptr(shift), ptr(out))
         ctx.save_for_backward(x, gamma, scale, shift, mean, rstd)
         ctx.cfg = (bool(relu), count, group)      # count: python float, or a 1-element device double under SyncBatchNorm
+        ctx.has_pre_bias = pre_bias is not None
         return out
 
     @staticmethod
@@ -67,7 +68,10 @@ class _BnActFn(Function):
         dx = torch.empty_like(x)
         call("geot_bn_bwd_apply", dev, b, c, l, int(relu), ptr(x), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
              ptr(rstd), ptr(scale), ptr(coef[2]), ptr(coef[3]), ptr(dx))
-        return dx, coef[0], coef[1], None, None, None, None, None, None, None
+        g_pre = None
+        if ctx.has_pre_bias:    # d/d pre_bias = sum of dx over (b, l): exactly 0 under batch statistics, scale * sum g otherwise
+            g_pre = scale * coef[1] if (not on_dev and float(count) == 0.0) else torch.zeros_like(scale)
+        return dx, coef[0], coef[1], None, None, None, None, None, None, None, g_pre
 
 
 def _covered(bn, x):
@@ -75,12 +79,14 @@ def _covered(bn, x):
             and x.dim() == 3 and x.shape[0] <= 65535 and x.shape[1] <= 65535 and x.numel() > 0)
 
 
-def bn_act(bn, x, relu=True, partial=None):
+def bn_act(bn, x, relu=True, partial=None, pre_bias=None):
     """act(bn(x)) for x (B, C, L) float32 on the GPU; `partial` (B, C, S, 2): per-slice (sum x, sum x^2) when the
-    producer of x already formed them (fp_front)."""
+    producer of x already formed them (fp_front).  `pre_bias` (C,): act(bn(x + pre_bias[:, None])) without the add --
+    the bias of the convolution in front: under batch statistics it cancels in the output (only the running mean sees
+    it, and its gradient is exactly zero), under running statistics it folds into the shift."""
     if not _covered(bn, x):
         from .pointnet2.pytorch_utils import batch_norm_nd
-        y = batch_norm_nd(bn, x)
+        y = batch_norm_nd(bn, x if pre_bias is None else x + pre_bias.view(1, -1, 1))
         return torch.relu(y) if relu else y
     x = x.contiguous()
     b, c, l = x.shape
@@ -90,9 +96,9 @@ def bn_act(bn, x, relu=True, partial=None):
     use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
     if not use_batch:
         with torch.no_grad():
-            mean = bn.running_mean.float()
+            mean = bn.running_mean.float() if pre_bias is None else bn.running_mean.float() - pre_bias.detach().float()
             rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
-        return _BnActFn.apply(x, gamma, beta, mean, rstd, None, None, relu, 0.0, None)
+        return _BnActFn.apply(x, gamma, beta, mean, rstd, None, None, relu, 0.0, None, pre_bias)
     group = _sync_group(bn)
     with torch.no_grad():
         if partial is None:
@@ -122,18 +128,21 @@ def bn_act(bn, x, relu=True, partial=None):
         f32_running = track and bn.running_mean.dtype == torch.float32 and bn.running_var.dtype == torch.float32
         stats = torch.empty((4, c), dtype=torch.float32, device=dev)         # mean, rstd, scale, shift
         g32, b32 = gamma.detach().float().contiguous(), beta.detach().float().contiguous()   # named: raw pointers below
+        p32 = None if pre_bias is None else pre_bias.detach().float().contiguous()
         call("geot_bn_finalize", dev, c, ptr(sums), 0.0 if count_dev is not None else count,
-             ptr(count_dev) if count_dev is not None else None, float(bn.eps), float(eaf), ptr(g32), ptr(b32),
+             ptr(count_dev) if count_dev is not None else None, float(bn.eps), float(eaf), ptr(g32), ptr(b32), ptr(p32),
              ptr(bn.running_mean) if f32_running else None, ptr(bn.running_var) if f32_running else None,
              ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(stats[3]))
         if track and not f32_running:          # buffers in another precision: the O(c) update in torch
             n = count_dev[0] if count_dev is not None else count
             mean64 = sums.view(c, 2)[:, 0] / n
             var64 = (sums.view(c, 2)[:, 1] / n - mean64 * mean64).clamp_min_(0.0)
+            if pre_bias is not None:
+                mean64 = mean64 + pre_bias.detach().double()
             unbiased = var64 * (n / (n - 1.0)) if torch.is_tensor(n) else var64 * (n / max(n - 1.0, 1.0))
             bn.running_mean.mul_(1.0 - eaf).add_(mean64.to(bn.running_mean.dtype), alpha=eaf)
             bn.running_var.mul_(1.0 - eaf).add_(unbiased.to(bn.running_var.dtype), alpha=eaf)
-    return _BnActFn.apply(x, gamma, beta, stats[0], stats[1], stats[2], stats[3], relu, count, group)
+    return _BnActFn.apply(x, gamma, beta, stats[0], stats[1], stats[2], stats[3], relu, count, group, pre_bias)
 
 
 class _FpFrontFn(Function):

@@ -192,21 +192,21 @@ class Encoder(nn.Module):
         bs, g, n, _ = point_groups.shape
         L = bs * g * n
 
-        def conv(m, x, w=None):
+        def conv(m, x, w=None, bias=True):
             w = m.weight.squeeze(-1) if w is None else w
             y = torch.mm(w, x)
-            return y if m.bias is None else y + m.bias.unsqueeze(1)
+            return y if m.bias is None or not bias else y + m.bias.unsqueeze(1)
 
-        def norm_act(seq, x):                                  # BatchNorm1d -> ReLU of a Sequential, on (C, L)
-            return bn_act(seq[1], x.unsqueeze(0), relu=True).squeeze(0)
+        def norm_act(seq, x):        # BatchNorm1d -> ReLU of a Sequential on (C, L); x arrives WITHOUT seq[0]'s bias:
+            return bn_act(seq[1], x.unsqueeze(0), relu=True, pre_bias=seq[0].bias).squeeze(0)   # bn_act accounts for it
 
         x = point_groups.reshape(L, 3).t()                                              # (3, L) view
-        f = conv(self.first_conv[3], norm_act(self.first_conv, conv(self.first_conv[0], x)))      # (256, L)
+        f = conv(self.first_conv[3], norm_act(self.first_conv, conv(self.first_conv[0], x, bias=False)))   # (256, L)
         c1 = f.shape[0]
         pooled = max_last(f.view(c1, bs * g, n))                                        # (256, BG)
         c2 = self.second_conv[0]
         w = c2.weight.squeeze(-1)
-        h = conv(c2, f, w[:, c1:]).view(-1, bs * g, n) + torch.mm(w[:, :c1], pooled).unsqueeze(2)
+        h = conv(c2, f, w[:, c1:], bias=False).view(-1, bs * g, n) + torch.mm(w[:, :c1], pooled).unsqueeze(2)
         h = conv(self.second_conv[3], norm_act(self.second_conv, h.view(-1, L)))                  # (C_enc, L)
         return max_last(h.view(-1, bs * g, n)).t().reshape(bs, g, self.encoder_channel)
 
@@ -422,7 +422,11 @@ class PointTransformer_seg_T(nn.Module):
         f_l0 = self._fp(self.propogation_0, center_original, center_pts[0], f_l0, f_l1)
 
         head = self.seg_head                     # conv -> BatchNorm1d -> Dropout -> conv; the BatchNorm as one fused op
-        logit = head[3](head[2](bn_act(head[1], head[0](f_l0), relu=False)))
+        if self.dense != "reference" and isinstance(head[0], PointwiseConv1d):
+            y = pointwise(head[0].weight.view(head[0].out_channels, -1), f_l0)       # the bias goes through bn_act
+            logit = head[3](head[2](bn_act(head[1], y, relu=False, pre_bias=head[0].bias)))
+        else:
+            logit = head[3](head[2](bn_act(head[1], head[0](f_l0), relu=False)))
         correction = self.T_linear(T) if T is not None else None
         return logit, correction, self.sigma, f_l0
 

@@ -155,12 +155,15 @@ int geot_three_nn_ws(int b, int n, int m, const float *unknown, const float *kno
  *   geot_bn_finalize  n = count_dev ? *count_dev (device double: the all-reduced element count) : count;
  *                     mean = sums0/n, var = max(sums1/n - mean^2, 0) in fp64; mean, rstd = 1/sqrt(var+eps) as fp32;
  *                     scale = gamma*rstd, shift = beta - mean*scale (gamma / beta NULL: 1 / 0); running_mean / _var
- *                     (NULL: not tracked) <- (1-eaf)*old + eaf*(mean | var*n/max(n-1,1))  (torch batch_norm semantics)
+ *                     (NULL: not tracked) <- (1-eaf)*old + eaf*(mean | var*n/max(n-1,1))  (torch batch_norm semantics);
+ *                     pre_bias (NULL: none): the statistics are those of y while the layer normalises y + pre_bias[c]
+ *                     (a convolution bias in front of a batch-statistics BatchNorm cancels in the output: the caller
+ *                     skips the add, only the running mean sees it)
  *   geot_bn_bwd_coef  g_beta, g_gamma = fp32 of local_sums (this rank's sum g, sum g xhat); c1, c2 = sums/n (0 if n == 0) */
 int geot_bn_sums(int b, int c, int s, const float *partial, double *sums, void *stream);
 int geot_bn_finalize(int c, const double *sums, double count, const double *count_dev, double eps, double eaf,
-                     const float *gamma, const float *beta, float *running_mean, float *running_var, float *mean,
-                     float *rstd, float *scale, float *shift, void *stream);
+                     const float *gamma, const float *beta, const float *pre_bias, float *running_mean,
+                     float *running_var, float *mean, float *rstd, float *scale, float *shift, void *stream);
 int geot_bn_bwd_coef(int c, const double *local_sums, const double *sums, double count, const double *count_dev,
                      float *g_gamma, float *g_beta, float *c1, float *c2, void *stream);
 int geot_bn_slices(int b, int c, int l);

@@ -181,6 +181,39 @@ def test_bn_act_equals_torch_batchnorm_relu(b, c, l, relu, training):
     assert int(res[0][6]) == int(res[1][6])
 
 
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_with_the_bias_of_the_layer_in_front(training):
+    """bn_act(bn, y, pre_bias=b) == relu(bn(y + b)) without the add: output, dx, d gamma, d beta, the running
+    statistics (the running mean sees the bias) and d b -- zero under batch statistics (the bias cancels), scale *
+    sum g under running statistics."""
+    from geot_amd.fused_norm import bn_act
+    dev = torch.device("cuda:0")
+    b, c, l = 3, 40, 777
+    g = torch.Generator().manual_seed(3)
+    y0 = (torch.randn(b, c, l, generator=g) * 2 + 0.5).to(dev)
+    bias0 = torch.randn(c, generator=g).to(dev)
+    up = torch.randn(b, c, l, generator=g).to(dev)
+    ref, ours = torch.nn.BatchNorm1d(c).to(dev).double(), torch.nn.BatchNorm1d(c).to(dev)
+    with torch.no_grad():
+        ours.weight.copy_(torch.randn(c, generator=g)); ours.bias.copy_(torch.randn(c, generator=g))
+        ours.running_mean.uniform_(-0.5, 0.5); ours.running_var.uniform_(0.5, 2.0)
+    ref.load_state_dict(ours.state_dict())
+    ref.train(training); ours.train(training)
+    res = []
+    for mod, fused in ((ref, False), (ours, True)):
+        y = (y0.double() if not fused else y0.clone()).requires_grad_(True)
+        bias = (bias0.double() if not fused else bias0.clone()).requires_grad_(True)
+        out = bn_act(mod, y, relu=True, pre_bias=bias) if fused else torch.relu(mod(y + bias.view(1, -1, 1)))
+        (out * up.to(out.dtype)).sum().backward()
+        res.append([t.double() for t in (out.detach(), y.grad, mod.weight.grad, mod.bias.grad, bias.grad, mod.running_mean,
+                                         mod.running_var)])
+    for name, a, f in zip(("out", "dy", "dgamma", "dbeta", "dbias", "running_mean", "running_var"), *res):
+        scale = float(res[0][1].abs().max() * l * b) if name == "dbias" and training else float(a.abs().max()) + 1e-12
+        assert float((a - f).abs().max()) <= 2e-5 * scale + 1e-6, (name, float((a - f).abs().max()), scale)
+    if training:
+        assert float(res[1][4].abs().max()) == 0.0          # exact zero, where torch accumulates rounding noise
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
