@@ -97,6 +97,7 @@ PROTOTYPES.update({
     "geot_bn_bwd_apply": [_c_int] * 4 + [_P] * 10 + [_c_void_p],
     "geot_fp_front": [_c_int] * 5 + [_P] * 7 + [_c_void_p],
     "geot_segment_max": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
+    "geot_segment_sum": [ctypes.c_longlong, _c_int, _P, _P, _c_void_p],
     "geot_segment_max_grad": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_edgeconv_gn_max": [_c_int] * 6 + [_c_float, _c_float] + [_P] * 11 + [ctypes.c_longlong, _c_void_p],
     "geot_edgeconv_gn_max_grad": [_c_int] * 6 + [_c_float] + [_P] * 15 + [ctypes.c_longlong, _c_void_p],

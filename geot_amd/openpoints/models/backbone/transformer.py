@@ -36,7 +36,7 @@ from ....knn_cuda import KNN, knn_sorted
 from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused,  # noqa: F401
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
-from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last
+from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast
 
 
 class DropPath(nn.Module):
@@ -206,7 +206,7 @@ class Encoder(nn.Module):
         pooled = max_last(f.view(c1, bs * g, n))                                        # (256, BG)
         c2 = self.second_conv[0]
         w = c2.weight.squeeze(-1)
-        h = conv(c2, f, w[:, c1:], bias=False).view(-1, bs * g, n) + torch.mm(w[:, :c1], pooled).unsqueeze(2)
+        h = add_last_broadcast(conv(c2, f, w[:, c1:], bias=False).view(-1, bs * g, n), torch.mm(w[:, :c1], pooled))
         h = conv(self.second_conv[3], norm_act(self.second_conv, h.view(-1, L)))                  # (C_enc, L)
         return max_last(h.view(-1, bs * g, n)).t().reshape(bs, g, self.encoder_channel)
 

@@ -179,6 +179,9 @@ int geot_bn_bwd_apply(int b, int c, int l, int relu, const float *x, const float
  * out (rows), arg (rows) uint8 = the first maximum's slot (torch.max semantics); _grad writes dx (rows, n) in full.
  * (Encoder's max over a group's points, transformer.py:127-134; max over nsample of the SA modules.) */
 int geot_segment_max(long long rows, int n, const float *x, float *out, unsigned char *arg, void *stream);
+/* out (rows) = the sum of every row, same shape rules: the gradient of a per-group term broadcast over the group's
+ * points (Encoder, transformer.py:131-132: feature_global expanded over n) at streaming speed, fixed summation order. */
+int geot_segment_sum(long long rows, int n, const float *x, float *out, void *stream);
 int geot_segment_max_grad(long long rows, int n, const float *dy, const unsigned char *arg, float *dx, void *stream);
 int geot_fp_front_slices(int b, int c, int m, int n);
 int geot_fp_front(int b, int c, int m, int n, int cs, const float *A, const int *idx, const float *weight,

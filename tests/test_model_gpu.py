@@ -214,6 +214,23 @@ def test_bn_act_with_the_bias_of_the_layer_in_front(training):
         assert float(res[1][4].abs().max()) == 0.0          # exact zero, where torch accumulates rounding noise
 
 
+def test_add_last_broadcast_gradient_is_the_row_sum():
+    from geot_amd.fused_norm import add_last_broadcast
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    a0, p0 = torch.randn(70, 333, 32, device=dev), torch.randn(70, 333, device=dev)
+    up = torch.randn(70, 333, 32, device=dev)
+    res = []
+    for fused in (False, True):
+        a, p = a0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+        y = add_last_broadcast(a, p) if fused else a + p.unsqueeze(-1)
+        (y * up).sum().backward()
+        res.append((y.detach(), a.grad, p.grad))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    want = up.double().sum(-1)
+    assert float((res[1][2].double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
