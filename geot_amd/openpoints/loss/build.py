@@ -5,6 +5,42 @@ tensors -- callers of the hot path, mirrored only so that the step of BASELINE c
 constructor arguments and forward signatures, same arithmetic."""
 import torch
 import torch.nn.functional as F
+from torch.autograd import Function
+
+
+class _Poly1FocalFn(Function):
+    """csrc/loss.hip: the loss from integer labels in two launches, its gradient in one."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, keep, alpha, gamma, epsilon):
+        from ... import _lib
+        from ...ext._common import call, ptr
+        b, c, n = logits.shape
+        ws = torch.empty(int(_lib.load().geot_poly1_focal_ws_doubles(b, c, n)), dtype=torch.float64, device=logits.device)
+        out2 = torch.empty(2, dtype=torch.float32, device=logits.device)
+        call("geot_poly1_focal", logits.device, b, c, n, float(alpha), float(gamma), float(epsilon), ptr(logits), ptr(labels),
+             ptr(keep), ptr(ws), ptr(out2))
+        ctx.save_for_backward(logits, labels, keep, out2)
+        ctx.cfg = (float(alpha), float(gamma), float(epsilon))
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from ...ext._common import call, ptr
+        logits, labels, keep, out2 = ctx.saved_tensors
+        b, c, n = logits.shape
+        up = g.reshape(1).float().contiguous()
+        grad = torch.empty_like(logits)
+        call("geot_poly1_focal_grad", logits.device, b, c, n, *ctx.cfg, ptr(logits), ptr(labels), ptr(keep), ptr(out2), ptr(up),
+             ptr(grad))
+        return grad, None, None, None, None, None
+
+
+def _fused_ok(mod, logits, labels, reduction_ok):
+    return (reduction_ok and not mod.label_is_onehot and mod.weight is None and mod.pos_weight is None and logits.is_cuda
+            and logits.dtype == torch.float32 and logits.dim() == 3 and labels.dim() == 2 and labels.dtype == torch.int64
+            and tuple(labels.shape) == (logits.shape[0], logits.shape[2]) and logits.numel() > 0
+            and logits.shape[0] <= 65535 and logits.shape[1] <= 65535)
 
 
 def _one_hot_like(logits, labels):
@@ -34,6 +70,8 @@ class Poly1FocalLoss(torch.nn.Module):
         self.weight, self.pos_weight, self.label_is_onehot = weight, pos_weight, label_is_onehot
 
     def forward(self, logits, labels):
+        if _fused_ok(self, logits, labels, self.reduction == "mean"):
+            return _Poly1FocalFn.apply(logits.contiguous(), labels.contiguous(), None, self.alpha, self.gamma, self.epsilon)
         if not self.label_is_onehot:
             labels = _one_hot_like(logits, labels)
         poly1 = _poly1(logits, labels.to(logits.dtype), self.weight, self.pos_weight, self.alpha, self.gamma, self.epsilon)
@@ -44,6 +82,10 @@ class Poly1FocalLoss(torch.nn.Module):
 
 class Poly1FocalLoss_U_corr(Poly1FocalLoss):
     def forward(self, logits, labels, logits_pred, thresh=0.95, mask=None):
+        if _fused_ok(self, logits, labels, True):
+            keep = (mask if mask is not None else logits_pred.ge(thresh)).to(torch.uint8).contiguous()
+            if tuple(keep.shape) == tuple(labels.shape):
+                return _Poly1FocalFn.apply(logits.contiguous(), labels.contiguous(), keep, self.alpha, self.gamma, self.epsilon)
         if not self.label_is_onehot:
             labels = _one_hot_like(logits, labels)
         poly1 = _poly1(logits, labels.to(logits.dtype), self.weight, self.pos_weight, self.alpha, self.gamma, self.epsilon)

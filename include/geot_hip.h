@@ -175,6 +175,18 @@ int geot_bn_bwd_reduce(int b, int c, int l, int relu, const float *x, const floa
 int geot_bn_bwd_apply(int b, int c, int l, int relu, const float *x, const float *dz, const float *scale,
                       const float *shift, const float *mean, const float *rstd, const float *k0, const float *c1,
                       const float *c2, float *dx, void *stream);
+/* Poly-1 focal loss (openpoints/loss/build.py:183-258 Poly1FocalLoss; :799-892 Poly1FocalLoss_U_corr when `keep` is
+ * given) on logits (b, c, n) with int64 class labels (b, n) -- no one-hot tensors, two launches forward, one backward:
+ *   l = at * BCEwithlogits(x, y) * (1 - pt)^gamma + epsilon * (1 - pt)^(gamma + 1),  y = [label == c], pt = y p + (1-y)(1-p),
+ *   at = alpha y + (1 - alpha)(1 - y) (alpha < 0: 1);  out2[0] = sum l / (b c n), or with keep (b, n) bytes:
+ *   sum l keep / (c sum keep + 0.001);  out2[1] = 1 / that denominator (for _grad).  workspace: _ws_doubles doubles.
+ *   _grad: grad_logits = upstream[0] * out2[1] * keep * dl/dx  (upstream: device scalar). */
+long long geot_poly1_focal_ws_doubles(int b, int c, int n);
+int geot_poly1_focal(int b, int c, int n, float alpha, float gamma, float epsilon, const float *logits,
+                     const long long *labels, const unsigned char *keep, double *workspace, float *out2, void *stream);
+int geot_poly1_focal_grad(int b, int c, int n, float alpha, float gamma, float epsilon, const float *logits,
+                          const long long *labels, const unsigned char *keep, const float *out2, const float *upstream,
+                          float *grad_logits, void *stream);
 /* max over the n innermost elements of every row, x (rows, n) contiguous and 16-byte aligned, n a multiple of 4, <= 256:
  * out (rows), arg (rows) uint8 = the first maximum's slot (torch.max semantics); _grad writes dx (rows, n) in full.
  * (Encoder's max over a group's points, transformer.py:127-134; max over nsample of the SA modules.) */

@@ -231,6 +231,32 @@ def test_add_last_broadcast_gradient_is_the_row_sum():
     assert float((res[1][2].double() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("alpha,gamma", [(0.25, 2.0), (-1.0, 1.5), (0.6, 1.0)])
+def test_fused_poly1_focal_losses_equal_the_torch_composition(alpha, gamma):
+    """csrc/loss.hip (integer labels, no one-hot tensors) vs the reference's op chain in fp64: Poly1FocalLoss and the
+    confidence-masked Poly1FocalLoss_U_corr, values and gradients; extreme logits included."""
+    from geot_amd.openpoints.loss import Poly1FocalLoss, Poly1FocalLoss_U_corr
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    b, c, n = 3, 17, 1111
+    logits0 = torch.randn(b, c, n, generator=g) * 4
+    logits0[0, :, :5] = torch.tensor([-60.0, 60.0, 0.0, 30.0, -30.0])
+    labels = torch.randint(0, c, (b, n), generator=g)
+    conf = torch.rand(b, n, generator=g)
+    for cls, extra in ((Poly1FocalLoss, ()), (Poly1FocalLoss_U_corr, (conf, 0.4))):
+        crit = cls(alpha=alpha, gamma=gamma, epsilon=1.0)
+        res = []
+        for device, dt in ((torch.device("cpu"), torch.float64), (dev, torch.float32)):       # CPU: the torch composition
+            x = logits0.to(device=device, dtype=dt).requires_grad_(True)
+            args = [a.to(device) if torch.is_tensor(a) else a for a in extra]
+            loss = crit(x, labels.to(device), *args)
+            (loss * 3.0).backward()
+            res.append((loss.detach().double().cpu(), x.grad.double().cpu()))
+        assert abs(float(res[0][0] - res[1][0])) <= 2e-6 * abs(float(res[0][0])) + 1e-9
+        scale = float(res[0][1].abs().max())
+        assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * scale
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
