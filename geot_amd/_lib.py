@@ -100,6 +100,7 @@ PROTOTYPES.update({
     "geot_fp_front": [_c_int] * 5 + [_P] * 7 + [_c_void_p],
     "geot_segment_max": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_segment_sum": [ctypes.c_longlong, _c_int, _P, _P, _c_void_p],
+    "geot_rowdot_small": [_c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
     "geot_segment_max_grad": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_edgeconv_gn_max": [_c_int] * 6 + [_c_float, _c_float] + [_P] * 11 + [ctypes.c_longlong, _c_void_p],
     "geot_edgeconv_gn_max_grad": [_c_int] * 6 + [_c_float] + [_P] * 15 + [ctypes.c_longlong, _c_void_p],
@@ -123,6 +124,7 @@ PLAIN = {
     "geot_fp_front_slices": ([_c_int] * 4, _c_int),
     "geot_edgeconv_ws_bytes": ([_c_int] * 5, ctypes.c_longlong),
     "geot_poly1_focal_ws_doubles": ([_c_int] * 3, ctypes.c_longlong),
+    "geot_rowdot_small_slices": ([_c_int] * 2, _c_int),
 }
 ABI_VERSION = 3     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
 

@@ -322,6 +322,37 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(long long rows, int n,
     for (int d = 1; d < LPR; d <<= 1) s += __shfl_xor(s, d);
     if (sub == 0) out[row] = s;
 }
+// partial[(row * S + slice) * J + j] = sum over the slice of a[row][l] * b[j][l], J <= 8 rows of b: the weight gradient of
+// a 1x1 convolution with a handful of input channels (the Encoder's Conv1d(3, 128) over 131 072 columns is a
+// 128 x 3 x 131072 GEMM to the libraries: 436 us; this streams the 67 MB once)
+template <int J>
+__global__ __launch_bounds__(256) void rowdot_small_kernel(int l, const float *__restrict__ a, const float *__restrict__ b,
+                                                           float *__restrict__ partial)
+{
+    const int row = blockIdx.y, per = (((l + gridDim.x - 1) / gridDim.x) + 3) & ~3;
+    const int e0 = blockIdx.x * per, e1 = min(l, e0 + per);
+    const float *ar = a + (size_t)row * l;
+    float acc[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[j] = 0.f;
+    for (int e = e0 + threadIdx.x; e < e1; e += 256) {
+        const float v = ar[e];
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[j] = fmaf(v, b[(size_t)j * l + e], acc[j]);
+    }
+    __shared__ float sh[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        float v = acc[j];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) sh[j][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < J)
+        partial[((size_t)row * gridDim.x + blockIdx.x) * J + threadIdx.x] =
+            (sh[threadIdx.x][0] + sh[threadIdx.x][1]) + (sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+}
 // dx (rows, n) = dy[row] at the arg-max slot, 0 elsewhere (written in full)
 __global__ __launch_bounds__(256) void segment_max_grad_kernel(long long total4, int n4, const float *__restrict__ dy,
                                                                const uint8_t *__restrict__ arg, float *__restrict__ dx)
@@ -544,6 +575,34 @@ GEOT_EXPORT int geot_segment_max(long long rows, int n, const float *x, float *o
     else if (lpr == 4) hipLaunchKernelGGL(segment_max_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out, arg);
     else if (lpr == 2) hipLaunchKernelGGL(segment_max_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out, arg);
     else hipLaunchKernelGGL(segment_max_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out, arg);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_rowdot_small_slices(int rows, int l)
+{
+    if (rows < 1 || l < 1) return -1;
+    long long s = (1024 + rows - 1) / rows;                  // >= 1024 workgroups, slices of >= 2048 elements
+    const long long most = (l + 2047) / 2048;
+    s = s > most ? most : s;
+    return (int)(s < 1 ? 1 : (s > 64 ? 64 : s));
+}
+
+GEOT_EXPORT int geot_rowdot_small(int rows, int l, int j, const float *a, const float *b, float *partial, void *stream)
+{
+    if (rows < 1 || rows > 65535 || l < 1 || j < 1 || j > 8 || !a || !b || !partial) return hipErrorInvalidValue;
+    const dim3 grid(geot_rowdot_small_slices(rows, l), rows);
+#define GEOT_RD(JV) hipLaunchKernelGGL(rowdot_small_kernel<JV>, grid, dim3(256), 0, (hipStream_t)stream, l, a, b, partial)
+    switch (j) {
+    case 1: GEOT_RD(1); break;
+    case 2: GEOT_RD(2); break;
+    case 3: GEOT_RD(3); break;
+    case 4: GEOT_RD(4); break;
+    case 5: GEOT_RD(5); break;
+    case 6: GEOT_RD(6); break;
+    case 7: GEOT_RD(7); break;
+    default: GEOT_RD(8); break;
+    }
+#undef GEOT_RD
     return hipGetLastError();
 }
 

@@ -243,3 +243,37 @@ def add_last_broadcast(a, p):
             and tuple(p.shape) == tuple(a.shape[:-1]) and a.numel() > 0):
         return a + p.unsqueeze(-1)
     return _AddLastBroadcastFn.apply(a, p)
+
+
+class _ThinMmFn(Function):
+    """w (C, J) @ x (J, L) for J <= 8: the forward is a fine library GEMM, its weight gradient (C x J x L with L ~ 1e5) is
+    not -- one streaming pass of geot_rowdot_small instead."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        ctx.save_for_backward(w, x)
+        return torch.mm(w, x)
+
+    @staticmethod
+    def backward(ctx, g):
+        w, x = ctx.saved_tensors
+        gw = gx = None
+        if ctx.needs_input_grad[0]:
+            g = g.contiguous()
+            c, l = g.shape
+            j = x.shape[0]
+            s = int(_lib.load().geot_rowdot_small_slices(c, l))
+            partial = torch.empty((c, s, j), dtype=torch.float32, device=g.device)
+            call("geot_rowdot_small", g.device, c, l, j, ptr(g), ptr(x), ptr(partial))
+            gw = partial.sum(1)
+        if ctx.needs_input_grad[1]:
+            gx = torch.mm(w.t(), g)
+        return gw, gx
+
+
+def thin_mm(w, x):
+    """torch.mm(w, x) for w (C, J), x (J, L) contiguous float32 on the GPU with J <= 8 and C <= 65535."""
+    if not (w.is_cuda and w.dtype == torch.float32 and x.dtype == torch.float32 and w.dim() == 2 and x.dim() == 2
+            and 1 <= x.shape[0] <= 8 and w.shape[0] <= 65535 and x.numel() > 0):
+        return torch.mm(w, x)
+    return _ThinMmFn.apply(w, x.contiguous())

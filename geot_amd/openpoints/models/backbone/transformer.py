@@ -36,7 +36,7 @@ from ....knn_cuda import KNN, knn_sorted
 from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused,  # noqa: F401
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
-from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast
+from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
 
 
 class DropPath(nn.Module):
@@ -194,7 +194,7 @@ class Encoder(nn.Module):
 
         def conv(m, x, w=None, bias=True):
             w = m.weight.squeeze(-1) if w is None else w
-            y = torch.mm(w, x)
+            y = thin_mm(w, x) if x.shape[0] <= 8 else torch.mm(w, x)
             return y if m.bias is None or not bias else y + m.bias.unsqueeze(1)
 
         def norm_act(seq, x):        # BatchNorm1d -> ReLU of a Sequential on (C, L); x arrives WITHOUT seq[0]'s bias:

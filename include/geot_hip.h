@@ -194,6 +194,11 @@ int geot_segment_max(long long rows, int n, const float *x, float *out, unsigned
 /* out (rows) = the sum of every row, same shape rules: the gradient of a per-group term broadcast over the group's
  * points (Encoder, transformer.py:131-132: feature_global expanded over n) at streaming speed, fixed summation order. */
 int geot_segment_sum(long long rows, int n, const float *x, float *out, void *stream);
+/* partial (rows, S, j) = per-slice sums of a[row][.] * b[jj][.] for a (rows, l), b (j, l), j <= 8, S =
+ * geot_rowdot_small_slices(rows, l): the weight gradient of a 1x1 convolution with a handful of input channels
+ * (Encoder first_conv, transformer.py:110: Conv1d(3, 128) over all points of all groups), one streaming pass. */
+int geot_rowdot_small_slices(int rows, int l);
+int geot_rowdot_small(int rows, int l, int j, const float *a, const float *b, float *partial, void *stream);
 int geot_segment_max_grad(long long rows, int n, const float *dy, const unsigned char *arg, float *dx, void *stream);
 int geot_fp_front_slices(int b, int c, int m, int n);
 int geot_fp_front(int b, int c, int m, int n, int cs, const float *A, const int *idx, const float *weight,

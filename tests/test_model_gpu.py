@@ -257,6 +257,20 @@ def test_fused_poly1_focal_losses_equal_the_torch_composition(alpha, gamma):
         assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * scale
 
 
+def test_thin_mm_weight_gradient():
+    from geot_amd.fused_norm import thin_mm
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    for c, j, l in ((128, 3, 131072), (37, 8, 5001), (5, 1, 7)):
+        w0, x0, up = torch.randn(c, j, device=dev), torch.randn(j, l, device=dev), torch.randn(c, l, device=dev)
+        w = w0.clone().requires_grad_(True)
+        y = thin_mm(w, x0)
+        (y * up).sum().backward()
+        assert torch.equal(y.detach(), torch.mm(w0, x0))
+        want = up.double() @ x0.double().t()
+        assert float((w.grad.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
