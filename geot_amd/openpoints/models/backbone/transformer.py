@@ -197,18 +197,32 @@ class Encoder(nn.Module):
             y = thin_mm(w, x) if x.shape[0] <= 8 else torch.mm(w, x)
             return y if m.bias is None or not bias else y + m.bias.unsqueeze(1)
 
-        def norm_act(seq, x):        # BatchNorm1d -> ReLU of a Sequential on (C, L); x arrives WITHOUT seq[0]'s bias:
-            return bn_act(seq[1], x.unsqueeze(0), relu=True, pre_bias=seq[0].bias).squeeze(0)   # bn_act accounts for it
+        def norm_act(seq, x, pre_bias):   # BatchNorm1d -> ReLU of a Sequential on (C, L); x arrives WITHOUT pre_bias,
+            return bn_act(seq[1], x.unsqueeze(0), relu=True, pre_bias=pre_bias).squeeze(0)     # bn_act accounts for it
 
+        # No bias is ever added to an (C, L) tensor: a per-channel constant commutes with the max over a group's points
+        # (exactly: rounding is monotone), passes through the next convolution as the constant W b, and in front of a
+        # BatchNorm goes through bn_act's pre_bias (cancels under batch statistics).  f0, h0 = the tensors without it.
         x = point_groups.reshape(L, 3).t()                                              # (3, L) view
-        f = conv(self.first_conv[3], norm_act(self.first_conv, conv(self.first_conv[0], x, bias=False)))   # (256, L)
-        c1 = f.shape[0]
-        pooled = max_last(f.view(c1, bs * g, n))                                        # (256, BG)
+        b1, b2 = self.first_conv[3].bias, self.second_conv[3].bias
+        f0 = conv(self.first_conv[3], norm_act(self.first_conv, conv(self.first_conv[0], x, bias=False),
+                                               self.first_conv[0].bias), bias=False)    # f = f0 + b1: (256, L)
+        c1 = f0.shape[0]
+        pooled = max_last(f0.view(c1, bs * g, n))                                       # (256, BG), + b1 below
+        if b1 is not None:
+            pooled = pooled + b1.unsqueeze(1)
         c2 = self.second_conv[0]
         w = c2.weight.squeeze(-1)
-        h = add_last_broadcast(conv(c2, f, w[:, c1:], bias=False).view(-1, bs * g, n), torch.mm(w[:, :c1], pooled))
-        h = conv(self.second_conv[3], norm_act(self.second_conv, h.view(-1, L)))                  # (C_enc, L)
-        return max_last(h.view(-1, bs * g, n)).t().reshape(bs, g, self.encoder_channel)
+        pre = c2.bias
+        if b1 is not None:                                     # W_f (f0 + b1) = W_f f0 + W_f b1
+            wb = torch.mv(w[:, c1:], b1)
+            pre = wb if pre is None else pre + wb
+        h = add_last_broadcast(conv(c2, f0, w[:, c1:], bias=False).view(-1, bs * g, n), torch.mm(w[:, :c1], pooled))
+        h0 = conv(self.second_conv[3], norm_act(self.second_conv, h.view(-1, L), pre), bias=False)  # (C_enc, L)
+        out = max_last(h0.view(-1, bs * g, n))
+        if b2 is not None:
+            out = out + b2.unsqueeze(1)
+        return out.t().reshape(bs, g, self.encoder_channel)
 
     def forward(self, point_groups):
         if self.factored:
