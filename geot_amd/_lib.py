@@ -101,6 +101,7 @@ PROTOTYPES.update({
     "geot_segment_max": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_segment_sum": [ctypes.c_longlong, _c_int, _P, _P, _c_void_p],
     "geot_rowdot_small": [_c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
+    "geot_colsum": [_c_int, _c_int, _P, _P, _P, _c_void_p],
     "geot_segment_max_grad": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_edgeconv_gn_max": [_c_int] * 6 + [_c_float, _c_float] + [_P] * 11 + [ctypes.c_longlong, _c_void_p],
     "geot_edgeconv_gn_max_grad": [_c_int] * 6 + [_c_float] + [_P] * 15 + [ctypes.c_longlong, _c_void_p],
@@ -125,6 +126,7 @@ PLAIN = {
     "geot_edgeconv_ws_bytes": ([_c_int] * 5, ctypes.c_longlong),
     "geot_poly1_focal_ws_doubles": ([_c_int] * 3, ctypes.c_longlong),
     "geot_rowdot_small_slices": ([_c_int] * 2, _c_int),
+    "geot_colsum_ws_floats": ([_c_int] * 2, ctypes.c_longlong),
 }
 ABI_VERSION = 3     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
 

@@ -277,3 +277,38 @@ def thin_mm(w, x):
             and 1 <= x.shape[0] <= 8 and w.shape[0] <= 65535 and x.numel() > 0):
         return torch.mm(w, x)
     return _ThinMmFn.apply(w, x.contiguous())
+
+
+class _LinearFn(Function):
+    """F.linear(x, w, b) with the same three GEMMs as torch's own backward; the bias gradient (column sums of the
+    output gradient) from geot_colsum: 2 launches of ~4 us instead of a 5 us fill + a 19 us generic reduction."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.mm(g2, w).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            gw = torch.mm(g2.t(), x2)
+        if ctx.needs_input_grad[2]:
+            g2 = g2.contiguous()
+            rows, cols = g2.shape
+            gb = torch.empty(cols, dtype=torch.float32, device=g.device)
+            ws = torch.empty(int(_lib.load().geot_colsum_ws_floats(rows, cols)), dtype=torch.float32, device=g.device)
+            call("geot_colsum", g.device, rows, cols, ptr(g2), ptr(gb), ptr(ws))
+        return gx, gw, gb
+
+
+def linear(mod, x):
+    """mod(x) for an nn.Linear with bias on a float32 GPU tensor (anything else: the module itself)."""
+    if mod.bias is None or not (x.is_cuda and x.dtype == torch.float32 and mod.weight.dtype == torch.float32 and x.numel() > 0):
+        return mod(x)
+    return _LinearFn.apply(x, mod.weight, mod.bias)

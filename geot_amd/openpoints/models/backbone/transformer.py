@@ -37,6 +37,7 @@ from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_gra
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
 from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
+from ....fused_norm import linear as lean_linear
 
 
 class DropPath(nn.Module):
@@ -72,9 +73,12 @@ class Mlp(nn.Module):
         self.fc1 = nn.Linear(in_features, hidden_features)
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features, out_features)
+        self.lean = False            # set by PointTransformer_seg_T when dense != "reference"
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
+        if self.lean:
+            return self.drop(lean_linear(self.fc2, self.drop(self.act(lean_linear(self.fc1, x)))))
         return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
 
 
@@ -103,7 +107,7 @@ class Attention(nn.Module):
             q, k, v = self.qkv(x).view(B, N, 3, H, d).permute(2, 0, 3, 1, 4).contiguous().view(3, B * H, N, d).unbind(0)
             attn = torch.baddbmm(q.new_empty(()), q, k.transpose(1, 2), beta=0.0, alpha=self.scale).softmax(dim=-1)
             x = torch.bmm(attn, v).view(B, H, N, d).transpose(1, 2).reshape(B, N, C)
-            return self.proj_drop(self.proj(x))
+            return self.proj_drop(lean_linear(self.proj, x))
         qkv = self.qkv(x).reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
         if self.fused and x.is_cuda and (self.attn_drop.p == 0.0 or not self.training):
@@ -352,7 +356,7 @@ class PointTransformer_seg_T(nn.Module):
                                            extract_layers=self.extract_layers)
         self.norm = nn.LayerNorm(self.trans_dim)
         for blk in self.blocks.blocks:
-            blk.attn.lean = self.dense != "reference"
+            blk.attn.lean = blk.mlp.lean = self.dense != "reference"
 
         self.propogation_2 = PointnetFPModule([self.trans_dim + 3, self.trans_dim * 4, self.trans_dim])
         self.propogation_1 = PointnetFPModule([self.trans_dim + 3, self.trans_dim * 4, self.trans_dim])

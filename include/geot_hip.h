@@ -197,6 +197,10 @@ int geot_segment_sum(long long rows, int n, const float *x, float *out, void *st
 /* partial (rows, S, j) = per-slice sums of a[row][.] * b[jj][.] for a (rows, l), b (j, l), j <= 8, S =
  * geot_rowdot_small_slices(rows, l): the weight gradient of a 1x1 convolution with a handful of input channels
  * (Encoder first_conv, transformer.py:110: Conv1d(3, 128) over all points of all groups), one streaming pass. */
+/* out (cols) = column sums of the row-major x (rows, cols): the bias gradient of a Linear layer (fixed summation order;
+ * workspace: geot_colsum_ws_floats floats). */
+long long geot_colsum_ws_floats(int rows, int cols);
+int geot_colsum(int rows, int cols, const float *x, float *out, float *workspace, void *stream);
 int geot_rowdot_small_slices(int rows, int l);
 int geot_rowdot_small(int rows, int l, int j, const float *a, const float *b, float *partial, void *stream);
 int geot_segment_max_grad(long long rows, int n, const float *dy, const unsigned char *arg, float *dx, void *stream);

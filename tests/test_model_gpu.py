@@ -271,6 +271,25 @@ def test_thin_mm_weight_gradient():
         assert float((w.grad.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+def test_lean_linear_equals_nn_linear():
+    from geot_amd.fused_norm import linear
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    for shape, cout in (((8, 512, 384), 1536), ((3, 7, 50), 33), ((4096, 1536), 384)):
+        lin = torch.nn.Linear(shape[-1], cout).to(dev)
+        x0, up = torch.randn(*shape, device=dev), torch.randn(*shape[:-1], cout, device=dev)
+        res = []
+        for fused in (False, True):
+            lin.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = linear(lin, x) if fused else lin(x)
+            (y * up).sum().backward()
+            res.append((y.detach(), x.grad, lin.weight.grad.clone(), lin.bias.grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+        want = up.double().reshape(-1, cout).sum(0)
+        assert float((res[1][3].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
