@@ -88,6 +88,8 @@ PROTOTYPES.update({
                                    _c_void_p],
 })
 PROTOTYPES.update({
+    "geot_res_ln": [_c_int] * 3 + [_c_float] + [_P] * 10 + [_c_void_p],
+    "geot_res_ln_grad": [_c_int] * 3 + [_P] * 12 + [_c_void_p],
     "geot_poly1_focal": [_c_int] * 3 + [_c_float] * 3 + [_P] * 5 + [_c_void_p],
     "geot_poly1_focal_grad": [_c_int] * 3 + [_c_float] * 3 + [_P] * 6 + [_c_void_p],
     "geot_bn_sums": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
@@ -125,6 +127,8 @@ PLAIN = {
     "geot_fp_front_slices": ([_c_int] * 4, _c_int),
     "geot_edgeconv_ws_bytes": ([_c_int] * 5, ctypes.c_longlong),
     "geot_poly1_focal_ws_doubles": ([_c_int] * 3, ctypes.c_longlong),
+    "geot_res_ln_supported": ([_c_int], _c_int),
+    "geot_res_ln_ws_floats": ([_c_int] * 2, ctypes.c_longlong),
     "geot_rowdot_small_slices": ([_c_int] * 2, _c_int),
     "geot_colsum_ws_floats": ([_c_int] * 2, ctypes.c_longlong),
 }

@@ -1,0 +1,179 @@
+// Residual add + LayerNorm as one pass each way, for the transformer blocks' 512-token rows (transformer.py:41-104):
+//   t = x + s[sample] * y + extra        (y, s, extra optional: drop-path scaled branch, position embedding)
+//   z = LayerNorm(t) = (t - mean) * rstd * gamma + beta
+// forward writes t and z (one launch instead of add / addcmul + layer_norm); backward takes the gradients of both and
+// returns  g = g_t + LayerNorm'(g_z)  (the gradient of x and of extra), s * g (of y) and the per-block partial sums of
+// d gamma / d beta (one launch + a finish instead of three LayerNorm kernels, a gradient add and a mask multiply).
+// One wave per row, lane l holds columns l + 64 e; C = 64 * EPL.
+#include "geot_common.h"
+#include "geot_hip.h"
+
+namespace geot {
+
+constexpr int LN_ROWS_PER_WAVE = 4; // backward: rows a wave walks, so that d gamma / d beta leave as rows/16 partial rows
+
+__device__ __forceinline__ float ln_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void res_ln_fwd_kernel(int rows, int rows_per_sample, float eps, const float *__restrict__ x,
+                                                         const float *__restrict__ y, const float *__restrict__ s,
+                                                         const float *__restrict__ extra, const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float *__restrict__ t_out,
+                                                         float *__restrict__ z_out, float *__restrict__ mean_out,
+                                                         float *__restrict__ rstd_out)
+{
+    constexpr int C = 64 * EPL;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t base = (size_t)row * C + lane;
+    const float sc = s ? s[row / rows_per_sample] : 1.f;
+    float t[EPL], sum = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        float v = x[base + 64 * e];
+        if (y) v = v + sc * y[base + 64 * e];
+        if (extra) v = v + extra[base + 64 * e];
+        t[e] = v;
+        sum += v;
+    }
+    const float mean = ln_wave_sum(sum) * (1.f / C);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) sq = fmaf(t[e] - mean, t[e] - mean, sq);
+    const float rstd = 1.f / sqrtf(ln_wave_sum(sq) * (1.f / C) + eps);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        if (t_out) t_out[base + 64 * e] = t[e];
+        z_out[base + 64 * e] = (t[e] - mean) * rstd * gamma[lane + 64 * e] + beta[lane + 64 * e];
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void res_ln_bwd_kernel(int rows, int rows_per_sample, const float *__restrict__ gz,
+                                                         const float *__restrict__ gt, const float *__restrict__ t,
+                                                         const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                         const float *__restrict__ gamma, const float *__restrict__ s,
+                                                         float *__restrict__ g_out, float *__restrict__ gy_out,
+                                                         float *__restrict__ partial)
+{
+    constexpr int C = 64 * EPL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gam[EPL], ag[EPL], ab[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { gam[e] = gamma[lane + 64 * e]; ag[e] = 0.f; ab[e] = 0.f; }
+    const int row0 = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
+    for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        const size_t base = (size_t)row * C + lane;
+        const float mu = mean[row], rs = rstd[row];
+        float a[EPL], xh[EPL], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const float g = gz ? gz[base + 64 * e] : 0.f;
+            xh[e] = (t[base + 64 * e] - mu) * rs;
+            a[e] = g * gam[e];
+            s1 += a[e];
+            s2 = fmaf(a[e], xh[e], s2);
+            ag[e] = fmaf(g, xh[e], ag[e]);
+            ab[e] += g;
+        }
+        const float c1 = ln_wave_sum(s1) * (1.f / C), c2 = ln_wave_sum(s2) * (1.f / C);
+        const float sc = s ? s[row / rows_per_sample] : 1.f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            float d = rs * (a[e] - c1 - xh[e] * c2);
+            if (gt) d = d + gt[base + 64 * e];
+            g_out[base + 64 * e] = d;
+            if (gy_out) gy_out[base + 64 * e] = sc * d;
+        }
+    }
+    __shared__ float sh[2][4][C];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) { sh[0][wave][lane + 64 * e] = ag[e]; sh[1][wave][lane + 64 * e] = ab[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int w = i / C, col = i - w * C;
+        partial[((size_t)blockIdx.x * 2 + w) * C + col] = (sh[w][0][col] + sh[w][1][col]) + (sh[w][2][col] + sh[w][3][col]);
+    }
+}
+
+// d gamma[col] = sum over blocks of partial[blk][0][col], d beta likewise: grid (C / 64), the 4 waves take every 4th block
+__global__ __launch_bounds__(256) void res_ln_finish_kernel(int nblk, int c, const float *__restrict__ partial,
+                                                            float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
+    float a = 0.f, b = 0.f;
+    if (col < c) {
+#pragma unroll 8
+        for (int blk = wave; blk < nblk; blk += 4) {
+            a += partial[((size_t)blk * 2) * c + col];
+            b += partial[((size_t)blk * 2 + 1) * c + col];
+        }
+    }
+    __shared__ float sh[2][4][64];
+    sh[0][wave][lane] = a;
+    sh[1][wave][lane] = b;
+    __syncthreads();
+    if (wave == 0 && col < c) {
+        dgamma[col] = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
+        dbeta[col] = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
+    }
+}
+
+static inline bool ln_c_ok(int c) { return c == 128 || c == 256 || c == 384 || c == 512 || c == 768 || c == 1024; }
+static inline int ln_bwd_blocks(int rows) { return (rows + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE); }
+
+} // namespace geot
+
+using namespace geot;
+
+GEOT_EXPORT int geot_res_ln_supported(int c) { return ln_c_ok(c) ? 1 : 0; }
+
+GEOT_EXPORT long long geot_res_ln_ws_floats(int rows, int c)
+{
+    if (rows < 1 || !ln_c_ok(c)) return -1;
+    return 2LL * ln_bwd_blocks(rows) * c;
+}
+
+#define GEOT_LN_DISPATCH(KERNEL, GRID, ...)                                                                     \
+    switch (c / 64) {                                                                                           \
+    case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;         \
+    case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;         \
+    case 6: hipLaunchKernelGGL(KERNEL<6>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;         \
+    case 8: hipLaunchKernelGGL(KERNEL<8>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;         \
+    case 12: hipLaunchKernelGGL(KERNEL<12>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;       \
+    default: hipLaunchKernelGGL(KERNEL<16>, GRID, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break;       \
+    }
+
+GEOT_EXPORT int geot_res_ln(int rows, int c, int rows_per_sample, float eps, const float *x, const float *y, const float *s,
+                            const float *extra, const float *gamma, const float *beta, float *t_out, float *z_out,
+                            float *mean, float *rstd, void *stream)
+{
+    if (rows < 1 || !ln_c_ok(c) || rows_per_sample < 1 || !x || !gamma || !beta || !z_out || !mean || !rstd || (s && !y))
+        return hipErrorInvalidValue;
+    GEOT_LN_DISPATCH(res_ln_fwd_kernel, dim3((rows + 3) / 4), rows, rows_per_sample, eps, x, y, s, extra, gamma, beta, t_out,
+                     z_out, mean, rstd)
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_res_ln_grad(int rows, int c, int rows_per_sample, const float *gz, const float *gt, const float *t,
+                                 const float *mean, const float *rstd, const float *gamma, const float *s, float *g_out,
+                                 float *gy_out, float *dgamma, float *dbeta, float *workspace, void *stream)
+{
+    if (rows < 1 || !ln_c_ok(c) || rows_per_sample < 1 || !t || !mean || !rstd || !gamma || !g_out || !dgamma || !dbeta ||
+        !workspace)
+        return hipErrorInvalidValue;
+    const int nblk = ln_bwd_blocks(rows);
+    GEOT_LN_DISPATCH(res_ln_bwd_kernel, dim3(nblk), rows, rows_per_sample, gz, gt, t, mean, rstd, gamma, s, g_out, gy_out,
+                     workspace)
+    hipLaunchKernelGGL(res_ln_finish_kernel, dim3((c + 63) / 64), dim3(256), 0, (hipStream_t)stream, nblk, c, workspace, dgamma,
+                       dbeta);
+    return hipGetLastError();
+}

@@ -312,3 +312,89 @@ def linear(mod, x):
     if mod.bias is None or not (x.is_cuda and x.dtype == torch.float32 and mod.weight.dtype == torch.float32 and x.numel() > 0):
         return mod(x)
     return _LinearFn.apply(x, mod.weight, mod.bias)
+
+
+def _res_ln_forward(x, y, s, extra, gamma, beta, eps, want_t):
+    c = x.shape[-1]
+    rows = x.numel() // c
+    rps = max(rows // x.shape[0], 1)
+    t = torch.empty_like(x) if want_t else None
+    z = torch.empty_like(x)
+    stats = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+    call("geot_res_ln", x.device, rows, c, rps, float(eps), ptr(x), ptr(y), ptr(s), ptr(extra), ptr(gamma), ptr(beta),
+         ptr(t), ptr(z), ptr(stats[0]), ptr(stats[1]))
+    return t, z, stats, (rows, c, rps)
+
+
+def _res_ln_backward(t, stats, gamma, s, dims, gt, gz, want_gy):
+    rows, c, rps = dims
+    dev = t.device
+    gt = None if gt is None else gt.contiguous()
+    gz = None if gz is None else gz.contiguous()
+    g = torch.empty_like(t)
+    gy = torch.empty_like(t) if want_gy else None
+    dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+    ws = torch.empty(int(_lib.load().geot_res_ln_ws_floats(rows, c)), dtype=torch.float32, device=dev)
+    call("geot_res_ln_grad", dev, rows, c, rps, ptr(gz), ptr(gt), ptr(t), ptr(stats[0]), ptr(stats[1]), ptr(gamma), ptr(s),
+         ptr(g), ptr(gy), ptr(dgb[0]), ptr(dgb[1]), ptr(ws))
+    return g, gy, dgb[0], dgb[1]
+
+
+class _ResLnFn(Function):
+    """t = x + s * y + extra, z = LayerNorm(t): csrc/layernorm.hip, one launch forward, one + a finish backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, s, extra, gamma, beta, eps):
+        t, z, stats, dims = _res_ln_forward(x, y, s, extra, gamma, beta, eps, True)
+        ctx.save_for_backward(t, stats, gamma, s)
+        ctx.cfg = (dims, y is not None, extra is not None)
+        ctx.set_materialize_grads(False)
+        return t, z
+
+    @staticmethod
+    def backward(ctx, gt, gz):
+        t, stats, gamma, s = ctx.saved_tensors
+        dims, has_y, has_extra = ctx.cfg
+        g, gy, dg, db = _res_ln_backward(t, stats, gamma, s, dims, gt, gz, has_y and s is not None)
+        return g, (gy if gy is not None else g) if has_y else None, None, g if has_extra else None, dg, db, None
+
+
+class _LnFn(Function):
+    """z = LayerNorm(x) through the same kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _, z, stats, dims = _res_ln_forward(x, None, None, None, gamma, beta, eps, False)
+        ctx.save_for_backward(x, stats, gamma)
+        ctx.dims = dims
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x, stats, gamma = ctx.saved_tensors
+        g, _, dg, db = _res_ln_backward(x, stats, gamma, None, ctx.dims, None, gz, False)
+        return g, dg, db, None
+
+
+def res_ln_eligible(x, norm):
+    return (isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None and x.is_cuda
+            and x.dtype == torch.float32 and x.dim() == 3 and len(norm.normalized_shape) == 1
+            and norm.normalized_shape[0] == x.shape[-1] and x.numel() > 0
+            and bool(_lib.load().geot_res_ln_supported(int(x.shape[-1]))))
+
+
+def res_ln(x, y, s, extra, norm):
+    """(t, norm(t)) with t = x + s * y + extra; y (branch output), s ((B,1,1) drop-path factors) and extra (position
+    embedding) may be None.  Falls back to the torch composition where the kernels do not apply."""
+    if not res_ln_eligible(x, norm):
+        t = x
+        if y is not None:
+            t = t + y if s is None else torch.addcmul(t, y, s)
+        if extra is not None:
+            t = t + extra
+        return t, norm(t)
+    if y is None and extra is None:
+        x = x.contiguous()
+        return x, _LnFn.apply(x, norm.weight, norm.bias, norm.eps)
+    cont = lambda v: None if v is None else v.contiguous()                      # noqa: E731
+    return _ResLnFn.apply(x.contiguous(), cont(y), cont(s), cont(extra), norm.weight, norm.bias, norm.eps)

@@ -37,7 +37,7 @@ from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_gra
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
 from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
-from ....fused_norm import linear as lean_linear
+from ....fused_norm import linear as lean_linear, res_ln, res_ln_eligible
 
 
 class DropPath(nn.Module):
@@ -156,11 +156,40 @@ class TransformerEncoder_h(nn.Module):
             for i in range(depth)])
 
     def forward(self, x, pos):
+        if len(self.blocks) and self.blocks[0].attn.lean and res_ln_eligible(x, self.blocks[0].norm1):
+            return self._forward_fused_norms(x, pos)
         inter_feats = []
         for i, block in enumerate(self.blocks):
             x = block(x + pos)
             if self.extract_layers is not None and i + 1 in self.extract_layers:
                 inter_feats.append(x)
+        return inter_feats if self.extract_layers is not None else x
+
+    def _forward_fused_norms(self, x, pos):
+        """The same blocks with every residual add fused into the LayerNorm behind it (fused_norm.res_ln): the
+        position embedding and the previous block's MLP branch enter the next block's norm1 in one pass, the attention
+        branch enters norm2 in one pass; a block's output is materialised only where it is extracted."""
+        def scale(blk, branch):
+            return blk.drop_path.scale(branch) if isinstance(blk.drop_path, DropPath) else None
+
+        inter_feats = []
+        pending = None                                 # (a1, mlp branch, drop-path factors) of the previous block
+        for i, blk in enumerate(self.blocks):
+            if pending is None:
+                a0, n1 = res_ln(x, None, None, pos, blk.norm1)
+            else:
+                a0, n1 = res_ln(pending[0], pending[1], pending[2], pos, blk.norm1)
+            att = blk.attn(n1)
+            a1, n2 = res_ln(a0, att, scale(blk, att), None, blk.norm2)
+            m = blk.mlp(n2)
+            wanted = self.extract_layers is not None and i + 1 in self.extract_layers
+            if wanted or i + 1 == len(self.blocks):
+                x = _residual(a1, m, blk.drop_path)
+                pending = None
+                if wanted:
+                    inter_feats.append(x)
+            else:
+                pending = (a1, m, scale(blk, m))
         return inter_feats if self.extract_layers is not None else x
 
 

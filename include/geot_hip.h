@@ -175,6 +175,21 @@ int geot_bn_bwd_reduce(int b, int c, int l, int relu, const float *x, const floa
 int geot_bn_bwd_apply(int b, int c, int l, int relu, const float *x, const float *dz, const float *scale,
                       const float *shift, const float *mean, const float *rstd, const float *k0, const float *c1,
                       const float *c2, float *dx, void *stream);
+/* Residual add + LayerNorm of the transformer blocks (transformer.py:41-104: x + drop_path(branch), then norm; the
+ * position embedding added between blocks, :395-400) as one pass each way over row-major (rows, c) tensors,
+ * c in {128, 256, 384, 512, 768, 1024} (geot_res_ln_supported):
+ *   t = x + s[row / rows_per_sample] * y + extra   (y, s, extra may be NULL; s needs y),  z = LayerNorm(t; gamma, beta, eps)
+ *   geot_res_ln       writes t (t_out NULL: not wanted), z, and the per-row mean / rstd
+ *   geot_res_ln_grad  g = gt + LayerNorm'(gz) (gt / gz NULL: zero) = the gradient of x and of extra; gy_out (NULL: not
+ *                     wanted) = s * g = the gradient of y; d gamma, d beta;  workspace: geot_res_ln_ws_floats floats. */
+int geot_res_ln_supported(int c);
+long long geot_res_ln_ws_floats(int rows, int c);
+int geot_res_ln(int rows, int c, int rows_per_sample, float eps, const float *x, const float *y, const float *s,
+                const float *extra, const float *gamma, const float *beta, float *t_out, float *z_out, float *mean,
+                float *rstd, void *stream);
+int geot_res_ln_grad(int rows, int c, int rows_per_sample, const float *gz, const float *gt, const float *t,
+                     const float *mean, const float *rstd, const float *gamma, const float *s, float *g_out, float *gy_out,
+                     float *dgamma, float *dbeta, float *workspace, void *stream);
 /* Poly-1 focal loss (openpoints/loss/build.py:183-258 Poly1FocalLoss; :799-892 Poly1FocalLoss_U_corr when `keep` is
  * given) on logits (b, c, n) with int64 class labels (b, n) -- no one-hot tensors, two launches forward, one backward:
  *   l = at * BCEwithlogits(x, y) * (1 - pt)^gamma + epsilon * (1 - pt)^(gamma + 1),  y = [label == c], pt = y p + (1-y)(1-p),

@@ -290,6 +290,43 @@ def test_lean_linear_equals_nn_linear():
         assert float((res[1][3].double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+def test_res_ln_equals_add_then_layernorm():
+    """fused_norm.res_ln (t = x + s*y + extra, z = LayerNorm(t)) vs the torch composition in fp64: both outputs, every
+    gradient with both outputs used downstream; all optional inputs present / absent."""
+    from geot_amd.fused_norm import res_ln
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    b, n, c = 3, 50, 384
+    x0, y0, e0 = (torch.randn(b, n, c, device=dev) for _ in range(3))
+    s0 = (torch.rand(b, 1, 1, device=dev) > 0.3).float() / 0.7
+    up_t, up_z = torch.randn(b, n, c, device=dev), torch.randn(b, n, c, device=dev)
+    for use_y, use_s, use_e in ((True, True, True), (True, False, False), (False, False, True), (False, False, False)):
+        res = []
+        for fused in (False, True):
+            dt = torch.float32 if fused else torch.float64
+            ln = torch.nn.LayerNorm(c).to(dev).to(dt)
+            with torch.no_grad():
+                ln.weight.copy_(torch.linspace(0.5, 1.5, c)); ln.bias.copy_(torch.linspace(-1, 1, c))
+            x = x0.detach().clone().to(dt).requires_grad_(True)
+            y = y0.detach().clone().to(dt).requires_grad_(True) if use_y else None
+            e = e0.detach().clone().to(dt).requires_grad_(True) if use_e else None
+            s = s0.to(dt) if use_s else None
+            if fused:
+                t, z = res_ln(x, y, s, e, ln)
+            else:
+                t = x
+                if y is not None:
+                    t = t + (y if s is None else y * s)
+                if e is not None:
+                    t = t + e
+                z = ln(t)
+            ((t * up_t.to(dt)).sum() + (z * up_z.to(dt)).sum()).backward()
+            res.append([v.double() for v in (t.detach(), z.detach(), x.grad, ln.weight.grad, ln.bias.grad)]
+                       + ([y.grad.double()] if use_y else []) + ([e.grad.double()] if use_e else []))
+        for a, f in zip(*res):
+            assert float((a - f).abs().max()) <= 2e-5 * (float(a.abs().max()) + 1e-9), (use_y, use_s, use_e)
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
