@@ -88,6 +88,8 @@ PROTOTYPES.update({
                                    _c_void_p],
 })
 PROTOTYPES.update({
+    "geot_qkv_split": [_c_int] * 4 + [_c_float] + [_P] * 2 + [_c_void_p],
+    "geot_qkv_split_grad": [_c_int] * 4 + [_c_float] + [_P] * 4 + [_c_void_p],
     "geot_res_ln": [_c_int] * 3 + [_c_float] + [_P] * 10 + [_c_void_p],
     "geot_res_ln_grad": [_c_int] * 3 + [_P] * 12 + [_c_void_p],
     "geot_poly1_focal": [_c_int] * 3 + [_c_float] * 3 + [_P] * 5 + [_c_void_p],

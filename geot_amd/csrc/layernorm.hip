@@ -177,3 +177,68 @@ GEOT_EXPORT int geot_res_ln_grad(int rows, int c, int rows_per_sample, const flo
                        dbeta);
     return hipGetLastError();
 }
+
+// ---- attention head split: (B, N, 3, H, d) projection -> q * scale, k, v as (3, B*H, N, d) ---------------------------
+// (transformer.py:70-72: reshape + permute + three slices; the copy torch makes for the batched GEMMs, with the
+// 1/sqrt(d) of the scores folded into q, and its gradient -- three (B*H, N, d) tensors back into one (B, N, 3, H, d)
+// gradient, d q scaled -- instead of a stack + permuted copy + a pass over the (B, H, N, N) score gradient.)
+namespace geot {
+__global__ __launch_bounds__(256) void qkv_split_kernel(long long total4, int n, int h, int d4, float scale,
+                                                        const float4 *__restrict__ qkv, float4 *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        long long r = i;                                   // out index (w, b, h, n, dd)
+        const int dd = (int)(r % d4); r /= d4;
+        const int nn = (int)(r % n); r /= n;
+        const int hh = (int)(r % h); r /= h;
+        const long long per_w = total4 / 3 / ((long long)h * n * d4);      // = B
+        const int b = (int)(r % per_w), w = (int)(r / per_w);
+        float4 v = qkv[((((long long)b * n + nn) * 3 + w) * h + hh) * d4 + dd];
+        if (w == 0) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
+        out[i] = v;
+    }
+}
+__global__ __launch_bounds__(256) void qkv_merge_kernel(long long total4, int bsz, int n, int h, int d4, float scale,
+                                                        const float4 *__restrict__ gq, const float4 *__restrict__ gk,
+                                                        const float4 *__restrict__ gv, float4 *__restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        long long r = i;                                   // out index (b, n, w, h, dd)
+        const int dd = (int)(r % d4); r /= d4;
+        const int hh = (int)(r % h); r /= h;
+        const int w = (int)(r % 3); r /= 3;
+        const int nn = (int)(r % n);
+        const int b = (int)(r / n);
+        const float4 *src = w == 0 ? gq : (w == 1 ? gk : gv);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (src) v = src[(((long long)b * h + hh) * n + nn) * d4 + dd];
+        if (w == 0) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
+        out[i] = v;
+    }
+}
+} // namespace geot
+
+GEOT_EXPORT int geot_qkv_split(int b, int n, int h, int d, float scale, const float *qkv, float *out, void *stream)
+{
+    if (b < 1 || n < 1 || h < 1 || d < 4 || (d & 3) || !qkv || !out || (((uintptr_t)qkv | (uintptr_t)out) & 15)) return hipErrorInvalidValue;
+    const long long total4 = 3LL * b * n * h * (d / 4);
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(qkv_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total4, n, h, d / 4, scale,
+                       (const float4 *)qkv, (float4 *)out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_qkv_split_grad(int b, int n, int h, int d, float scale, const float *gq, const float *gk, const float *gv,
+                                    float *grad_qkv, void *stream)
+{
+    if (b < 1 || n < 1 || h < 1 || d < 4 || (d & 3) || !grad_qkv ||
+        (((uintptr_t)gq | (uintptr_t)gk | (uintptr_t)gv | (uintptr_t)grad_qkv) & 15))
+        return hipErrorInvalidValue;
+    const long long total4 = 3LL * b * n * h * (d / 4);
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(qkv_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total4, b, n, h, d / 4, scale,
+                       (const float4 *)gq, (const float4 *)gk, (const float4 *)gv, (float4 *)grad_qkv);
+    return hipGetLastError();
+}

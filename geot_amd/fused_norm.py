@@ -398,3 +398,32 @@ def res_ln(x, y, s, extra, norm):
         return x, _LnFn.apply(x, norm.weight, norm.bias, norm.eps)
     cont = lambda v: None if v is None else v.contiguous()                      # noqa: E731
     return _ResLnFn.apply(x.contiguous(), cont(y), cont(s), cont(extra), norm.weight, norm.bias, norm.eps)
+
+
+class _QkvSplitFn(Function):
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        b, n, c3 = qkv.shape
+        d = c3 // (3 * heads)
+        out = torch.empty((3, b * heads, n, d), dtype=torch.float32, device=qkv.device)
+        call("geot_qkv_split", qkv.device, b, n, heads, d, float(scale), ptr(qkv), ptr(out))
+        ctx.cfg = (b, n, heads, d, float(scale))
+        ctx.set_materialize_grads(False)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, gq, gk, gv):
+        b, n, heads, d, scale = ctx.cfg
+        gq, gk, gv = (None if g is None else g.contiguous() for g in (gq, gk, gv))
+        dev = next(g for g in (gq, gk, gv) if g is not None).device
+        grad = torch.empty((b, n, 3 * heads * d), dtype=torch.float32, device=dev)
+        call("geot_qkv_split_grad", dev, b, n, heads, d, scale, ptr(gq), ptr(gk), ptr(gv), ptr(grad))
+        return grad, None, None
+
+
+def qkv_split(qkv, heads, scale):
+    """qkv (B, N, 3*H*d) -> (q * scale, k, v), each (B*H, N, d) contiguous (csrc/layernorm.hip); None where it does not apply."""
+    if not (qkv.is_cuda and qkv.dtype == torch.float32 and qkv.dim() == 3 and qkv.is_contiguous() and qkv.numel() > 0
+            and qkv.shape[2] % (3 * heads) == 0 and (qkv.shape[2] // (3 * heads)) % 4 == 0):
+        return None
+    return _QkvSplitFn.apply(qkv, heads, scale)

@@ -37,7 +37,7 @@ from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_gra
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
 from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
-from ....fused_norm import linear as lean_linear, res_ln, res_ln_eligible
+from ....fused_norm import linear as lean_linear, res_ln, res_ln_eligible, qkv_split
 
 
 class DropPath(nn.Module):
@@ -108,8 +108,14 @@ class Attention(nn.Module):
             # contiguous (B*H, N, d) views (their gradients come back through one stack instead of three
             # zero-fill + copy + add chains), and the 1/sqrt(d) rides in the GEMM (baddbmm's alpha) instead of an
             # element-wise pass over the (B, H, N, N) scores each way.
-            q, k, v = self.qkv(x).view(B, N, 3, H, d).permute(2, 0, 3, 1, 4).contiguous().view(3, B * H, N, d).unbind(0)
-            attn = torch.baddbmm(q.new_empty(()), q, k.transpose(1, 2), beta=0.0, alpha=self.scale).softmax(dim=-1)
+            qkv = self.qkv(x)
+            split = qkv_split(qkv, H, self.scale)          # one launch each way, the softmax scale folded into q
+            if split is not None:
+                q, k, v = split
+                attn = torch.bmm(q, k.transpose(1, 2)).softmax(dim=-1)
+            else:
+                q, k, v = qkv.view(B, N, 3, H, d).permute(2, 0, 3, 1, 4).contiguous().view(3, B * H, N, d).unbind(0)
+                attn = torch.baddbmm(q.new_empty(()), q, k.transpose(1, 2), beta=0.0, alpha=self.scale).softmax(dim=-1)
             x = torch.bmm(attn, v).view(B, H, N, d).transpose(1, 2).reshape(B, N, C)
             return self.proj_drop(lean_linear(self.proj, x))
         qkv = self.qkv(x).reshape(B, N, 3, H, d).permute(2, 0, 3, 1, 4)

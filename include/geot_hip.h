@@ -190,6 +190,13 @@ int geot_res_ln(int rows, int c, int rows_per_sample, float eps, const float *x,
 int geot_res_ln_grad(int rows, int c, int rows_per_sample, const float *gz, const float *gt, const float *t,
                      const float *mean, const float *rstd, const float *gamma, const float *s, float *g_out, float *gy_out,
                      float *dgamma, float *dbeta, float *workspace, void *stream);
+/* Attention head split (transformer.py:70-72): the (b, n, 3, h, d) qkv projection -> out (3, b*h, n, d) = (q * scale, k,
+ * v) contiguous for the batched GEMMs, d a multiple of 4; _grad: three (b*h, n, d) gradients (NULL: zero) back into
+ * the (b, n, 3, h, d) gradient with d q scaled -- one launch each instead of a stack, a permuted copy and an
+ * element-wise pass over the (b, h, n, n) score gradient. */
+int geot_qkv_split(int b, int n, int h, int d, float scale, const float *qkv, float *out, void *stream);
+int geot_qkv_split_grad(int b, int n, int h, int d, float scale, const float *gq, const float *gk, const float *gv,
+                        float *grad_qkv, void *stream);
 /* Poly-1 focal loss (openpoints/loss/build.py:183-258 Poly1FocalLoss; :799-892 Poly1FocalLoss_U_corr when `keep` is
  * given) on logits (b, c, n) with int64 class labels (b, n) -- no one-hot tensors, two launches forward, one backward:
  *   l = at * BCEwithlogits(x, y) * (1 - pt)^gamma + epsilon * (1 - pt)^(gamma + 1),  y = [label == c], pt = y p + (1-y)(1-p),

@@ -327,6 +327,33 @@ def test_res_ln_equals_add_then_layernorm():
             assert float((a - f).abs().max()) <= 2e-5 * (float(a.abs().max()) + 1e-9), (use_y, use_s, use_e)
 
 
+def test_qkv_split_and_its_gradient():
+    from geot_amd.fused_norm import qkv_split
+    dev = torch.device("cuda:0")
+    torch.manual_seed(9)
+    b, n, h, d, scale = 3, 50, 4, 24, 0.37
+    x0 = torch.randn(b, n, 3 * h * d, device=dev)
+    ups = [torch.randn(b * h, n, d, device=dev) for _ in range(3)]
+    res = []
+    for fused in (False, True):
+        x = x0.clone().requires_grad_(True)
+        if fused:
+            q, k, v = qkv_split(x, h, scale)
+        else:
+            q, k, v = x.view(b, n, 3, h, d).permute(2, 0, 3, 1, 4).contiguous().view(3, b * h, n, d).unbind(0)
+            q = q * scale
+        ((q * ups[0]).sum() + (k * ups[1]).sum() + (v * ups[2]).sum()).backward()
+        res.append((q.detach(), k.detach(), v.detach(), x.grad))
+    for a, f in zip(*res):
+        assert torch.equal(a, f)
+    x = x0.clone().requires_grad_(True)
+    q, k, v = qkv_split(x, h, scale)
+    (k * ups[1]).sum().backward()                               # q and v unused: their gradients are zeros
+    want = torch.zeros(b, n, 3, h, d, device=dev)
+    want[:, :, 1] = ups[1].view(b, h, n, d).permute(0, 2, 1, 3)
+    assert torch.equal(x.grad, want.view(b, n, -1))
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
