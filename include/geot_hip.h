@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEOT_ABI_VERSION 3
+#define GEOT_ABI_VERSION 4
 
 /* ABI version / diagnostics. */
 int geot_abi_version(void);
