@@ -88,6 +88,7 @@ PROTOTYPES.update({
                                    _c_void_p],
 })
 PROTOTYPES.update({
+    "geot_softmax_grad": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_qkv_split": [_c_int] * 4 + [_c_float] + [_P] * 2 + [_c_void_p],
     "geot_qkv_split_grad": [_c_int] * 4 + [_c_float] + [_P] * 4 + [_c_void_p],
     "geot_res_ln": [_c_int] * 3 + [_c_float] + [_P] * 10 + [_c_void_p],

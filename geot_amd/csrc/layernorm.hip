@@ -242,3 +242,45 @@ GEOT_EXPORT int geot_qkv_split_grad(int b, int n, int h, int d, float scale, con
                        (const float4 *)gq, (const float4 *)gk, (const float4 *)gv, (float4 *)grad_qkv);
     return hipGetLastError();
 }
+
+// ---- row soft-max backward: gi = y * (g - sum_j g_j y_j), one wave per row, n <= 1024 a multiple of 64 -------------------
+// (torch's backward is an element-wise g * y pass followed by its warp kernel)
+namespace geot {
+template <int EPL>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(long long rows, const float *__restrict__ g, const float *__restrict__ y,
+                                                          float *__restrict__ gi)
+{
+    constexpr int N = 64 * EPL;
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const size_t base = (size_t)row * N + lane;
+    float gv[EPL], yv[EPL], dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+        gv[e] = g[base + 64 * e];
+        yv[e] = y[base + 64 * e];
+        dot = fmaf(gv[e], yv[e], dot);
+    }
+    dot = ln_wave_sum(dot);
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) gi[base + 64 * e] = yv[e] * (gv[e] - dot);
+}
+} // namespace geot
+
+GEOT_EXPORT int geot_softmax_grad(long long rows, int n, const float *grad, const float *y, float *grad_in, void *stream)
+{
+    if (rows < 0 || !(n == 64 || n == 128 || n == 256 || n == 512 || n == 1024) || !grad || !y || !grad_in) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    const long long blocks = (rows + 3) / 4;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)blocks);
+    switch (n / 64) {
+    case 1: hipLaunchKernelGGL(softmax_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, rows, grad, y, grad_in); break;
+    case 2: hipLaunchKernelGGL(softmax_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, rows, grad, y, grad_in); break;
+    case 4: hipLaunchKernelGGL(softmax_bwd_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, rows, grad, y, grad_in); break;
+    case 8: hipLaunchKernelGGL(softmax_bwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, rows, grad, y, grad_in); break;
+    default: hipLaunchKernelGGL(softmax_bwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, rows, grad, y, grad_in); break;
+    }
+    return hipGetLastError();
+}

@@ -427,3 +427,26 @@ def qkv_split(qkv, heads, scale):
             and qkv.shape[2] % (3 * heads) == 0 and (qkv.shape[2] // (3 * heads)) % 4 == 0):
         return None
     return _QkvSplitFn.apply(qkv, heads, scale)
+
+
+class _SoftmaxLastFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.softmax(x, dim=-1)
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, = ctx.saved_tensors
+        g = g.contiguous()
+        gi = torch.empty_like(y)
+        call("geot_softmax_grad", y.device, y.numel() // y.shape[-1], y.shape[-1], ptr(g), ptr(y), ptr(gi))
+        return gi
+
+
+def softmax_last(x):
+    """x.softmax(dim=-1) whose gradient is one pass (csrc/layernorm.hip) for float32 GPU rows of 64 .. 1024 (power of two)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] in (64, 128, 256, 512, 1024) and x.numel() > 0):
+        return x.softmax(dim=-1)
+    return _SoftmaxLastFn.apply(x)

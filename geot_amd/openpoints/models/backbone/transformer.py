@@ -37,7 +37,7 @@ from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_gra
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
 from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
-from ....fused_norm import linear as lean_linear, res_ln, res_ln_eligible, qkv_split
+from ....fused_norm import linear as lean_linear, res_ln, res_ln_eligible, qkv_split, softmax_last
 
 
 class DropPath(nn.Module):
@@ -112,7 +112,7 @@ class Attention(nn.Module):
             split = qkv_split(qkv, H, self.scale)          # one launch each way, the softmax scale folded into q
             if split is not None:
                 q, k, v = split
-                attn = torch.bmm(q, k.transpose(1, 2)).softmax(dim=-1)
+                attn = softmax_last(torch.bmm(q, k.transpose(1, 2)))
             else:
                 q, k, v = qkv.view(B, N, 3, H, d).permute(2, 0, 3, 1, 4).contiguous().view(3, B * H, N, d).unbind(0)
                 attn = torch.baddbmm(q.new_empty(()), q, k.transpose(1, 2), beta=0.0, alpha=self.scale).softmax(dim=-1)

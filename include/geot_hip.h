@@ -197,6 +197,9 @@ int geot_res_ln_grad(int rows, int c, int rows_per_sample, const float *gz, cons
 int geot_qkv_split(int b, int n, int h, int d, float scale, const float *qkv, float *out, void *stream);
 int geot_qkv_split_grad(int b, int n, int h, int d, float scale, const float *gq, const float *gk, const float *gv,
                         float *grad_qkv, void *stream);
+/* Gradient of a soft-max over the last dimension n in {64, 128, 256, 512, 1024} of row-major (rows, n): grad_in = y * (grad -
+ * sum_j grad_j y_j) in one pass (the attention scores of transformer.py:75-77; torch runs grad * y as a pass of its own). */
+int geot_softmax_grad(long long rows, int n, const float *grad, const float *y, float *grad_in, void *stream);
 /* Poly-1 focal loss (openpoints/loss/build.py:183-258 Poly1FocalLoss; :799-892 Poly1FocalLoss_U_corr when `keep` is
  * given) on logits (b, c, n) with int64 class labels (b, n) -- no one-hot tensors, two launches forward, one backward:
  *   l = at * BCEwithlogits(x, y) * (1 - pt)^gamma + epsilon * (1 - pt)^(gamma + 1),  y = [label == c], pt = y p + (1-y)(1-p),

@@ -354,6 +354,22 @@ def test_qkv_split_and_its_gradient():
     assert torch.equal(x.grad, want.view(b, n, -1))
 
 
+def test_softmax_last_gradient():
+    from geot_amd.fused_norm import softmax_last
+    dev = torch.device("cuda:0")
+    torch.manual_seed(10)
+    for shape in ((6, 70, 512), (5, 64), (3, 2, 1024)):
+        x0, up = torch.randn(*shape, device=dev) * 3, torch.randn(*shape, device=dev)
+        res = []
+        for fused in (False, True):
+            x = (x0.double() if not fused else x0.clone()).requires_grad_(True)
+            y = softmax_last(x) if fused else x.softmax(dim=-1)
+            (y * up.to(y.dtype)).sum().backward()
+            res.append((y.detach().double(), x.grad.double()))
+        assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-6
+        assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-6 * (float(res[0][1].abs().max()) + 1e-9) + 1e-7
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
