@@ -564,7 +564,11 @@ __global__ __launch_bounds__(256) void rix_place_kernel(long long total, long lo
     if (WEIGHTED) revw[pos] = weight[x];
 }
 
-template <bool WEIGHTED, int CH>
+// LPT lanes per target (1, 4, 8 or 16 adjacent lanes): a layer with few targets and long lists (the FP modules that
+// interpolate from the 512 group centres: 48 entries per target, half the workgroup idle at one thread per target)
+// spreads every list over LPT lanes -- lane `sub` takes entries sub, sub + LPT, ... (consecutive lanes read consecutive
+// entries) -- and sums the partial results inside the lane group.  LPT = 1 is the one-thread-per-target walk.
+template <bool WEIGHTED, int CH, int LPT>
 __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
     int c, int m, int L, int Q, int partlen, const float *__restrict__ grad_out, size_t src_bstride,
     const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw,
@@ -581,23 +585,24 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
     __syncthreads();
     const int per = (m + gridDim.x - 1) / gridDim.x;
     const int j0 = blockIdx.x * per, j1 = min(m, j0 + per);
-    // TP targets per thread, their lists walked in lock step RU entries at a time: TP x RU x 2 independent
+    // TP targets per lane group, their lists walked in lock step RU entries per lane at a time: TP x RU x 2 independent
     // loads in flight per thread (one workgroup per CU, so the memory-level parallelism must come from here)
-    constexpr int RU = 4, TP = 4;
-    for (int jb = j0 + threadIdx.x; jb < j1; jb += TP * TLDS_THREADS) {
+    constexpr int RU = 4, TP = 4, SLOTS = TLDS_THREADS / LPT;
+    const int sub = threadIdx.x & (LPT - 1), slot = threadIdx.x / LPT;
+    for (int jb = j0 + slot; jb < j1; jb += TP * SLOTS) {
         int a[TP], z[TP];
         float acc[TP][CH];
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
-            const int j = jb + p * TLDS_THREADS;
+            const int j = jb + p * SLOTS;
             a[p] = j < j1 ? off[(size_t)bq * m + j] : 0;
             z[p] = j < j1 ? off[(size_t)bq * m + j + 1] : 0;
 #pragma unroll
             for (int l = 0; l < CH; ++l) acc[p][l] = 0.f;
         }
-        int longest = 0;
+        int longest = 0; // entries per lane of the longest of the TP lists
 #pragma unroll
-        for (int p = 0; p < TP; ++p) longest = max(longest, z[p] - a[p]);
+        for (int p = 0; p < TP; ++p) longest = max(longest, (z[p] - a[p] + LPT - 1) / LPT);
         for (int it = 0; it < longest; it += RU) {
             int e[TP][RU];
             float w[TP][RU];
@@ -605,7 +610,7 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
             for (int p = 0; p < TP; ++p)
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
-                    const int q = a[p] + it + u;
+                    const int q = a[p] + (it + u) * LPT + sub;
                     const bool in = q < z[p];
                     e[p][u] = in ? rev[q] : 0;
                     w[p][u] = in ? (WEIGHTED ? revw[q] : 1.f) : 0.f;
@@ -620,10 +625,18 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
                     }
                 }
         }
+        if (LPT > 1) {
+#pragma unroll
+            for (int p = 0; p < TP; ++p)
+#pragma unroll
+                for (int l = 0; l < CH; ++l)
+#pragma unroll
+                    for (int o = LPT / 2; o >= 1; o >>= 1) acc[p][l] += __shfl_xor(acc[p][l], o);
+        }
 #pragma unroll
         for (int p = 0; p < TP; ++p) {
-            const int j = jb + p * TLDS_THREADS;
-            if (j < j1 && (set || z[p] > a[p])) { // untouched targets keep what they had (the buffer is accumulated into)
+            const int j = jb + p * SLOTS;
+            if (sub == 0 && j < j1 && (set || z[p] > a[p])) { // untouched targets keep what they had (the buffer is accumulated into)
 #pragma unroll
                 for (int l = 0; l < CH; ++l) {
                     if (l < nch) {
@@ -813,14 +826,23 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     if (slices < 1) slices = 1;
     if ((long long)b * Q > 65535) return hipErrorNotSupported;
     const dim3 grid((int)slices, chunks, b * Q);
-#define GEOT_CSR_LAUNCH(CHV)                                                                                     \
+#define GEOT_CSR_LAUNCH2(CHV, LPTV)                                                                               \
     {                                                                                                            \
-        e = tlds_set_lds(table_gather_csr_lds_kernel<WEIGHTED, CHV>, lds);                                       \
+        e = tlds_set_lds(table_gather_csr_lds_kernel<WEIGHTED, CHV, LPTV>, lds);                                 \
         if (e != hipSuccess) return e;                                                                           \
-        hipLaunchKernelGGL((table_gather_csr_lds_kernel<WEIGHTED, CHV>), grid, dim3(TLDS_THREADS), lds, s, c, m, L, \
+        hipLaunchKernelGGL((table_gather_csr_lds_kernel<WEIGHTED, CHV, LPTV>), grid, dim3(TLDS_THREADS), lds, s, c, m, L, \
                            Q, rp.partlen, grad_out, src_bstride, off, rev, revw, grad_table, set);               \
     }
+#define GEOT_CSR_LAUNCH(CHV)                                                                                     \
+    {                                                                                                            \
+        if (lpt == 16) GEOT_CSR_LAUNCH2(CHV, 16) else if (lpt == 8) GEOT_CSR_LAUNCH2(CHV, 8)                      \
+        else if (lpt == 4) GEOT_CSR_LAUNCH2(CHV, 4) else GEOT_CSR_LAUNCH2(CHV, 1)                                 \
+    }
+    // lanes per target from the mean list length (entries per target and part)
+    const double mean_len = (double)L * NT / ((double)Q * m);
+    const int lpt = mean_len >= 32.0 ? 16 : (mean_len >= 16.0 ? 8 : (mean_len >= 8.0 ? 4 : 1));
     if (ch == 8) GEOT_CSR_LAUNCH(8) else if (ch == 4) GEOT_CSR_LAUNCH(4) else if (ch == 2) GEOT_CSR_LAUNCH(2) else GEOT_CSR_LAUNCH(1)
+#undef GEOT_CSR_LAUNCH2
 #undef GEOT_CSR_LAUNCH
     return hipGetLastError();
 }

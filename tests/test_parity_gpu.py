@@ -270,6 +270,8 @@ def test_three_interpolate_fwd_bwd(ext, oracle):
 
 @pytest.mark.parametrize("b,c,m,n", [(2, 64, 2048, 6000),      # reverse index, whole rows in LDS (one part)
                                       (2, 32, 4096, 24000),     # reverse index, source parts looped in the workgroup
+                                      (2, 48, 128, 3000),       # few targets, long lists: 16 lanes per target
+                                      (2, 32, 512, 3500),       # 8 lanes per target
                                       (1, 40, 50, 300),         # too small for the reverse index: channels-last scatter
                                       (1, 24, 70, 0)])          # nothing to scatter: zeros
 def test_three_interpolate_grad_out_overwrites_uninitialised_buffers(ext, oracle, b, c, m, n):
