@@ -362,17 +362,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(int rows, int cols, const f
     const int col = blockIdx.x * 64 + lane;
     const int per = (rows + gridDim.y - 1) / gridDim.y;
     const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f;
     if (col < cols) {
         int r = r0 + wave;
-        for (; r + 4 < r1; r += 8) {                       // two rows in flight per wave
-            s0 += x[(size_t)r * cols + col];
-            s1 += x[(size_t)(r + 4) * cols + col];
+        for (; r + 28 < r1; r += 32) {                     // eight rows in flight per wave (the pass is latency-bound)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(r + 4 * u) * cols + col];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s0 += v[u];
         }
-        if (r < r1) s0 += x[(size_t)r * cols + col];
+        for (; r < r1; r += 4) s0 += x[(size_t)r * cols + col];
     }
     __shared__ float sh[4][64];
-    sh[wave][lane] = s0 + s1;
+    sh[wave][lane] = s0;
     __syncthreads();
     if (wave == 0 && col < cols) partial[(size_t)blockIdx.y * cols + col] = (sh[0][lane] + sh[1][lane]) + (sh[2][lane] + sh[3][lane]);
 }

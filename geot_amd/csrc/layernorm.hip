@@ -68,16 +68,29 @@ __global__ __launch_bounds__(256) void res_ln_bwd_kernel(int rows, int rows_per_
 #pragma unroll
     for (int e = 0; e < EPL; ++e) { gam[e] = gamma[lane + 64 * e]; ag[e] = 0.f; ab[e] = 0.f; }
     const int row0 = (blockIdx.x * 4 + wave) * LN_ROWS_PER_WAVE;
+    // the wave's rows are independent: all their loads are issued before the first row's arithmetic
+    float gzv[LN_ROWS_PER_WAVE][EPL], tv[LN_ROWS_PER_WAVE][EPL];
+#pragma unroll
+    for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+        const bool ok = row0 + rr < rows;
+        const size_t base = (size_t)(ok ? row0 + rr : 0) * C + lane;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            gzv[rr][e] = (ok && gz) ? gz[base + 64 * e] : 0.f;
+            tv[rr][e] = ok ? t[base + 64 * e] : 0.f;
+        }
+    }
+#pragma unroll
     for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
         const int row = row0 + rr;
-        if (row >= rows) break;
+        if (row >= rows) continue;
         const size_t base = (size_t)row * C + lane;
         const float mu = mean[row], rs = rstd[row];
         float a[EPL], xh[EPL], s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const float g = gz ? gz[base + 64 * e] : 0.f;
-            xh[e] = (t[base + 64 * e] - mu) * rs;
+            const float g = gzv[rr][e];
+            xh[e] = (tv[rr][e] - mu) * rs;
             a[e] = g * gam[e];
             s1 += a[e];
             s2 = fmaf(a[e], xh[e], s2);
