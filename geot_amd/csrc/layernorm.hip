@@ -10,7 +10,7 @@
 
 namespace geot {
 
-constexpr int LN_ROWS_PER_WAVE = 4; // backward: rows a wave walks, so that d gamma / d beta leave as rows/16 partial rows
+constexpr int LN_ROWS_PER_WAVE = 2; // backward: rows a wave walks (4: 17 us + 6 us finish at 4096 x 384; 2: 11 + 4; 1: 9 + 8)
 
 __device__ __forceinline__ float ln_wave_sum(float v)
 {
@@ -117,26 +117,40 @@ __global__ __launch_bounds__(256) void res_ln_bwd_kernel(int rows, int rows_per_
     }
 }
 
-// d gamma[col] = sum over blocks of partial[blk][0][col], d beta likewise: grid (C / 64), the 4 waves take every 4th block
-__global__ __launch_bounds__(256) void res_ln_finish_kernel(int nblk, int c, const float *__restrict__ partial,
-                                                            float *__restrict__ dgamma, float *__restrict__ dbeta)
+// d gamma[col] = sum over blocks of partial[blk][0][col], d beta likewise: grid (C / 64), 16 waves take every 16th block
+// (the partial rows are read one batch of 8 after the other: with 4 waves this pass was as long as the one before it)
+__global__ __launch_bounds__(1024) void res_ln_finish_kernel(int nblk, int c, const float *__restrict__ partial,
+                                                             float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
     float a = 0.f, b = 0.f;
     if (col < c) {
-#pragma unroll 8
-        for (int blk = wave; blk < nblk; blk += 4) {
+        int blk = wave;
+        for (; blk + 7 * 16 < nblk; blk += 8 * 16) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                va[u] = partial[((size_t)(blk + 16 * u) * 2) * c + col];
+                vb[u] = partial[((size_t)(blk + 16 * u) * 2 + 1) * c + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+        }
+        for (; blk < nblk; blk += 16) {
             a += partial[((size_t)blk * 2) * c + col];
             b += partial[((size_t)blk * 2 + 1) * c + col];
         }
     }
-    __shared__ float sh[2][4][64];
+    __shared__ float sh[2][16][64];
     sh[0][wave][lane] = a;
     sh[1][wave][lane] = b;
     __syncthreads();
     if (wave == 0 && col < c) {
-        dgamma[col] = (sh[0][0][lane] + sh[0][1][lane]) + (sh[0][2][lane] + sh[0][3][lane]);
-        dbeta[col] = (sh[1][0][lane] + sh[1][1][lane]) + (sh[1][2][lane] + sh[1][3][lane]);
+        float ga = 0.f, gb = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { ga += sh[0][w][lane]; gb += sh[1][w][lane]; }
+        dgamma[col] = ga;
+        dbeta[col] = gb;
     }
 }
 
@@ -186,7 +200,7 @@ GEOT_EXPORT int geot_res_ln_grad(int rows, int c, int rows_per_sample, const flo
     const int nblk = ln_bwd_blocks(rows);
     GEOT_LN_DISPATCH(res_ln_bwd_kernel, dim3(nblk), rows, rows_per_sample, gz, gt, t, mean, rstd, gamma, s, g_out, gy_out,
                      workspace)
-    hipLaunchKernelGGL(res_ln_finish_kernel, dim3((c + 63) / 64), dim3(256), 0, (hipStream_t)stream, nblk, c, workspace, dgamma,
+    hipLaunchKernelGGL(res_ln_finish_kernel, dim3((c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, nblk, c, workspace, dgamma,
                        dbeta);
     return hipGetLastError();
 }
