@@ -13,6 +13,8 @@ Both are plain callables over device tensors; `ddp()` wraps student and T_predic
 does (SyncBatchNorm + DistributedDataParallel) -- and also wraps T_predictor, which the reference leaves
 unsynchronised (last row: an intentional divergence).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -94,6 +96,8 @@ class FixMatchNTMStep:
         self.cm = cm if cm is not None else torch.full((c, c), 1.0 / c, device=dev)    # cal_mean_feature's output
         self.group = group
         self._side = None
+        self._teacher_stream = None
+        self.overlap_teacher = True    # the frozen teacher's forward on its own stream beside the student's (same results)
 
     def __call__(self, data, data_u):
         """data: labelled batch {pos (B_l,N,3), x (B_l,3,N), cls (B_l,1), y (B_l,N)}; data_u: unlabelled batch
@@ -113,8 +117,18 @@ class FixMatchNTMStep:
                 raw = data_u["raw_pos"].contiguous()
                 nbr = self.threed_loss.neighbours(raw)
                 order = ntm_mod.spatial_order(raw)
-        # 1. pseudo labels from the frozen teacher on the weak view (train.py:462-475)
-        with torch.no_grad():
+        # 1. pseudo labels from the frozen teacher on the weak view (train.py:462-475).  The teacher's 2-cloud forward
+        #    is short and mostly waits for its own 8192-sample FPS (4.7 ms on 2 CUs); nothing in the student's forward
+        #    depends on it, so it is queued on a stream of its own and the student's kernels fill the gap (the eval-mode
+        #    teacher draws no random numbers: identical results).  Its outputs are first used at step 3, after the join;
+        #    next iteration's entry wait keeps the stream's allocations ordered behind this iteration's readers.
+        t_stream = None
+        if dev.type == "cuda" and self.overlap_teacher:
+            if self._teacher_stream is None:
+                self._teacher_stream = torch.cuda.Stream(device=dev)
+            t_stream = self._teacher_stream
+            t_stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.no_grad(), (torch.cuda.stream(t_stream) if t_stream is not None else contextlib.nullcontext()):
             self.model_t.eval()
             pred_u = F.softmax(self.model_t(data_u, if_teacher=True)[0], dim=1)
             logits_u_aug, label_u_aug = torch.max(pred_u, dim=1)
@@ -124,6 +138,8 @@ class FixMatchNTMStep:
         data_u = dict(data_u, T=self.ema_t)
         pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True)
         pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
+        if t_stream is not None:
+            torch.cuda.current_stream(dev).wait_stream(t_stream)
         # 3. class-level transition matrix, prior, EMA (train.py:502-545, 556-557)
         ema_t_corr, ema_next, _, _ = ntm_mod.class_transition(
             pred_u, sigma, self.ema_t, cfg["geo_lambma"], cfg["ema_t_decay"], group=self.group,

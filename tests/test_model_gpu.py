@@ -118,6 +118,32 @@ def test_fixmatch_ntm_step_end_to_end():
     assert all(not p.requires_grad for p in trainer.model_t.parameters())               # frozen teacher
 
 
+def test_fixmatch_teacher_on_its_own_stream_gives_the_same_iteration():
+    """FixMatchNTMStep queues the frozen teacher's forward on a stream of its own beside the student's forward: two
+    iterations from the same initialisation and random state, with and without it, give the same losses."""
+    from geot_amd import train_step as ts
+    from geot_amd.synth import make_batch
+    dev = torch.device("cuda:0")
+    _, pos, target = _batch(2, 6000, dev)
+    xu = torch.from_numpy(make_batch(2, 6000, start_index=50)[0]).to(dev)
+    xs = (xu * 1.1).contiguous()
+    z = torch.zeros(2, 1, dtype=torch.long, device=dev)
+    data = {"pos": pos, "x": pos.transpose(1, 2).contiguous(), "cls": z, "y": target}
+    data_u = {"pos_w": xu, "x_w": xu.transpose(1, 2).contiguous(), "cls_w": z, "pos_s": xs,
+              "x_s": xs.transpose(1, 2).contiguous(), "cls_s": z, "raw_pos": xu}
+    runs = []
+    for overlap in (False, True):
+        torch.manual_seed(4)
+        trainer = ts.build_fixmatch(dev, seg_cfg=SMALL, use_ddp=False)
+        trainer.overlap_teacher = overlap
+        torch.manual_seed(5)
+        out = [trainer(data, data_u) for _ in range(2)]
+        torch.cuda.synchronize()
+        runs.append([float(v) for o in out for v in o.values()])
+    for a, b in zip(*runs):
+        assert abs(a - b) <= 2e-5 * abs(a) + 1e-7, runs         # float atomics in the graph loss: last-bit differences
+
+
 @pytest.mark.parametrize("b,c,nq,nk,k,groups", [(2, 64, 1000, 700, 4, 4), (1, 32, 333, 333, 5, 2), (2, 512, 4096, 512, 4, 4),
                                                  (1, 24, 2048, 9000, 3, 1)])
 def test_edgeconv_tail_matches_composed(b, c, nq, nk, k, groups):
