@@ -49,6 +49,7 @@ def ddp(module, device, sync_bn=True, unused=(), **kw):
     if skip:
         nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(module, skip)
     ids = [device.index] if device.type == "cuda" else None
+    kw.setdefault("gradient_as_bucket_view", True)      # gradients live in the all-reduce buckets: no 108 MB copy per step
     return nn.parallel.DistributedDataParallel(module, device_ids=ids, **kw)
 
 
