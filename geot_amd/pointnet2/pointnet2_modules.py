@@ -45,7 +45,7 @@ def _sa_factored(xyz_flipped, new_xyz, features, idx, mlp, xyz_scale):
     points instead of the npoint x nsample rows (32x fewer at nsample = 32) and neither grouped tensor of the
     reference ((B,3,np,ns), (B,C,np,ns)) nor their concatenation is built; BatchNorm + ReLU of every stage is one
     fused pass each way (fused_norm.bn_act).  Same function as the composed path (tests: 1e-4)."""
-    from ..fused_norm import bn_act, max_last
+    from ..fused_norm import bn_act, max_last, add_last_broadcast
     stages = list(mlp.children())
     conv = stages[0].conv
     w = conv.weight.view(conv.out_channels, -1)
@@ -54,7 +54,7 @@ def _sa_factored(xyz_flipped, new_xyz, features, idx, mlp, xyz_scale):
     q = pt_utils.pointwise(w[:, :3] * (-xyz_scale), new_xyz.transpose(1, 2).contiguous())   # (B, C1, np)
     b, c1, npoint = q.shape
     ns = idx.shape[2]
-    y = (pointnet2_utils.grouping_operation(p.contiguous(), idx) + q.unsqueeze(-1)).view(b, c1, npoint * ns)
+    y = add_last_broadcast(pointnet2_utils.grouping_operation(p.contiguous(), idx), q).view(b, c1, npoint * ns)
     y = bn_act(stages[0].bn.bn, y, relu=True)
     y = pt_utils.shared_mlp_nd(stages[1:], y)
     return max_last(y.view(b, y.shape[1], npoint, ns))
