@@ -105,6 +105,8 @@ PROTOTYPES.update({
     "geot_fp_front": [_c_int] * 5 + [_P] * 7 + [_c_void_p],
     "geot_segment_max": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_segment_sum": [ctypes.c_longlong, _c_int, _P, _P, _c_void_p],
+    "geot_bn_pool": [_c_int] * 5 + [_P] * 6 + [_c_void_p],
+    "geot_bn_pool_grad": [_c_int] * 4 + [_P] * 9 + [_c_void_p],
     "geot_rowdot_small": [_c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
     "geot_colsum": [_c_int, _c_int, _P, _P, _P, _c_void_p],
     "geot_segment_max_grad": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],

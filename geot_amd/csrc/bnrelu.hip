@@ -391,6 +391,77 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(int s, int cols, con
     for (int i = 0; i < 16; ++i) a += v[i];
     out[col] = a;
 }
+// ---- BatchNorm -> ReLU -> max over the n innermost elements, without materialising the normalised tensor ---------------
+// max_j relu(a y_j + b) = relu(a sel + b) with sel = max_j y_j if a >= 0 else min_j y_j (the affine map is monotone): the
+// last stage of a SetAbstraction module in training mode (pointnet2_modules.py:57-66: SharedMLP then max_pool2d over
+// nsample).  Forward: rows = (b, c, group) of n elements; out = relu(a_c sel + b_c), sel, arg = slot of the first
+// extremum.  Backward: the gradient of the (never built) normalised tensor is g at arg (if the pre-activation was
+// positive) and 0 elsewhere, so  dx_j = k0_c ([j == arg] gm - c1_c - xhat_j c2_c)  in one pass over y.
+template <int LPR>
+__global__ __launch_bounds__(256) void bn_pool_kernel(long long rows, int n, int groups, int c, int relu,
+                                                      const float *__restrict__ y, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, float *__restrict__ out,
+                                                      float *__restrict__ sel_out, uint8_t *__restrict__ arg)
+{
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long row = gid / LPR;
+    const int sub = (int)(gid % LPR);
+    if (row >= rows) return;
+    const int cc = (int)((row / groups) % c);
+    const float a = scale[cc];
+    const float sgn = a >= 0.f ? 1.f : -1.f;               // max of sgn * y: the maximum, or the minimum
+    const float4 *src = reinterpret_cast<const float4 *>(y + row * n);
+    float best = -INFINITY;
+    int bj = 0x7fffffff;
+    for (int v = sub; v < (n >> 2); v += LPR) {
+        const float4 q = src[v];
+        const float e[4] = {sgn * q.x, sgn * q.y, sgn * q.z, sgn * q.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = 4 * v + u;
+            const bool take = seg_better(e[u], j, best, bj);
+            best = take ? e[u] : best;
+            bj = take ? j : bj;
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < LPR; d <<= 1) {
+        const float ob = __shfl_xor(best, d);
+        const int oj = __shfl_xor(bj, d);
+        const bool take = seg_better(ob, oj, best, bj);
+        best = take ? ob : best;
+        bj = take ? oj : bj;
+    }
+    if (sub == 0) {
+        float sv = sgn * best;
+        if (a == 0.f) {                                    // every slot ties at relu(b): the reference's max takes the first
+            bj = 0;
+            sv = y[row * n];
+        }
+        const float z = fmaf(sv, a, shift[cc]);
+        out[row] = relu ? fmaxf(z, 0.f) : z;               // (NaN: fmaxf drops it; the reference's relu keeps it -- inputs are finite)
+        sel_out[row] = sv;
+        arg[row] = (uint8_t)(bj == 0x7fffffff ? 0 : bj);
+    }
+}
+__global__ __launch_bounds__(256) void bn_pool_bwd_kernel(long long total4, int n4, int groups, int c,
+                                                          const float *__restrict__ y, const float *__restrict__ gm,
+                                                          const uint8_t *__restrict__ arg, const float *__restrict__ mean,
+                                                          const float *__restrict__ rstd, const float *__restrict__ k0,
+                                                          const float *__restrict__ c1, const float *__restrict__ c2,
+                                                          float *__restrict__ dx)
+{
+    for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < total4; v += (long long)gridDim.x * 256) {
+        const long long row = v / n4;
+        const int cc = (int)((row / groups) % c);
+        const int j0 = (int)(v - row * n4) * 4, a = arg[row];
+        const float g = gm[row], mu = mean[cc], r = rstd[cc], kk = k0[cc], m1 = c1[cc], m2 = c2[cc];
+        const float4 q = reinterpret_cast<const float4 *>(y)[v];
+        reinterpret_cast<float4 *>(dx)[v] =
+            make_float4(kk * ((a == j0 ? g : 0.f) - m1 - (q.x - mu) * r * m2), kk * ((a == j0 + 1 ? g : 0.f) - m1 - (q.y - mu) * r * m2),
+                        kk * ((a == j0 + 2 ? g : 0.f) - m1 - (q.z - mu) * r * m2), kk * ((a == j0 + 3 ? g : 0.f) - m1 - (q.w - mu) * r * m2));
+    }
+}
 // dx (rows, n) = dy[row] at the arg-max slot, 0 elsewhere (written in full)
 __global__ __launch_bounds__(256) void segment_max_grad_kernel(long long total4, int n4, const float *__restrict__ dy,
                                                                const uint8_t *__restrict__ arg, float *__restrict__ dx)
@@ -677,6 +748,38 @@ GEOT_EXPORT int geot_segment_sum(long long rows, int n, const float *x, float *o
     else if (lpr == 4) hipLaunchKernelGGL(segment_sum_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out);
     else if (lpr == 2) hipLaunchKernelGGL(segment_sum_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out);
     else hipLaunchKernelGGL(segment_sum_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, x, out);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_pool(int b, int c, int groups, int n, int relu, const float *y, const float *scale, const float *shift,
+                             float *out, float *sel, unsigned char *arg, void *stream)
+{
+    if (b < 1 || c < 1 || groups < 1 || n < 4 || n > 256 || (n & 3) || !y || !scale || !shift || !out || !sel || !arg ||
+        (((uintptr_t)y) & 15))
+        return hipErrorInvalidValue;
+    const long long rows = (long long)b * c * groups;
+    const int lpr = n >= 32 ? 8 : (n >= 16 ? 4 : (n >= 8 ? 2 : 1));
+    const long long blocks = (rows * lpr + 255) / 256;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+#define GEOT_BP(L) hipLaunchKernelGGL(bn_pool_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rows, n, groups, c, \
+                                      relu, y, scale, shift, out, sel, arg)
+    if (lpr == 8) GEOT_BP(8); else if (lpr == 4) GEOT_BP(4); else if (lpr == 2) GEOT_BP(2); else GEOT_BP(1);
+#undef GEOT_BP
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_pool_grad(int b, int c, int groups, int n, const float *y, const float *gm, const unsigned char *arg,
+                                  const float *mean, const float *rstd, const float *k0, const float *c1, const float *c2,
+                                  float *dx, void *stream)
+{
+    if (b < 1 || c < 1 || groups < 1 || n < 4 || n > 256 || (n & 3) || !y || !gm || !arg || !mean || !rstd || !k0 || !c1 || !c2 ||
+        !dx || ((((uintptr_t)y) | ((uintptr_t)dx)) & 15))
+        return hipErrorInvalidValue;
+    const long long total4 = (long long)b * c * groups * (n >> 2);
+    long long blocks = (total4 + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(bn_pool_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, total4, n >> 2, groups, c, y, gm,
+                       arg, mean, rstd, k0, c1, c2, dx);
     return hipGetLastError();
 }
 

@@ -84,26 +84,12 @@ def _covered(bn, x):
             and x.dim() == 3 and x.shape[0] <= 65535 and x.shape[1] <= 65535 and x.numel() > 0)
 
 
-def bn_act(bn, x, relu=True, partial=None, pre_bias=None):
-    """act(bn(x)) for x (B, C, L) float32 on the GPU; `partial` (B, C, S, 2): per-slice (sum x, sum x^2) when the
-    producer of x already formed them (fp_front).  `pre_bias` (C,): act(bn(x + pre_bias[:, None])) without the add --
-    the bias of the convolution in front: under batch statistics it cancels in the output (only the running mean sees
-    it, and its gradient is exactly zero), under running statistics it folds into the shift."""
-    if not _covered(bn, x):
-        from .pointnet2.pytorch_utils import batch_norm_nd
-        y = batch_norm_nd(bn, x if pre_bias is None else x + pre_bias.view(1, -1, 1))
-        return torch.relu(y) if relu else y
-    x = x.contiguous()
+def _batch_statistics(bn, x, gamma, beta, partial, pre_bias):
+    """Training-mode statistics of x (B, C, L) for the module `bn`: the stats pass (unless `partial` came with x), the
+    all-reduce under SyncBatchNorm, mean / rstd / scale / shift and the running-statistics update.
+    -> (stats (4, C) = mean, rstd, scale, shift; count (python float, or a 1-element device double); group)."""
     b, c, l = x.shape
     dev = x.device
-    gamma = bn.weight if bn.weight is not None else torch.ones(c, device=dev)
-    beta = bn.bias if bn.bias is not None else torch.zeros(c, device=dev)
-    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
-    if not use_batch:
-        with torch.no_grad():
-            mean = bn.running_mean.float() if pre_bias is None else bn.running_mean.float() - pre_bias.detach().float()
-            rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
-        return _BnActFn.apply(x, gamma, beta, mean, rstd, None, None, relu, 0.0, None, pre_bias)
     group = _sync_group(bn)
     with torch.no_grad():
         if partial is None:
@@ -147,6 +133,30 @@ def bn_act(bn, x, relu=True, partial=None, pre_bias=None):
             unbiased = var64 * (n / (n - 1.0)) if torch.is_tensor(n) else var64 * (n / max(n - 1.0, 1.0))
             bn.running_mean.mul_(1.0 - eaf).add_(mean64.to(bn.running_mean.dtype), alpha=eaf)
             bn.running_var.mul_(1.0 - eaf).add_(unbiased.to(bn.running_var.dtype), alpha=eaf)
+    return stats, count, group
+
+
+def bn_act(bn, x, relu=True, partial=None, pre_bias=None):
+    """act(bn(x)) for x (B, C, L) float32 on the GPU; `partial` (B, C, S, 2): per-slice (sum x, sum x^2) when the
+    producer of x already formed them (fp_front).  `pre_bias` (C,): act(bn(x + pre_bias[:, None])) without the add --
+    the bias of the convolution in front: under batch statistics it cancels in the output (only the running mean sees
+    it, and its gradient is exactly zero), under running statistics it folds into the shift."""
+    if not _covered(bn, x):
+        from .pointnet2.pytorch_utils import batch_norm_nd
+        y = batch_norm_nd(bn, x if pre_bias is None else x + pre_bias.view(1, -1, 1))
+        return torch.relu(y) if relu else y
+    x = x.contiguous()
+    b, c, l = x.shape
+    dev = x.device
+    gamma = bn.weight if bn.weight is not None else torch.ones(c, device=dev)
+    beta = bn.bias if bn.bias is not None else torch.zeros(c, device=dev)
+    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    if not use_batch:
+        with torch.no_grad():
+            mean = bn.running_mean.float() if pre_bias is None else bn.running_mean.float() - pre_bias.detach().float()
+            rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        return _BnActFn.apply(x, gamma, beta, mean, rstd, None, None, relu, 0.0, None, pre_bias)
+    stats, count, group = _batch_statistics(bn, x, gamma, beta, partial, pre_bias)
     return _BnActFn.apply(x, gamma, beta, stats[0], stats[1], stats[2], stats[3], relu, count, group, pre_bias)
 
 
@@ -455,3 +465,50 @@ def softmax_last(x):
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] in (64, 128, 256, 512, 1024) and x.numel() > 0):
         return x.softmax(dim=-1)
     return _SoftmaxLastFn.apply(x)
+
+
+class _BnPoolFn(Function):
+    """max over the last n of relu(bn(y)) for y (B, C, G*n) under batch statistics, the normalised tensor never built."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, stats, n, count):
+        b, c, l = y.shape
+        g = l // n
+        out = torch.empty((b, c, g), dtype=torch.float32, device=y.device)
+        sel = torch.empty((b, c, g), dtype=torch.float32, device=y.device)
+        arg = torch.empty((b, c, g), dtype=torch.uint8, device=y.device)
+        call("geot_bn_pool", y.device, b, c, g, n, 1, ptr(y), ptr(stats[2]), ptr(stats[3]), ptr(out), ptr(sel), ptr(arg))
+        ctx.save_for_backward(y, stats, sel, arg, out)
+        ctx.cfg = (n, count)
+        return out
+
+    @staticmethod
+    def backward(ctx, gp):
+        y, stats, sel, arg, out = ctx.saved_tensors
+        n, count = ctx.cfg
+        b, c, l = y.shape
+        g = l // n
+        mean, rstd, scale = stats[0], stats[1], stats[2]
+        gm = (gp * (out > 0)).contiguous()                                  # gradient of the normalised tensor at arg
+        xh = (sel - mean.view(1, c, 1)) * rstd.view(1, c, 1)
+        s1 = gm.sum(dim=(0, 2), dtype=torch.float64)
+        s2 = (gm * xh).sum(dim=(0, 2), dtype=torch.float64)
+        c1, c2 = (s1 / count).float().contiguous(), (s2 / count).float().contiguous()
+        dx = torch.empty_like(y)
+        call("geot_bn_pool_grad", y.device, b, c, g, n, ptr(y), ptr(gm), ptr(arg), ptr(mean), ptr(rstd), ptr(scale), ptr(c1), ptr(c2),
+             ptr(dx))
+        return dx, s2.float(), s1.float(), None, None, None
+
+
+def bn_relu_max(bn, y, n):
+    """relu(bn(y)) max-pooled over the last n of y (B, C, G*n): (B, C, G).  Training mode of a plain BatchNorm goes through
+    the monotone form (csrc/bnrelu.hip bn_pool: one pass forward besides the statistics, one backward); everything else
+    composes bn_act + max_last."""
+    b, c, l = y.shape
+    fused = (_covered(bn, y) and bn.training and _sync_group(bn) is None and not isinstance(bn, nn.SyncBatchNorm)
+             and bn.weight is not None and bn.bias is not None and 4 <= n <= 256 and n % 4 == 0 and l % n == 0)
+    if not fused:
+        return max_last(bn_act(bn, y, relu=True).view(b, c, l // n, n))
+    y = y.contiguous()
+    stats, count, _ = _batch_statistics(bn, y, bn.weight, bn.bias, None, None)
+    return _BnPoolFn.apply(y, bn.weight, bn.bias, stats, n, count)

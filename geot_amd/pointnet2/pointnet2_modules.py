@@ -45,7 +45,7 @@ def _sa_factored(xyz_flipped, new_xyz, features, idx, mlp, xyz_scale):
     points instead of the npoint x nsample rows (32x fewer at nsample = 32) and neither grouped tensor of the
     reference ((B,3,np,ns), (B,C,np,ns)) nor their concatenation is built; BatchNorm + ReLU of every stage is one
     fused pass each way (fused_norm.bn_act).  Same function as the composed path (tests: 1e-4)."""
-    from ..fused_norm import bn_act, max_last, add_last_broadcast
+    from ..fused_norm import bn_act, max_last, add_last_broadcast, bn_relu_max
     stages = list(mlp.children())
     conv = stages[0].conv
     w = conv.weight.view(conv.out_channels, -1)
@@ -56,6 +56,14 @@ def _sa_factored(xyz_flipped, new_xyz, features, idx, mlp, xyz_scale):
     ns = idx.shape[2]
     y = add_last_broadcast(pointnet2_utils.grouping_operation(p.contiguous(), idx), q).view(b, c1, npoint * ns)
     y = bn_act(stages[0].bn.bn, y, relu=True)
+    last = stages[-1]
+    names = [n for n, _ in last.named_children()]
+    if len(stages) > 1 and names == ["conv", "bn", "activation"] and isinstance(last.activation, nn.ReLU):
+        # the last stage's BatchNorm -> ReLU -> max over nsample without the normalised (B, C, np, ns) tensor
+        y = pt_utils.shared_mlp_nd(stages[1:-1], y)
+        y = pt_utils.conv1x1(last.conv, y) if not isinstance(last.conv, (pt_utils.PointwiseConv1d, pt_utils.PointwiseConv2d)) \
+            else last.conv(y)
+        return bn_relu_max(last.bn.bn, y.view(b, y.shape[1], npoint * ns), ns)
     y = pt_utils.shared_mlp_nd(stages[1:], y)
     return max_last(y.view(b, y.shape[1], npoint, ns))
 

@@ -216,6 +216,17 @@ int geot_poly1_focal_grad(int b, int c, int n, float alpha, float gamma, float e
  * out (rows), arg (rows) uint8 = the first maximum's slot (torch.max semantics); _grad writes dx (rows, n) in full.
  * (Encoder's max over a group's points, transformer.py:127-134; max over nsample of the SA modules.) */
 int geot_segment_max(long long rows, int n, const float *x, float *out, unsigned char *arg, void *stream);
+/* BatchNorm -> ReLU -> max over the n innermost elements of y (b, c, groups, n) without building the normalised tensor
+ * (the last SharedMLP stage + max_pool2d of a SetAbstraction module in training mode, pointnet2_modules.py:57-66): the
+ * affine map is monotone, so out = relu(scale_c sel + shift_c) with sel = the row's maximum (scale_c >= 0) or minimum;
+ * sel and arg (slot of the first extremum) are kept for _grad:  dx_j = k0_c ([j == arg] gm - c1_c - xhat_j c2_c),
+ * gm (b, c, groups) = the pooled output's gradient where the pre-activation was positive, c1 / c2 = the means of the
+ * (sparse) gradient and of gradient * xhat (caller: geot_amd/fused_norm.py bn_relu_max).  n as geot_segment_max. */
+int geot_bn_pool(int b, int c, int groups, int n, int relu, const float *y, const float *scale, const float *shift, float *out,
+                 float *sel, unsigned char *arg, void *stream);
+int geot_bn_pool_grad(int b, int c, int groups, int n, const float *y, const float *gm, const unsigned char *arg,
+                      const float *mean, const float *rstd, const float *k0, const float *c1, const float *c2, float *dx,
+                      void *stream);
 /* out (rows) = the sum of every row, same shape rules: the gradient of a per-group term broadcast over the group's
  * points (Encoder, transformer.py:131-132: feature_global expanded over n) at streaming speed, fixed summation order. */
 int geot_segment_sum(long long rows, int n, const float *x, float *out, void *stream);

@@ -396,6 +396,31 @@ def test_softmax_last_gradient():
         assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-6 * (float(res[0][1].abs().max()) + 1e-9) + 1e-7
 
 
+def test_bn_relu_max_equals_batchnorm_relu_maxpool():
+    """fused_norm.bn_relu_max (monotone form: relu(a sel + b), sel = max or min by the sign of a) vs BatchNorm -> ReLU ->
+    max over the last n in fp64: output, dx, d gamma, d beta, running statistics; both signs of gamma, zero gamma."""
+    from geot_amd.fused_norm import bn_relu_max
+    dev = torch.device("cuda:0")
+    b, c, g, n = 3, 24, 77, 32
+    gen = torch.Generator().manual_seed(12)
+    y0 = (torch.randn(b, c, g * n, generator=gen) * 2 + 0.3).to(dev)
+    up = torch.randn(b, c, g, generator=gen).to(dev)
+    ref, ours = torch.nn.BatchNorm1d(c).to(dev).double(), torch.nn.BatchNorm1d(c).to(dev)
+    with torch.no_grad():
+        w = torch.randn(c, generator=gen); w[3] = 0.0
+        ours.weight.copy_(w); ours.bias.copy_(torch.randn(c, generator=gen))
+    ref.load_state_dict(ours.state_dict())
+    res = []
+    for mod, fused in ((ref, False), (ours, True)):
+        y = (y0.double() if not fused else y0.clone()).requires_grad_(True)
+        out = bn_relu_max(mod, y, n) if fused else torch.relu(mod(y)).view(b, c, g, n).max(-1)[0]
+        (out * up.to(out.dtype)).sum().backward()
+        res.append([t.double() for t in (out.detach(), y.grad, mod.weight.grad, mod.bias.grad, mod.running_mean, mod.running_var)])
+    for name, a, f in zip(("out", "dy", "dgamma", "dbeta", "running_mean", "running_var"), *res):
+        scale = float(a.abs().max()) + 1e-12
+        assert float((a - f).abs().max()) <= 3e-5 * scale + 1e-6, (name, float((a - f).abs().max()), scale)
+
+
 def test_fp_front_equals_interpolate_plus_skip_conv():
     """fused_norm.fp_front (interpolation + skip 1x1 conv + BatchNorm sums) vs three_interpolate + bmm, fwd and bwd."""
     from geot_amd.fused_norm import fp_front
