@@ -223,7 +223,6 @@ __global__ __launch_bounds__(MAXW >= 8 ? 512 : SA_WAVES * 64) void sa_group_mlp_
         // a workgroup owns a contiguous run of groups and its waves walk it together: the 4-byte stores of one
         // output column then land next to each other in the SAME L2 within a few tiles and leave it as whole lines
         // (interleaving the groups over workgroups scattered every line over all eight L2s: partial-sector writes)
-        const int chunk = (int)((ngroups + gridDim.x - 1) / gridDim.x);
         auto load = [&](SaRow &R, int g) {
 #ifdef GEOT_SA_LAB_NOGATHER
             for (int x = 0; x < 3; ++x) { R.p[x] = 0.01f * r; R.q[x] = 0.f; }
