@@ -186,3 +186,29 @@ def test_capture_ntm_half_step(overlap):
         return (corr.detach(), loss.detach(), nt.ema_t) + tuple(grads)
     _check(fn, [xyz, pw, ps], list(_ntm_inputs(2, 6000, 15)))
     assert len(names) == len(grads)
+
+
+def test_capture_lean_transformer_block_and_losses():
+    """The small kernels of DESIGN 4.10 (residual + LayerNorm, head split, soft-max gradient, Linear bias gradients,
+    fused Poly-1 focal loss): two encoder blocks forward + loss + backward captured as one graph, replay == eager."""
+    from geot_amd.openpoints.models.backbone.transformer import TransformerEncoder_h
+    from geot_amd.openpoints.loss import Poly1FocalLoss
+    torch.manual_seed(0)
+    enc = TransformerEncoder_h(embed_dim=384, depth=2, num_heads=4, drop_path_rate=0.0, extract_layers=[2]).to(DEV)
+    for blk in enc.blocks:
+        blk.attn.lean = blk.mlp.lean = True
+    head = torch.nn.Linear(384, 17).to(DEV)
+    crit = Poly1FocalLoss()
+    x, pos = torch.randn(2, 512, 384, device=DEV), torch.randn(2, 512, 384, device=DEV)
+    labels = torch.randint(0, 17, (2, 512), device=DEV)
+    params = list(enc.parameters()) + list(head.parameters())
+    grads = [torch.zeros_like(p) for p in params]
+
+    def fn():
+        feats = enc(x, pos)[0]
+        loss = crit(head(feats).transpose(1, 2).contiguous(), labels)
+        gs = torch.autograd.grad(loss, params)
+        for dst, g in zip(grads, gs):
+            dst.copy_(g)
+        return (loss.detach(), feats.detach()) + tuple(grads)
+    _check(fn, [x, pos], [torch.randn(2, 512, 384, device=DEV), torch.randn(2, 512, 384, device=DEV)])
