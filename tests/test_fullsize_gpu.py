@@ -229,3 +229,40 @@ def test_gather_gradients_of_the_model_are_bit_reproducible():
         outs.append((p.grad.clone(), q.grad.clone(), norm.weight.grad.clone()))
         norm.zero_grad()
     assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
+def test_fixmatch_iteration_at_the_configured_sizes():
+    """BASELINE configs[4] as bench.py runs it: the full PointTransformer_seg_T (depth 12, 512 x 32 groups, targets
+    8192 / 4096 / 2048) as student and frozen teacher, B_l = B_u = 2 clouds of 24 000 points, two FixMatch+NTM
+    iterations: every loss finite, the 3-D loss non-negative, the EMA transition matrix a row-stochastic mixture, both
+    optimisers stepped; and the same two iterations with the teacher on the main stream give the same losses."""
+    import torch
+    from geot_amd import train_step as ts
+    from geot_amd.synth import make_batch
+    dev = torch.device("cuda:0")
+    xyz, lab = make_batch(2, 24000, start_index=0)
+    pos, target = torch.from_numpy(xyz).to(dev), torch.from_numpy(lab).long().to(dev)
+    xu = torch.from_numpy(make_batch(2, 24000, start_index=7)[0]).to(dev)
+    xs = (xu * 1.05).contiguous()
+    z = torch.zeros(2, 1, dtype=torch.long, device=dev)
+    data = {"pos": pos, "x": pos.transpose(1, 2).contiguous(), "cls": z, "y": target}
+    data_u = {"pos_w": xu, "x_w": xu.transpose(1, 2).contiguous(), "cls_w": z, "pos_s": xs,
+              "x_s": xs.transpose(1, 2).contiguous(), "cls_s": z, "raw_pos": xu}
+    runs = []
+    for overlap in (True, False):
+        torch.manual_seed(11)
+        trainer = ts.build_fixmatch(dev, use_ddp=False)
+        trainer.overlap_teacher = overlap
+        w0 = [l.weight.detach().clone() for l in trainer.T_predictor.T_predictor.fc]
+        torch.manual_seed(12)
+        out = [trainer(data, data_u) for _ in range(2)]
+        torch.cuda.synchronize()
+        for o in out:
+            assert all(bool(torch.isfinite(v)) for v in o.values()), o
+            assert float(o["threed"]) >= 0
+        rows = trainer.ema_t.sum(1)
+        assert torch.allclose(rows, torch.ones_like(rows), atol=1e-3), rows
+        assert any(not torch.equal(a, l.weight) for a, l in zip(w0, trainer.T_predictor.T_predictor.fc))
+        runs.append([float(v) for o in out for v in o.values()])
+    for a, b in zip(*runs):
+        assert abs(a - b) <= 5e-5 * abs(a) + 1e-7, runs
