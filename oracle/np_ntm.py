@@ -62,17 +62,22 @@ def gaussian(x, mu, s):
     return (1.0 / (s * np.sqrt(2 * np.pi))) * np.exp(-((x - mu) ** 2) / (2 * s ** 2))
 
 
-def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999):
+def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, filter_outlier=False, outlier_q=0.97):
     """eta (B_u, C, N) softmax of the weak view, sigma (C,), ema_t (C,C).
+    filter_outlier (train.py:510-517): class cc's probabilities at or above their q-quantile are zeroed IN PLACE in
+    the working copy before its arg-max, so the anchor rows read afterwards see classes 0..cc already filtered.
     Returns dict(class_T, prior_T, new_T, ema_t_corr, ema_t_next).  `X / X.sum(1)` broadcasts the
     row sums along the LAST axis (column j divided by row-sum j): reference quirk, reproduced."""
-    eta = np.asarray(eta, dtype=np.float64)
+    eta = np.array(eta, dtype=np.float64)        # a copy: the filter writes into it, as the reference's clone() (:507)
     sigma = np.asarray(sigma, dtype=np.float64)
     ema_t = np.asarray(ema_t, dtype=np.float64)
     B, C, N = eta.shape
     class_T = np.empty((C, C))
     prior_T = np.zeros((C, C))
     for cc in range(C):
+        if filter_outlier:
+            view = eta[:, cc, :]
+            view[view >= np.quantile(view, outlier_q)] = 0.0          # torch.quantile: linear interpolation, as numpy
         flat = eta[:, cc, :].reshape(B * N)
         best = int(np.argmax(flat))                                   # first maximum
         class_T[cc] = eta[best // N, :, best % N]
