@@ -15,6 +15,7 @@
 // C is a template parameter (the reference fixes num_classes = 17).
 #include "geot_common.h"
 #include "geot_hip.h"
+#include "ntm_generic.h"
 #include <cstdlib>
 
 namespace geot {
@@ -508,13 +509,14 @@ __global__ __launch_bounds__(NTM_THREADS) void ntm_correct_fwd_kernel(
 //           with coef_i = 2 * gscale / (sum_j w_ij + 1e-3)     (gscale = upstream grad / (B*N))
 // SIGNED (feature_space_loss, insT_loss.py:9-58): w_ij = (label_i == label_j ? +1 : -1) * exp(..) over
 // pd-dimensional features and the per-point sum is NOT normalised (the caller divides by B*N*k).
-template <int CC, bool BACKWARD, bool SIGNED>
+// R = registers per lane for one row of C*C floats (ceil(CC / 64)); CC itself is a run-time argument, so one
+// instantiation serves a range of class counts (R = 5: up to 17 classes, 2: up to 11, 8: up to 22, 16: up to 32).
+template <int R, bool BACKWARD, bool SIGNED>
 __global__ __launch_bounds__(256) void threed_loss_kernel(
-    int total_pts, int n, int k, int pd, float inv2s2, float gscale, const float *__restrict__ pos,
+    int total_pts, int n, int k, int pd, int CC, float inv2s2, float gscale, const float *__restrict__ pos,
     const int *__restrict__ labels, const float *__restrict__ T, const int *__restrict__ nbr,
     const int *__restrict__ order, float *__restrict__ per_point, float *__restrict__ grad_T)
 {
-    constexpr int R = (CC + 63) / 64;
     const int lane = lane_id();
     // XCD-aware walk of the (spatially sorted) point order: workgroups are dealt round-robin to the 8 XCDs,
     // so XCD x takes the x-th eighth of the order and its private L2 caches one region of the cloud instead of
@@ -1055,7 +1057,31 @@ static inline int ntm_blocks(int total_pts)
 
 using namespace geot;
 
-#define GEOT_NTM_C 17 /* the reference's num_classes (cfgs/tooth_semi/default.yaml:29) */
+#define GEOT_NTM_C 17 /* the reference's num_classes (cfgs/tooth_semi/default.yaml:29): the specialised kernels */
+
+// Any other class count 1..GEN_MAXC runs the run-time-C kernels of ntm_generic.hip / the R-bucketed graph kernel.
+static inline bool ntm_generic_c(int c) { return c >= 1 && c <= GEN_MAXC && c != GEOT_NTM_C; }
+
+template <bool BWD, bool SIGNED>
+static hipError_t launch_threed_plain(int b, int n, int c, int k, int pd, float sigma, float gscale, const float *pos,
+                                      const int *labels, const float *T, const int *nbr, const int *order,
+                                      float *per_point, float *grad_T, hipStream_t s)
+{
+    int blocks = (b * n + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
+    const int cc = c * c, r = (cc + 63) / 64;
+    const float inv2s2 = 1.f / (2.f * sigma * sigma);
+#define GEOT_TL_PLAIN(R)                                                                                            \
+    hipLaunchKernelGGL((threed_loss_kernel<R, BWD, SIGNED>), dim3(blocks), dim3(256), 0, s, b * n, n, k, pd, cc, inv2s2, \
+                       gscale, pos, labels, T, nbr, order, per_point, grad_T)
+    if (r <= 2) GEOT_TL_PLAIN(2);
+    else if (r <= 5) GEOT_TL_PLAIN(5);
+    else if (r <= 8) GEOT_TL_PLAIN(8);
+    else GEOT_TL_PLAIN(16);
+#undef GEOT_TL_PLAIN
+    return hipGetLastError();
+}
 
 static inline int sig_mfma_blocks(long long total_pts, int per_cu)
 {
@@ -1067,8 +1093,9 @@ constexpr int SIG_FWD_PER_CU = 4, SIG_BWD_PER_CU = 2; // forward: 37 KB of LDS, 
 GEOT_EXPORT int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const float *W, const float *cm,
                                     float *ins_T, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((c != GEOT_NTM_C && !ntm_generic_c(c)) || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
+    if (c != GEOT_NTM_C) return gen_sig_t_mean(false, b, n, c, p, W, cm, nullptr, ins_T, (hipStream_t)stream);
     constexpr int C = GEOT_NTM_C;
     size_t lds = (size_t)SigMfma<C>::LDS_FLOATS_FWD * sizeof(float);
     hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, false>, lds);
@@ -1106,8 +1133,9 @@ GEOT_EXPORT int geot_ntm_sig_t_mean_grad_raw(int b, int n, int c, const float *p
                                              const float *cm, const float *grad_ins_T, float *grad_raw,
                                              void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((c != GEOT_NTM_C && !ntm_generic_c(c)) || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
+    if (c != GEOT_NTM_C) return gen_sig_t_mean(true, b, n, c, p, W, cm, grad_ins_T, grad_raw, (hipStream_t)stream);
     constexpr int C = GEOT_NTM_C;
     size_t lds = (size_t)(C * C * C + C * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
     hipError_t e = set_lds(sig_t_mean_kernel<C, true>, lds);
@@ -1120,8 +1148,9 @@ GEOT_EXPORT int geot_ntm_sig_t_mean_grad_raw(int b, int n, int c, const float *p
 GEOT_EXPORT int geot_ntm_correct(int b, int n, int c, float lam, const float *logits, const float *ins_T,
                                  const float *ema_t, float *out, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((c != GEOT_NTM_C && !ntm_generic_c(c)) || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
+    if (c != GEOT_NTM_C) return gen_correct_fwd(b, n, c, lam, logits, ins_T, ema_t, out, (hipStream_t)stream);
     constexpr int C = GEOT_NTM_C;
     size_t lds = (size_t)(C * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
     hipError_t e = set_lds(ntm_correct_fwd_kernel<C>, lds);
@@ -1136,8 +1165,11 @@ GEOT_EXPORT int geot_ntm_correct_grad(int b, int n, int c, float lam, const floa
                                       float *grad_logits, float *grad_ins_T, float *grad_ema_t,
                                       void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((c != GEOT_NTM_C && !ntm_generic_c(c)) || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
+    if (c != GEOT_NTM_C)
+        return gen_correct_bwd(b, n, c, lam, logits, ins_T, ema_t, grad_out, grad_logits, grad_ins_T, grad_ema_t,
+                               (hipStream_t)stream);
     constexpr int C = GEOT_NTM_C;
     size_t lds = (size_t)(C * C + 4 + NTM_TILE * NtmLds<C>::STRIDE) * sizeof(float);
     hipError_t e = set_lds(ntm_correct_bwd_kernel<C>, lds);
@@ -1191,9 +1223,9 @@ GEOT_EXPORT int geot_ntm_correct_grad_ws(int b, int n, int c, float lam, const f
                                          float *grad_logits, float *grad_ins_T, float *grad_ema_t,
                                          float *workspace, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0) return hipErrorInvalidValue;
+    if ((c != GEOT_NTM_C && !ntm_generic_c(c)) || b < 0 || n < 0) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
-    if (!workspace)
+    if (!workspace || c != GEOT_NTM_C)
         return geot_ntm_correct_grad(b, n, c, lam, logits, ins_T, ema_t, grad_out, grad_logits, grad_ins_T, grad_ema_t,
                                      stream);
     constexpr int C = GEOT_NTM_C;
@@ -1212,24 +1244,21 @@ GEOT_EXPORT int geot_ntm_threed_loss(int b, int n, int c, int k, float sigma, co
                                      const int *labels, const float *ins_T, const int *nbr,
                                      float *per_point, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
+    if (c < 1 || c > GEN_MAXC || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
-    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
-    int blocks = (b * n + 3) / 4;
-    if (blocks > 16384) blocks = 16384;
-    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
-    hipLaunchKernelGGL((threed_loss_kernel<CC, false, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, 3, 1.f / (2.f * sigma * sigma), 0.f, positions, labels, ins_T, nbr, nullptr,
-                       per_point, nullptr);
-    return hipGetLastError();
+    return launch_threed_plain<false, false>(b, n, c, k, 3, sigma, 0.f, positions, labels, ins_T, nbr, nullptr, per_point,
+                                             nullptr, (hipStream_t)stream);
 }
 
 GEOT_EXPORT int geot_ntm_threed_loss_ord(int b, int n, int c, int k, float sigma, const float *positions,
                                          const int *labels, const float *ins_T, const int *nbr, const int *order,
                                          float *per_point, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
+    if ((c != GEOT_NTM_C && !ntm_generic_c(c)) || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
+    if (c != GEOT_NTM_C)   // the one-point-per-wave kernel walks the same order
+        return launch_threed_plain<false, false>(b, n, c, k, 3, sigma, 0.f, positions, labels, ins_T, nbr, order, per_point,
+                                                 nullptr, (hipStream_t)stream);
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
     const char *ge = getenv("GEOT_NTM_G");
     const int Gsel = ge ? atoi(ge) : 4;
@@ -1263,10 +1292,10 @@ GEOT_EXPORT int geot_ntm_threed_loss_grad_ws(int b, int n, int c, int k, float s
                                              const int *nbr, const int *order, float *grad_ins_T,
                                              void *workspace, long long ws_bytes, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
+    if ((c != GEOT_NTM_C && !ntm_generic_c(c)) || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
     if ((long long)b * n * 64 > 0x7fffffffLL) return hipErrorInvalidValue;
-    if (!workspace || ws_bytes < geot_ntm_threed_loss_ws_bytes(b, n, k))
+    if (c != GEOT_NTM_C || !workspace || ws_bytes < geot_ntm_threed_loss_ws_bytes(b, n, k))
         return geot_ntm_threed_loss_grad(b, n, c, k, sigma, grad_scale, positions, labels, ins_T, nbr, grad_ins_T,
                                          stream);
     constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
@@ -1380,48 +1409,30 @@ GEOT_EXPORT int geot_ntm_feature_loss(int b, int n, int c, int k, int feat_dim, 
                                       const int *labels, const float *ins_T, const int *nbr,
                                       float *per_point, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || feat_dim < 1 || !(sigma > 0.f))
+    if (c < 1 || c > GEN_MAXC || b < 0 || n < 0 || k < 1 || k > 64 || feat_dim < 1 || !(sigma > 0.f))
         return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
-    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
-    int blocks = (b * n + 3) / 4;
-    if (blocks > 16384) blocks = 16384;
-    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
-    hipLaunchKernelGGL((threed_loss_kernel<CC, false, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), 0.f, feats, labels, ins_T, nbr, nullptr,
-                       per_point, nullptr);
-    return hipGetLastError();
+    return launch_threed_plain<false, true>(b, n, c, k, feat_dim, sigma, 0.f, feats, labels, ins_T, nbr, nullptr, per_point,
+                                            nullptr, (hipStream_t)stream);
 }
 
 GEOT_EXPORT int geot_ntm_feature_loss_grad(int b, int n, int c, int k, int feat_dim, float sigma,
                                            float grad_scale, const float *feats, const int *labels,
                                            const float *ins_T, const int *nbr, float *grad_ins_T, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || feat_dim < 1 || !(sigma > 0.f))
+    if (c < 1 || c > GEN_MAXC || b < 0 || n < 0 || k < 1 || k > 64 || feat_dim < 1 || !(sigma > 0.f))
         return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
-    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
-    int blocks = (b * n + 3) / 4;
-    if (blocks > 16384) blocks = 16384;
-    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
-    hipLaunchKernelGGL((threed_loss_kernel<CC, true, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, feat_dim, 1.f / (2.f * sigma * sigma), grad_scale, feats, labels, ins_T,
-                       nbr, nullptr, nullptr, grad_ins_T);
-    return hipGetLastError();
+    return launch_threed_plain<true, true>(b, n, c, k, feat_dim, sigma, grad_scale, feats, labels, ins_T, nbr, nullptr,
+                                           nullptr, grad_ins_T, (hipStream_t)stream);
 }
 
 GEOT_EXPORT int geot_ntm_threed_loss_grad(int b, int n, int c, int k, float sigma, float grad_scale,
                                           const float *positions, const int *labels, const float *ins_T,
                                           const int *nbr, float *grad_ins_T, void *stream)
 {
-    if (c != GEOT_NTM_C || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
+    if (c < 1 || c > GEN_MAXC || b < 0 || n < 0 || k < 1 || k > 64 || !(sigma > 0.f)) return hipErrorInvalidValue;
     if ((long long)b * n == 0) return hipSuccess;
-    constexpr int CC = GEOT_NTM_C * GEOT_NTM_C;
-    int blocks = (b * n + 3) / 4;
-    if (blocks > 16384) blocks = 16384;
-    blocks = (blocks + 7) & ~7; // the XCD-chunked walk needs a multiple of 8 workgroups
-    hipLaunchKernelGGL((threed_loss_kernel<CC, true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       b * n, n, k, 3, 1.f / (2.f * sigma * sigma), grad_scale, positions, labels, ins_T, nbr,
-                       nullptr, nullptr, grad_ins_T);
-    return hipGetLastError();
+    return launch_threed_plain<true, false>(b, n, c, k, 3, sigma, grad_scale, positions, labels, ins_T, nbr, nullptr,
+                                            nullptr, grad_ins_T, (hipStream_t)stream);
 }

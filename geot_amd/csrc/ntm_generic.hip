@@ -1,0 +1,185 @@
+// ntm_generic.hip -- the per-point transition-matrix kernels for ANY class count 2 <= C <= 32.
+//
+// The reference builds `nclasses` Linear(2C -> C) heads for whatever nclasses the config names
+// (openpoints/models/backbone/transformer.py:1104-1110) and its losses take num_classes as an argument
+// (utils/insT_loss.py:62-67).  ntm.hip holds the kernels specialised for the configured tooth label set
+// (C = 17: MFMA tiles of 289 columns, LDS tiles of 32 x 289 floats); this file serves every other count with
+// one mapping that needs no compile-time C:
+//
+//     one wave per point, a half-wave (32 lanes) per matrix row, lane = column  (C <= 32)
+//
+// so the L1 norms / dot products over a row are five xor-shuffles inside the half-wave, a row of T_i is one
+// contiguous 4C-byte access of the half-wave (two adjacent rows per wave instruction), and nothing goes
+// through shared memory except the read-only weights.  Lane efficiency is C/32; these are streaming kernels
+// over (B*N, C, C) and stay HBM-bound from C ~ 12 up.  Same arithmetic, same operation order per element as the
+// specialised kernels (one reciprocal per row).
+#include "geot_common.h"
+#include "ntm_generic.h"
+
+namespace geot {
+
+__device__ __forceinline__ float half_sum(float v)   // sum over the 32 lanes of this lane's half-wave
+{
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- sig_t_mean forward / d raw ---------------------------------------------------------------------------
+// raw[kk][o] = sum_j p_j W[kk][o][j] + sum_j cm[kk][j] W[kk][o][C+j];  clamp to [1e-5, 1-1e-5];  L1-normalise over o.
+// BACKWARD: out = d raw = [raw inside the clamp] * (g - sum_o g tn) / den   (the d/dW GEMM is the caller's).
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void gen_sig_t_mean_kernel(int total_pts, int n, int c, const float *__restrict__ p,
+                                                             const float *__restrict__ W, const float *__restrict__ cm,
+                                                             const float *__restrict__ grad_out, float *__restrict__ out)
+{
+    extern __shared__ float gen_lds[];
+    const int cc = c * c;
+    float *Wl = gen_lds;          // [j][kk*c + o] = W[kk][o][j]   (lanes o read consecutive words)
+    float *bias = Wl + c * cc;    // [kk*c + o]
+    for (int e = threadIdx.x; e < c * cc; e += 256) {
+        const int j = e / cc, col = e - j * cc;
+        Wl[e] = W[(size_t)col * 2 * c + j];
+    }
+    for (int col = threadIdx.x; col < cc; col += 256) {
+        const int kk = col / c;
+        float acc = 0.f;
+        for (int j = 0; j < c; ++j) acc += cm[kk * c + j] * W[(size_t)col * 2 * c + c + j];
+        bias[col] = acc;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, o = lane & 31, h = lane >> 5;
+    const bool live_o = o < c;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total_pts; i += gridDim.x * 4) {
+        const int b = i / n, ni = i - b * n;
+        const float pl = lane < c ? p[((size_t)b * c + lane) * n + ni] : 0.f;   // lane j holds p_j
+        for (int k0 = 0; k0 < c; k0 += 2) {
+            const int kk = k0 + h;
+            const bool live = live_o && kk < c;
+            const int col = live ? kk * c + o : 0;
+            float raw = live ? bias[col] : 0.f;
+            for (int j = 0; j < c; ++j) {
+                const float pj = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(pl), j));
+                raw = fmaf(pj, live ? Wl[j * cc + col] : 0.f, raw);
+            }
+            const float cl = live ? fminf(fmaxf(raw, 1e-5f), 1.f - 1e-5f) : 0.f;   // clamped values are positive
+            const float rden = 1.f / fmaxf(half_sum(cl), 1e-12f);
+            if (!BACKWARD) {
+                if (live) out[(size_t)i * cc + col] = cl * rden;
+            } else {
+                const float g = live ? grad_out[(size_t)i * cc + col] : 0.f;
+                const float dot = half_sum(g * (cl * rden));
+                const bool inside = raw >= 1e-5f && raw <= 1.f - 1e-5f;
+                if (live) out[(size_t)i * cc + col] = inside ? (g - dot) * rden : 0.f;
+            }
+        }
+    }
+}
+
+// ---- logit correction (train.py:549-552) --------------------------------------------------------------------
+// v = lam*E + (1-lam)*T_i;  tn = v / max(sum_c |v|, eps);  out[c] = sum_r logit[r] * tn[r][c]
+__global__ __launch_bounds__(256) void gen_correct_fwd_kernel(int total_pts, int n, int c, float lam,
+                                                              const float *__restrict__ logits,
+                                                              const float *__restrict__ insT, const float *__restrict__ E,
+                                                              float *__restrict__ out)
+{
+    const int cc = c * c;
+    const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total_pts; i += gridDim.x * 4) {
+        const int b = i / n, ni = i - b * n;
+        float acc = 0.f;
+        for (int r0 = 0; r0 < c; r0 += 2) {
+            const int r = r0 + h;
+            const bool live = col < c && r < c;
+            const float v = live ? lam * E[r * c + col] + (1.f - lam) * insT[(size_t)i * cc + r * c + col] : 0.f;
+            const float s = half_sum(fabsf(v));
+            const float l = r < c ? logits[((size_t)b * c + r) * n + ni] : 0.f;
+            acc = fmaf(l / fmaxf(s, 1e-12f), v, acc);
+        }
+        acc += __shfl_xor(acc, 32);     // even rows + odd rows
+        if (lane < c) out[((size_t)b * c + lane) * n + ni] = acc;
+    }
+}
+
+// Backward: grad_logits[r] = sum_c tn[r][c] go[c];  d v = (l go - sign(v) l gl) / den;  grad_T = (1-lam) d v;
+// grad_E += lam * sum_points d v -- accumulated per wave in its own LDS copy (plain read-modify-write: a lane
+// always meets the same address), folded into grad_E with one atomic per entry and workgroup.
+__global__ __launch_bounds__(256) void gen_correct_bwd_kernel(int total_pts, int n, int c, float lam,
+                                                              const float *__restrict__ logits,
+                                                              const float *__restrict__ insT, const float *__restrict__ E,
+                                                              const float *__restrict__ grad_out,
+                                                              float *__restrict__ grad_logits, float *__restrict__ grad_insT,
+                                                              float *__restrict__ grad_E)
+{
+    extern __shared__ float gen_lds[];
+    const int cc = c * c;
+    float *eacc = gen_lds + (threadIdx.x >> 6) * cc;      // [4 waves][cc]
+    for (int e = threadIdx.x; e < 4 * cc; e += 256) gen_lds[e] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, col = lane & 31, h = lane >> 5;
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < total_pts; i += gridDim.x * 4) {
+        const int b = i / n, ni = i - b * n;
+        const float go = col < c ? grad_out[((size_t)b * c + col) * n + ni] : 0.f;
+        for (int r0 = 0; r0 < c; r0 += 2) {
+            const int r = r0 + h;
+            const bool live = col < c && r < c;
+            const float v = live ? lam * E[r * c + col] + (1.f - lam) * insT[(size_t)i * cc + r * c + col] : 0.f;
+            const float s = half_sum(fabsf(v));
+            const float rden = 1.f / fmaxf(s, 1e-12f);
+            const float l = r < c ? logits[((size_t)b * c + r) * n + ni] : 0.f;
+            const float gl = half_sum((v * rden) * go);
+            if (col == 0 && r < c) grad_logits[((size_t)b * c + r) * n + ni] = gl;
+            const float sg = v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f);
+            const float dv = s > 1e-12f ? (l * go - sg * (l * gl)) * rden : l * go * rden;
+            if (live) {
+                grad_insT[(size_t)i * cc + r * c + col] = (1.f - lam) * dv;
+                eacc[r * c + col] += lam * dv;
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cc; e += 256)
+        atomicAdd(grad_E + e, (gen_lds[e] + gen_lds[cc + e]) + (gen_lds[2 * cc + e] + gen_lds[3 * cc + e]));
+}
+
+static inline int gen_blocks(long long total_pts)
+{
+    long long blocks = (total_pts + 3) / 4;
+    return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));   // 8 workgroups per CU, grid-stride beyond
+}
+
+hipError_t gen_sig_t_mean(bool backward, int b, int n, int c, const float *p, const float *W, const float *cm,
+                          const float *grad_out, float *out, hipStream_t s)
+{
+    const size_t lds = (size_t)(c + 1) * c * c * sizeof(float);        // 135 KB at C = 32
+    const void *fn = backward ? (const void *)gen_sig_t_mean_kernel<true> : (const void *)gen_sig_t_mean_kernel<false>;
+    hipError_t e = allow_big_lds(fn, lds);
+    if (e != hipSuccess) return e;
+    // few, fat workgroups: each stages the (C+1) C^2 weight floats once
+    long long blocks = ((long long)b * n + 3) / 4;
+    const long long cap = lds > 64 * 1024 ? 256 : 512;
+    if (blocks > cap) blocks = cap;
+    if (backward)
+        hipLaunchKernelGGL(gen_sig_t_mean_kernel<true>, dim3((int)blocks), dim3(256), lds, s, b * n, n, c, p, W, cm, grad_out, out);
+    else
+        hipLaunchKernelGGL(gen_sig_t_mean_kernel<false>, dim3((int)blocks), dim3(256), lds, s, b * n, n, c, p, W, cm, grad_out, out);
+    return hipGetLastError();
+}
+
+hipError_t gen_correct_fwd(int b, int n, int c, float lam, const float *logits, const float *insT, const float *E,
+                           float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(gen_correct_fwd_kernel, dim3(gen_blocks((long long)b * n)), dim3(256), 0, s, b * n, n, c, lam, logits,
+                       insT, E, out);
+    return hipGetLastError();
+}
+
+hipError_t gen_correct_bwd(int b, int n, int c, float lam, const float *logits, const float *insT, const float *E,
+                           const float *grad_out, float *grad_logits, float *grad_insT, float *grad_E, hipStream_t s)
+{
+    hipLaunchKernelGGL(gen_correct_bwd_kernel, dim3(gen_blocks((long long)b * n)), dim3(256), (size_t)4 * c * c * sizeof(float), s,
+                       b * n, n, c, lam, logits, insT, E, grad_out, grad_logits, grad_insT, grad_E);
+    return hipGetLastError();
+}
+
+} // namespace geot

@@ -25,12 +25,13 @@ from .ext._common import f32, i32, same_device, need, call, ptr
 from .knn_cuda import knn_sorted
 
 LABEL_PROJ = [0, 8, 7, 6, 5, 4, 3, 2, 1, 9, 10, 11, 12, 13, 14, 15, 16]  # train.py:48
-NTM_CLASSES = len(LABEL_PROJ)   # = GEOT_NTM_C in include/geot_hip.h: the per-point kernels are built for this count
+NTM_CLASSES = len(LABEL_PROJ)   # = GEOT_NTM_C in include/geot_hip.h: the class count the specialised kernels are built for
+NTM_MAX_CLASSES = 32            # any other count up to here runs the run-time-C kernels (csrc/ntm_generic.hip)
 
 
 def _need_ntm_classes(c, what):
-    need(c == NTM_CLASSES, "%s: the per-point NTM kernels are built for %d classes (the tooth label set, train.py:48; "
-                           "include/geot_hip.h GEOT_NTM_C), got %d" % (what, NTM_CLASSES, c))
+    need(1 <= c <= NTM_MAX_CLASSES, "%s: the per-point NTM kernels take 1..%d classes (a half-wave per matrix row; "
+                                    "include/geot_hip.h GEOT_NTM_MAX_C), got %d" % (what, NTM_MAX_CLASSES, c))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -54,6 +55,14 @@ class _SigTMeanFn(Function):
         p, cm, W = ctx.saved_tensors
         b, c, n = p.shape
         g = grad_out.contiguous()
+        if c != NTM_CLASSES:
+            # run-time class count: d raw from the generic kernel, then ONE library GEMM  G = d raw^T [p | 1]
+            # (columns C..2C-1 of a head see the constant cm row: G[:, C] * cm[kk])
+            raw = torch.empty_like(g)
+            call("geot_ntm_sig_t_mean_grad_raw", p.device, b, n, c, ptr(p), ptr(W), ptr(cm), ptr(g), ptr(raw))
+            aug = torch.cat([p.permute(0, 2, 1).reshape(b * n, c), p.new_ones((b * n, 1))], dim=1)
+            G = torch.mm(raw.view(b * n, c * c).t(), aug)                   # (C*C, C + 1)
+            return None, None, torch.cat([G[:, :c].reshape(c, c, c), G[:, c].reshape(c, c, 1) * cm.unsqueeze(1)], dim=2)
         # the Linear heads' weight gradient, fused: d raw is formed on chip and contracted with [p_i | 1]
         # by a second MFMA GEMM (train.py never needs d/dp: the predictor's input is detached)
         lib = _lib.load()
@@ -282,6 +291,7 @@ class _CorrectFn(Function):
         gl = torch.empty_like(logits)
         gi = torch.empty_like(ins_T)
         ge = torch.zeros_like(ema_t)
+        # (the workspace carries per-workgroup partial sums of grad_ema_t for the 17-class kernel; other counts ignore it)
         ws = torch.empty(int(_lib.load().geot_ntm_correct_ws_floats(b, n)), dtype=torch.float32, device=logits.device)
         call("geot_ntm_correct_grad_ws", logits.device, b, n, c, ctx.lam, ptr(logits), ptr(ins_T), ptr(ema_t),
              ptr(g), ptr(gl), ptr(gi), ptr(ge), ptr(ws))
@@ -314,6 +324,8 @@ class _ThreeDLossFn(Function):
         if order is None:
             order = spatial_order(positions)      # processing order only: neighbour rows then hit L2
         mode = os.environ.get("GEOT_NTM_GRAD", "graph")   # graph | gather | atomic (A/B tests)
+        if c != NTM_CLASSES:
+            mode = "atomic"      # the reverse-adjacency kernels are built for the 17-class rows; other counts scatter
         graph = None
         if ctx.needs_input_grad[2] and mode == "graph":
             # the forward pass leaves the reverse adjacency behind: the backward is then the gather alone

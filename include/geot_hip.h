@@ -26,6 +26,7 @@ extern "C" {
 #endif
 
 #define GEOT_ABI_VERSION 4
+#define GEOT_NTM_MAX_C 32   /* largest class count of the geot_ntm_* entry points */
 
 /* ABI version / diagnostics. */
 int geot_abi_version(void);
@@ -358,7 +359,13 @@ int geot_sa_group_mlp_max(int b, int n, int npoint, int nsample, int c_feat, con
                           const float *params, float *out, void *stream);
 
 /* ---- NTM: per-point instance-dependent transition matrix ------
- * c must be 17 (the reference's num_classes, cfgs/tooth_semi/default.yaml:29).
+ * c = class count, 1 <= c <= GEOT_NTM_MAX_C (32).  c == 17 (the reference's num_classes,
+ * cfgs/tooth_semi/default.yaml:29) runs the kernels specialised for it (MFMA / LDS tiles of 17 x 17 rows); every
+ * other count -- the reference builds its heads and losses for any nclasses (transformer.py:1104-1110,
+ * insT_loss.py:62-67) -- runs run-time-C kernels with the same arithmetic.  Three entry points exist for c == 17
+ * only and return hipErrorInvalidValue otherwise, each with a generic counterpart: geot_ntm_sig_t_mean_grad_w
+ * (use _grad_raw + one GEMM), geot_ntm_threed_loss_fwd_graph / _grad_graph (use geot_ntm_threed_loss[_ord] +
+ * geot_ntm_threed_loss_grad).
  *
  * sig_t_mean.forward (openpoints/models/backbone/transformer.py:1120-1131), fused:
  *   p (b,c,n) softmax probs, W (c,c,2c) = the c Linear(2c->c, bias=False) weights stacked

@@ -310,3 +310,75 @@ def test_class_anchor_kernel_first_maximum_and_rows():
     finally:
         del os.environ["GEOT_NTM_CT"]
     assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("Cn", [2, 5, 12, 20, 32])
+def test_any_class_count_matches_the_oracle(Cn):
+    """transformer.py:1104-1110 builds `nclasses` heads for ANY nclasses and insT_loss.py takes num_classes: every
+    per-point kernel at class counts other than the specialised 17 (run-time-C kernels, csrc/ntm_generic.hip)."""
+    from geot_amd import ntm
+    rng = np.random.default_rng(Cn)
+    B, N, k = 2, 700, 9
+    p = _softmax(rng.standard_normal((B, Cn, N)) * 2, 1).astype(np.float32)
+    cm = _softmax(rng.standard_normal((Cn, Cn)), 1).astype(np.float32)
+    mod = ntm.Ins_T_mean(nclasses=Cn).to(DEV)
+    with torch.no_grad():
+        for kk, l in enumerate(mod.T_predictor.fc):
+            l.weight[kk, kk] += 0.6
+            l.weight += 0.03
+    W = torch.stack([l.weight for l in mod.T_predictor.fc]).detach().cpu().numpy()
+    insT = mod(T(p), T(cm))
+    want = np_ntm.sig_t_mean(p, cm, W)
+    np.testing.assert_allclose(insT.detach().cpu().numpy(), want, rtol=1e-5, atol=2e-5)
+    g = rng.standard_normal(want.shape).astype(np.float32)
+    (insT * T(g)).sum().backward()
+    got = torch.stack([l.weight.grad for l in mod.T_predictor.fc]).cpu().numpy()
+    ref = np_ntm.sig_t_mean_grad_W(p, cm, W, g)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4 * np.abs(ref).max())
+    # logit correction, forward + the three gradients
+    logits = (rng.standard_normal((B, Cn, N)) * 2).astype(np.float32)
+    E = np_ntm.l1_normalize(rng.random((Cn, Cn)) + 0.01, 1).astype(np.float32)
+    tl, ti, tE = T(logits).requires_grad_(True), T(want).requires_grad_(True), T(E).requires_grad_(True)
+    out = ntm.correct_logits(tl, ti, tE, 0.9)
+    _, corr = np_ntm.correct_logits(logits, want.astype(np.float32), E, 0.9)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), corr, rtol=1e-5, atol=1e-5 * np.abs(corr).max())
+    go = rng.standard_normal(corr.shape).astype(np.float32)
+    (out * T(go)).sum().backward()
+    gl, gi, gE = np_ntm.correct_logits_grads(logits, want.astype(np.float32), E, 0.9, go)
+    np.testing.assert_allclose(tl.grad.cpu().numpy(), gl, rtol=1e-5, atol=1e-5 * np.abs(gl).max())
+    np.testing.assert_allclose(ti.grad.cpu().numpy(), gi, rtol=1e-5, atol=1e-5 * np.abs(gi).max())
+    np.testing.assert_allclose(tE.grad.cpu().numpy(), gE, rtol=1e-4, atol=1e-4 * np.abs(gE).max())
+    # graph losses (neighbours from the exact kNN)
+    xyz, _ = make_batch(B, N, start_index=3, origin_pts=0)
+    labels = rng.integers(0, min(Cn, 3), (B, N))
+    loss_mod = ntm.threeD_space_loss(k=k, sigma=1.0, num_classes=Cn)
+    nbr = loss_mod.neighbours(T(xyz))
+    for env in ("graph", "atomic"):       # "graph" falls to the scatter form at class counts without the graph kernels
+        ti = T(want).requires_grad_(True)
+        import os
+        os.environ["GEOT_NTM_GRAD"] = env
+        try:
+            loss = loss_mod(T(xyz), T(labels, torch.int64), ti, nbr=nbr)
+            loss.backward()
+        finally:
+            del os.environ["GEOT_NTM_GRAD"]
+        wl, wg, _ = np_ntm.threed_space_loss(xyz, labels, want, nbr.cpu().numpy(), sigma=1.0)
+        assert abs(loss.item() - wl) <= 1e-5 * abs(wl)
+        np.testing.assert_allclose(ti.grad.cpu().numpy(), wg, rtol=1e-4, atol=1e-4 * np.abs(wg).max())
+    ti = T(want).requires_grad_(True)
+    fl = ntm.feature_space_loss(k=k, sigma=1.0, num_classes=Cn)(T(p), T(labels, torch.int64), ti)
+    fl.backward()
+    assert torch.isfinite(fl) and torch.isfinite(ti.grad).all()
+    from geot_amd.openpoints.models.layers.knn import knn_point
+    feats = T(p).permute(0, 2, 1).contiguous()
+    fnbr = knn_point(k + 1, feats, feats)[1][:, :, 1:].cpu().numpy()
+    wl, wg, _ = np_ntm.feature_space_loss(p, labels, want, fnbr, sigma=1.0)
+    assert abs(fl.item() - wl) <= 1e-5 * max(abs(wl), 1e-3)
+    np.testing.assert_allclose(ti.grad.cpu().numpy(), wg, rtol=1e-4, atol=1e-4 * np.abs(wg).max())
+
+
+def test_class_count_out_of_range_is_an_error():
+    from geot_amd import ntm
+    p = torch.softmax(torch.randn(1, 33, 50, device=DEV), 1)
+    with pytest.raises(RuntimeError, match="1..32 classes"):
+        ntm.sig_t_mean(33).to(DEV)(p, torch.eye(33, device=DEV))
