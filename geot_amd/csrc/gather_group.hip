@@ -676,9 +676,14 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
     for (int part = 0; part < Q; ++part) {
         const int p0 = part * partlen, plen = min(partlen, L - p0);
         if (part) __syncthreads(); // the previous part's rows have been read by everyone
+#ifndef GEOT_GG_LAB_NOSTAGE
         for (int l = 0; l < nch; ++l)
             tlds_load_rows(tlds_rows + (size_t)l * partlen, grad_out + (size_t)bi * src_bstride + (size_t)(c0 + l) * L + p0, plen);
+#endif
         __syncthreads();
+#ifdef GEOT_GG_LAB_NOWALK
+        continue;
+#endif
         const int *offp = off + ((size_t)bi * Q + part) * m;
 #pragma unroll
         for (int g = 0; g < TPT; g += TP) {
@@ -699,8 +704,13 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
                     for (int u = 0; u < RU; ++u) {
                         const int q = a[p] + it + u;
                         const bool in = q < z[p];
+#ifdef GEOT_GG_LAB_NOIDX
+                        e[p][u] = in ? (q & 4095) : 0;
+                        w[p][u] = in ? 1.f : 0.f;
+#else
                         e[p][u] = in ? rev[q] : 0;
                         w[p][u] = in ? (WEIGHTED ? revw[q] : 1.f) : 0.f;
+#endif
                     }
 #pragma unroll
                 for (int p = 0; p < TP; ++p)
@@ -709,7 +719,11 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
                         if (l < nch) {
 #pragma unroll
                             for (int u = 0; u < RU; ++u)
+#ifdef GEOT_GG_LAB_NOLDSREAD
+                                acc[g + p][l] = fmaf(w[p][u], __int_as_float(e[p][u]), acc[g + p][l]);
+#else
                                 acc[g + p][l] = fmaf(w[p][u], tlds_rows[(size_t)l * partlen + e[p][u]], acc[g + p][l]);
+#endif
                         }
                     }
             }
