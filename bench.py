@@ -51,7 +51,15 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--clouds", type=int, default=None,
                     help="clouds per GPU per step (model/backbone_ops/ntm: 8, sa: 1, fixmatch: 2 labelled + 2 unlabelled)")
-    ap.add_argument("--workload", choices=["model", "sa", "backbone_ops", "ntm", "fixmatch"], default="model")
+    ap.add_argument("--points", type=int, default=N_POINTS,
+                    help="points per cloud: 24000 = BASELINE.json's metric; 16000 = the authors' own operating point "
+                         "(cfgs/tooth_semi/default.yaml:6 num_points)")
+    ap.add_argument("--workload", choices=["model", "sa", "ops_only", "backbone_ops", "ntm", "fixmatch"], default="model",
+                    help="ops_only (old name: backbone_ops): the hot-path ops of the backbone with the dense layers replaced "
+                         "by NOTHING -- a kernel-timing stand-in, never the metric")
+    ap.add_argument("--no-dense-reference", action="store_true",
+                    help="model: skip the 3 extra steps in the reference's op order that fill the JSON's dense.reference_order")
+    ap.add_argument("--no-saturated", action="store_true", help="sa: skip the extra run at 256 clouds per launch")
     ap.add_argument("--dense", choices=["factored", "reference"], default=None,
                     help="model: how the first 1x1 conv behind a gather is evaluated (see transformer.py)")
     ap.add_argument("--no-tuned-gemm", action="store_true",
@@ -108,11 +116,14 @@ class EventTimer:
 
     def __init__(self):
         self.pairs = []
+        self.only = None        # wrap(): time a call only if only(*args) is true (e.g. the student's batch, not the teacher's)
 
     def wrap(self, fn):
         import torch
 
         def timed(*a, **k):
+            if self.only is not None and not self.only(*a, **k):
+                return fn(*a, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a, **k)
@@ -238,8 +249,28 @@ def hot_path_attribution(step, steps=2):
     return {k: sum(a.elapsed_time(b) for a, b in v) / steps for k, v in rec.items()}
 
 
+def timed_steps(step, steps, dev, rehearsal):
+    """barrier + synchronize, `steps` steps, synchronize + barrier; MAX over ranks of the elapsed seconds."""
+    import torch
+    from geot_amd import dist_utils
+    torch.cuda.synchronize()
+    dist_utils.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dist_utils.barrier()
+    torch.cuda.synchronize()
+    return dist_utils.max_over_ranks(time.perf_counter() - t0, "cpu" if rehearsal else dev), out
+
+
 def main():
+    global N_POINTS
     args = parse()
+    N_POINTS = args.points
+    if args.workload == "backbone_ops":
+        args.workload = "ops_only"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
 
@@ -282,6 +313,8 @@ def main():
     patch_owner = patch_name = None
     unpatch = []
     fps_rounds = 0
+    fps_clouds = B
+    ddp_modules = []
     parallelism = "independent clouds per rank, no collective"
 
     if workload == "model":
@@ -292,16 +325,17 @@ def main():
         model = PointTransformer_seg_T(**TOOTH_SEG_CFG, dense=args.dense).to(dev)
         dense_mode = model.dense
         net = ts.ddp(model, dev, unused=ts.UNUSED_SUPERVISED)
+        ddp_modules = [net] if net is not model else []
         trainer = ts.SupervisedStep(net)
         target = torch.from_numpy(region_labels(xyz_np)).to(dev)
         cls = torch.from_numpy(np.random.default_rng(1609 + rank).integers(0, 2, size=(B, 1))).to(dev)
         patch_owner, patch_name = pops, "furthestsampling_uniform"
         fps_rounds = max(TOOTH_SEG_CFG["downsample_targets"]) - 1
-        desc = ("configs[2]: B=%d x 24k-pt clouds, full transformer_finetune backbone PointTransformer_seg_T "
+        desc = ("configs[2]: B=%d x %dk-pt clouds, full transformer_finetune backbone PointTransformer_seg_T "
                 "(trans_dim 384, depth 12, 512 groups x 32, targets 8192/4096/2048) fwd + Poly1FocalLoss + bwd + AdamW, "
-                "train mode, random init" % B) if world == 1 else \
-               ("configs[3]: data-parallel %d x (B=%d x 24k-pt clouds), same model; SyncBatchNorm + DDP gradient "
-                "all-reduce over %s" % (world, B, "gloo (rehearsal)" if rehearsal else "RCCL"))
+                "train mode, random init" % (B, N_POINTS // 1000)) if world == 1 else \
+               ("configs[3]: data-parallel %d x (B=%d x %dk-pt clouds), same model; SyncBatchNorm + DDP gradient "
+                "all-reduce over %s" % (world, B, N_POINTS // 1000, "gloo (rehearsal)" if rehearsal else "RCCL"))
         if world > 1:
             parallelism = "dp%d: DistributedDataParallel (25 MB buckets, overlapped with backward) + SyncBatchNorm" % world
 
@@ -312,7 +346,15 @@ def main():
         torch.manual_seed(1609)
         trainer = ts.build_fixmatch(dev, use_ddp=True,
                                     group=torch.distributed.group.WORLD if world > 1 else None)
+        if world > 1:
+            ddp_modules = [trainer.model, trainer.T_predictor]
+        from geot_amd.pointops.functions import pointops as pops
+        patch_owner, patch_name = pops, "furthestsampling_uniform"      # the student's 8192-sample FPS: its largest kernel
+        from geot_amd.openpoints.models.backbone.transformer import TOOTH_SEG_CFG
+        fps_rounds = max(TOOTH_SEG_CFG["downsample_targets"]) - 1
         bl = bu = B
+        fps_clouds = bl + 2 * bu              # the student batch: labelled + strong + weak views (train.py:478-490)
+        fps_timer.only = lambda flat, b, n, k: b == fps_clouds
         clouds_per_step = bl + bu
         xyz_u_np, _ = make_batch(bu, N_POINTS, start_index=10_000 + dist_utils.cloud_range(rank, bu)[0])
         xyz_u = torch.from_numpy(xyz_u_np).to(dev)
@@ -324,8 +366,8 @@ def main():
                   "pos_s": strong, "x_s": strong.transpose(1, 2).contiguous(), "cls_s": torch.zeros(bu, 1, dtype=torch.long, device=dev),
                   "raw_pos": xyz_u}
         desc = ("configs[4]: FixMatch+NTM semi-supervised step per rank: teacher fwd on %d weak clouds, student fwd+bwd on "
-                "%d labelled + %d strong + %d weak clouds x 24k pts, class transition + sig_t_mean + logit correction + "
-                "threeD_space_loss(k=32) + Poly1Focal losses, AdamW x2" % (bu, bl, bu, bu))
+                "%d labelled + %d strong + %d weak clouds x %dk pts, class transition + sig_t_mean + logit correction + "
+                "threeD_space_loss(k=32) + Poly1Focal losses, AdamW x2" % (bu, bl, bu, bu, N_POINTS // 1000))
         if world > 1:
             parallelism = "dp%d: DDP(student) + DDP(T_predictor) + SyncBatchNorm + all-gather of the class anchors" % world
 
@@ -345,14 +387,15 @@ def main():
         def step():
             with torch.no_grad():
                 return sa(xyz, feats)[1]
-    elif workload == "backbone_ops":
+    elif workload == "ops_only":
         from geot_amd import workloads as wl
         from geot_amd.pointops.functions import pointops as pops
         hot = wl.BackboneHotPath().to(dev)
         tokens = torch.randn(B, wl.TRANS_DIM, wl.GROUPS, device=dev)
         patch_owner, patch_name = pops, "furthestsampling_uniform"
-        fps_rounds, desc = 8191, ("configs[2] hot-path ops only: PointTransformer_seg_T sampling/grouping/interpolation "
-                                  "fwd+bwd (FPS 512+8192, kNN 32/4, three_nn+interpolate x3), dense layers excluded")
+        fps_rounds, desc = 8191, ("STAND-IN, not a BASELINE config: the sampling / grouping / interpolation ops of "
+                                  "PointTransformer_seg_T fwd+bwd (FPS 512+8192, kNN 32/4, three_nn+interpolate x3) with "
+                                  "every dense layer replaced by nothing -- kernel timing only")
 
         def step():
             return wl.backbone_hotpath_step(hot, xyz, tokens)
@@ -399,41 +442,35 @@ def main():
         import geot_amd.sa_fused as sa_fused_mod
         orig_mlp = sa_fused_mod.fused_group_mlp_max
         sa_fused_mod.fused_group_mlp_max = mlp_timer.wrap(orig_mlp)
-    torch.cuda.synchronize()
-    dist_utils.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     if args.streams > 1 and workload == "sa":
         pool = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
-        for i in range(args.steps):
-            with torch.cuda.stream(pool[i % args.streams]):
-                out = step()
+        dealt = [0]
+
+        def dealt_step():
+            with torch.cuda.stream(pool[dealt[0] % args.streams]):
+                dealt[0] += 1
+                return step()
+        elapsed, out = timed_steps(dealt_step, args.steps, dev, rehearsal)
     else:
-        for _ in range(args.steps):
-            out = step()
-    torch.cuda.synchronize()
-    dist_utils.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        elapsed, out = timed_steps(step, args.steps, dev, rehearsal)
     if patch_owner is not None:
         setattr(patch_owner, patch_name, orig_fn)
     if workload == "sa" and not args.graph:
         sa_fused_mod.fused_group_mlp_max = orig_mlp
     for h in unpatch:
         h.remove()
-    elapsed = dist_utils.max_over_ranks(elapsed, "cpu" if rehearsal else dev)
     assert torch.isfinite(out).all()
 
     ms_per_step = 1e3 * elapsed / args.steps
     fps_ms = fps_timer.mean_ms()
-    fps_flop = B * N_POINTS * fps_rounds * FPS_FLOP_PER_UPDATE
+    fps_flop = fps_clouds * N_POINTS * fps_rounds * FPS_FLOP_PER_UPDATE
     fps_tf = fps_flop / (fps_ms * 1e-3) / 1e12 if fps_rounds else float("nan")
     tag = {"model": "bench_model", "sa": "bench_sa"}.get(workload, workload)
     traffic, source = pmc_traffic("fps_pruned_kernel", tag) if (B == default_b and workload != "model") else (None, None)
     fps_roofline = {
         "kernel": "fps_pruned_kernel", "bound": "valu", "achieved": fps_tf, "peak": FP32_VECTOR_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": fps_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
-        "avg_launch_ms": fps_ms, "cus_used": B,
+        "avg_launch_ms": fps_ms, "cus_used": fps_clouds,
         "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic flop = clouds*N*(m-1) updates "
                 "* 10 (what the reference executes); the pruned kernel skips most of them exactly; one workgroup "
                 "(one CU of 256) per cloud"}
@@ -452,7 +489,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: all ranks on one GPU over gloo -- not a measurement)",
         "config": {"workload": desc + graph_note, "clouds_per_gpu": clouds_per_step, "points": N_POINTS,
-                   "parallelism": parallelism},
+                   "parallelism": parallelism, "stand_in": workload in ("ops_only", "ntm")},
         "roofline": fps_roofline if (fps_rounds and not args.graph) else None,
     }
     if workload == "model":
@@ -504,6 +541,72 @@ def main():
             "avg_launch_ms": mlp_ms,
             "note": "fused group + [6,64,64,128] 1x1-conv stack on fp32 MFMA + max over nsample; algorithmic flop = "
                     "2*rows*sum(Cin*Cout) with the unpadded 3+3 input channels"}
+    if workload == "fixmatch":
+        fps_roofline.update(kernel="fps_pruned_kernel<768,32,false,8> (the student's pointops.fps 24000 -> 8192 over its "
+                                   "%d clouds: the longest kernel of the iteration; the teacher runs the same on %d)" % (fps_clouds, bu))
+        att = hot_path_attribution(step)
+        hot_ms = sum(att.values())
+        result["hot_path"] = {"c_abi_gpu_ms_per_step": hot_ms, "share_of_step": hot_ms / ms_per_step,
+                              "top_entry_points_ms": dict(sorted(att.items(), key=lambda kv: -kv[1])[:8]),
+                              "note": "HIP-event durations around every C-ABI launch in 2 extra untimed iterations; the FPS "
+                                      "launches and the teacher run on side streams, so this is GPU work, not wall time"}
+    if world > 1:
+        # Audit trail for a multi-GPU record: (a) an all-reduce of ones over the backend the step used -- the number of
+        # ranks that really took part; (b) what the gradient all-reduce costs on the critical path: the same steps with
+        # DDP's reduction switched off (no_sync: gradients stay local; SyncBatchNorm and the anchor exchange still talk)
+        import contextlib
+        import torch.distributed as dist
+        ones = torch.ones(1, device="cpu" if rehearsal else dev)
+        dist.all_reduce(ones)
+        k2 = max(2, min(args.steps, 5))
+
+        def local_step():
+            with contextlib.ExitStack() as stack:
+                for m in ddp_modules:
+                    stack.enter_context(m.no_sync())
+                return step()
+        local_step()
+        t_local, _ = timed_steps(local_step, k2, dev, rehearsal)
+        grad_bytes = sum(p.numel() * 4 for m in ddp_modules for p in m.parameters() if p.requires_grad)
+        result["comm"] = {"backend": dist.get_backend(), "ranks_in_collective": int(ones.item()),
+                          "gradient_allreduce_mb_per_step": grad_bytes / 1e6,
+                          "ms_per_step_without_gradient_allreduce": 1e3 * t_local / k2,
+                          "exposed_allreduce_ms": ms_per_step - 1e3 * t_local / k2,
+                          "note": "exposed = timed step minus the same step under DDP.no_sync() (%d steps); negative = noise" % k2}
+    if workload == "model" and world == 1 and dense_mode != "reference" and not args.no_dense_reference:
+        # the same step with every layer in the REFERENCE's op order (first 1x1 conv after the gather, op-by-op attention /
+        # LayerNorm) on the same kernels: what the algebraic re-ordering is worth, observed in this run
+        del trainer, net
+        torch.manual_seed(1609)
+        ref_model = PointTransformer_seg_T(**TOOTH_SEG_CFG, dense="reference").to(dev)
+        ref_model.load_state_dict(model.state_dict())
+        ref_trainer = ts.SupervisedStep(ref_model)
+
+        def ref_step():
+            return ref_trainer(xyz, cls, target)
+        ref_step()
+        t_ref, ref_out = timed_steps(ref_step, 3, dev, rehearsal)
+        assert torch.isfinite(ref_out).all()
+        result["dense"]["reference_order"] = {"clouds_per_s": clouds_per_step * 3 / t_ref, "ms_per_step": 1e3 * t_ref / 3,
+                                              "steps": 3, "note": "--dense reference: the reference's op order, same HIP "
+                                                                  "kernels and GEMM selection; 1 warm-up + 3 timed steps"}
+        del ref_trainer, ref_model
+    if workload == "sa" and world == 1 and not args.graph and not args.no_saturated and B < 64:
+        # one cloud occupies ONE of the 256 CUs in FPS (96 % of this step): the same module at 256 clouds per launch
+        # is what the chip does when every CU has a cloud (the reference's per-cloud semantics are unchanged)
+        bs = 256
+        xs = torch.from_numpy(make_batch(bs, N_POINTS, start_index=5000)[0]).to(dev)
+        fs = torch.randn(bs, MLP[0], N_POINTS, device=dev)
+
+        def sat_step():
+            with torch.no_grad():
+                return sa(xs, fs)[1]
+        sat_step()
+        t_sat, _ = timed_steps(sat_step, 3, dev, rehearsal)
+        result["saturated"] = {"clouds_per_launch": bs, "clouds_per_s": bs * 3 / t_sat, "ms_per_step": 1e3 * t_sat / 3,
+                               "steps": 3, "note": "same SetAbstraction forward with one cloud per CU (256 clouds in one "
+                                                   "call): throughput when FPS fills the chip"}
+        del xs, fs
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if workload == "sa":
             from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes

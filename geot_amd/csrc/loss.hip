@@ -44,7 +44,12 @@ __global__ __launch_bounds__(PL_THREADS) void poly1_fwd_kernel(int c, int n, Pol
         P.eval(row[i], lab[i] == cc, l, dl);
         const float w = kp ? (kp[i] ? 1.f : 0.f) : 1.f;
         s += (double)(l * w);
-        if (cc == 0) k += (double)w;
+        if (cc == 0) {
+            k += (double)w;
+            // the reference's F.one_hot raises on a label outside [0, C) (an ignore index of -1 / 255, say); a kernel
+            // cannot raise, and treating the point as all-negative would be a silently different loss: poison it
+            if (lab[i] < 0 || lab[i] >= c) s += (double)__int_as_float(0x7fc00000);
+        }
     }
     __shared__ double sh[2][PL_THREADS / 64];
 #pragma unroll

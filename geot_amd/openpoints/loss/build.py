@@ -3,6 +3,8 @@ criterion_args / criterion_u_args): Poly1FocalLoss (openpoints/loss/build.py:183
 Poly1FocalLoss_U_corr (:799-892) on the NTM-corrected strong-view logits.  Element-wise torch on (B, 17, N)
 tensors -- callers of the hot path, mirrored only so that the step of BASELINE configs[4] closes; same
 constructor arguments and forward signatures, same arithmetic."""
+import os
+
 import torch
 import torch.nn.functional as F
 from torch.autograd import Function
@@ -34,6 +36,18 @@ class _Poly1FocalFn(Function):
         call("geot_poly1_focal_grad", logits.device, b, c, n, *ctx.cfg, ptr(logits), ptr(labels), ptr(keep), ptr(out2), ptr(up),
              ptr(grad))
         return grad, None, None, None, None, None
+
+
+def _check_labels(logits, labels):
+    """GEOT_CHECK_LABELS=1: the synchronous range check F.one_hot does in the reference (openpoints/loss/build.py:223-230
+    raise on a label outside [0, C)).  Off by default -- it costs a device round trip per call; without it the fused
+    kernel returns NaN for such input (csrc/loss.hip) instead of a silently different loss."""
+    if os.environ.get("GEOT_CHECK_LABELS", "0") == "1" and labels.numel():
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0:
+            raise RuntimeError("Class values must be non-negative.")
+        if hi >= logits.shape[1]:
+            raise RuntimeError("Class values must be smaller than num_classes.")
 
 
 def _fused_ok(mod, logits, labels, reduction_ok):
@@ -71,6 +85,7 @@ class Poly1FocalLoss(torch.nn.Module):
 
     def forward(self, logits, labels):
         if _fused_ok(self, logits, labels, self.reduction == "mean"):
+            _check_labels(logits, labels)
             return _Poly1FocalFn.apply(logits.contiguous(), labels.contiguous(), None, self.alpha, self.gamma, self.epsilon)
         if not self.label_is_onehot:
             labels = _one_hot_like(logits, labels)
@@ -82,7 +97,10 @@ class Poly1FocalLoss(torch.nn.Module):
 
 class Poly1FocalLoss_U_corr(Poly1FocalLoss):
     def forward(self, logits, labels, logits_pred, thresh=0.95, mask=None):
-        if _fused_ok(self, logits, labels, True):
+        # a soft (float) mask multiplies the loss by its VALUES in the reference (:872-875): only a 0/1 mask is a `keep` flag
+        hard_mask = mask is None or mask.dtype in (torch.bool, torch.uint8)
+        if hard_mask and _fused_ok(self, logits, labels, True):
+            _check_labels(logits, labels)
             keep = (mask if mask is not None else logits_pred.ge(thresh)).to(torch.uint8).contiguous()
             if tuple(keep.shape) == tuple(labels.shape):
                 return _Poly1FocalFn.apply(logits.contiguous(), labels.contiguous(), keep, self.alpha, self.gamma, self.epsilon)

@@ -53,17 +53,55 @@ def ddp(module, device, sync_bn=True, unused=(), **kw):
     return nn.parallel.DistributedDataParallel(module, device_ids=ids, **kw)
 
 
-def make_optimizer(params, lr=1e-3, weight_decay=1e-4):
-    params = [p for p in params if p.requires_grad]
+def parameter_groups(model, weight_decay=1e-4, skip_list=()):
+    """The two AdamW parameter groups of the reference's optimizer factory (openpoints/optim/optim_factory.py:66-119
+    get_parameter_groups, reached through build_optimizer_from_cfg :190-198 with its default filter_bias_and_bn=True,
+    train.py:169 / :225): every 1-D parameter (BatchNorm / LayerNorm / GroupNorm weights, `sigma`, ...), every
+    `*.bias` and everything named in the model's no_weight_decay() goes WITHOUT weight decay, the rest with it.
+    Group order and the `lr_scale` key are the factory's (first appearance; 1.0 without layer decay)."""
+    module = model.module if hasattr(model, "module") else model          # DDP wrapper: the factory looks inside (:190-193)
+    if not skip_list and hasattr(module, "no_weight_decay"):
+        skip_list = module.no_weight_decay()
+    groups = {}
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        no_decay = param.ndim == 1 or name.endswith(".bias") or any(key in name for key in skip_list)
+        key = "no_decay" if no_decay else "decay"
+        if key not in groups:
+            groups[key] = {"weight_decay": 0.0 if no_decay else weight_decay, "params": [], "lr_scale": 1.0}
+        groups[key]["params"].append(param)
+    return list(groups.values())
+
+
+def _join(dev, side, *tensors):
+    """The one place a side stream's results are handed to the current stream: the current stream waits for `side`,
+    and -- outside graph capture, where record_stream is not allowed and the capture's own dependency edges keep the
+    memory alive -- every tensor allocated on `side` is recorded as used by the current stream, so the caching allocator
+    cannot hand its block to a later allocation on `side` while a reader queued here is still pending (whatever the
+    order of frees / allocations a future change introduces)."""
+    cur = torch.cuda.current_stream(dev)
+    cur.wait_stream(side)
+    if not torch.cuda.is_current_stream_capturing():
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(cur)
+
+
+def make_optimizer(model, lr=1e-3, weight_decay=1e-4):
+    """AdamW as train.py:169 / :225 build it (cfgs/tooth_semi/default.yaml:66-68: adamw, weight_decay 1e-4)."""
+    groups = parameter_groups(model, weight_decay) if weight_decay else \
+        [{"params": [p for p in model.parameters() if p.requires_grad]}]
+    params = [p for g in groups for p in g["params"]]
     fused = bool(params) and all(p.is_cuda for p in params)
-    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, fused=fused)
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=0.0 if weight_decay else weight_decay, fused=fused)
 
 
 class SupervisedStep:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, grad_norm_clip=None):
         self.model = model
         self.criterion = Poly1FocalLoss()
-        self.optimizer = make_optimizer(model.parameters(), lr, weight_decay)
+        self.optimizer = make_optimizer(model, lr, weight_decay)
         self.clip = grad_norm_clip
 
     def __call__(self, pos, cls, target):
@@ -91,8 +129,8 @@ class FixMatchNTMStep:
         dev = next(student.parameters()).device
         self.criterion, self.criterion_u = Poly1FocalLoss(), Poly1FocalLoss_U_corr()
         self.threed_loss = ntm_mod.threeD_space_loss(self.cfg["threed_k"], self.cfg["threed_sigma"], c)
-        self.optimizer = make_optimizer(student.parameters(), self.cfg["lr"], self.cfg["weight_decay"])
-        self.T_optimizer = make_optimizer(t_predictor.parameters(), self.cfg["lr"], self.cfg["weight_decay"])
+        self.optimizer = make_optimizer(student, self.cfg["lr"], self.cfg["weight_decay"])
+        self.T_optimizer = make_optimizer(t_predictor, self.cfg["lr"], self.cfg["weight_decay"])
         self.ema_t = torch.eye(c, device=dev)                                          # train.py:274
         self.cm = cm if cm is not None else torch.full((c, c), 1.0 / c, device=dev)    # cal_mean_feature's output
         self.group = group
@@ -140,7 +178,7 @@ class FixMatchNTMStep:
         pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True)
         pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
         if t_stream is not None:
-            torch.cuda.current_stream(dev).wait_stream(t_stream)
+            _join(dev, t_stream, pred_u, logits_u_aug, label_u_aug)
         # 3. class-level transition matrix, prior, EMA (train.py:502-545, 556-557)
         ema_t_corr, ema_next, _, _ = ntm_mod.class_transition(
             pred_u, sigma, self.ema_t, cfg["geo_lambma"], cfg["ema_t_decay"], group=self.group,
@@ -151,7 +189,7 @@ class FixMatchNTMStep:
         self.ema_t = ema_next.detach()
         # 5. losses (train.py:570-602)
         if nbr is not None:
-            torch.cuda.current_stream(dev).wait_stream(self._side)
+            _join(dev, self._side, nbr, order)
         loss_3d = self.threed_loss(data_u["raw_pos"], label_u_aug, ins_t, nbr=nbr, order=order) * cfg["threed_loss_weight"]
         sup_loss = self.criterion(pred_l, data["y"])
         unsup_loss = self.criterion_u(pred_u_strong_corr, label_u_aug.detach(), logits_u_aug.detach(),

@@ -25,20 +25,38 @@ def enable(tune=False, path=None):
     work = path
     if not tune:
         # TunableOp owns the file it is pointed at (it may rewrite it): every process works on a private copy, so N
-        # ranks never write one file and the recorded selection in the tree stays byte-identical
+        # ranks never write one file and the recorded selection in the tree stays byte-identical.  mkstemp: an
+        # unpredictable name created O_EXCL (the old /tmp/geot_tunableop_<pid>.csv could be pre-planted); removed at exit
+        import atexit
         import shutil
         import tempfile
-        work = os.path.join(tempfile.gettempdir(), "geot_tunableop_%d.csv" % os.getpid())
         try:
+            fd, work = tempfile.mkstemp(prefix="geot_tunableop_", suffix=".csv")
+            os.close(fd)
             shutil.copyfile(path, work)
         except OSError:
             return None
+        atexit.register(_remove, work)
     tunable.enable(True)
     tunable.tuning_enable(bool(tune))
     tunable.set_filename(work, insert_device_ordinal=False)     # one selection for every rank: the shapes are per rank
-    if os.path.exists(work):
+    if not tune:
+        tunable.write_file_on_exit(False)                       # nothing was tuned: nothing to write back
+        ok = False
         try:
-            tunable.read_file(work)
-        except Exception:                                       # noqa: BLE001  (validator mismatch: library defaults)
+            ok = bool(tunable.read_file(work))                  # False on a Validator mismatch (other torch / ROCm / GPU)
+        except Exception:                                       # noqa: BLE001
+            ok = False
+        if not ok:
+            # the recorded selection does not apply to this stack: say so (None) and run plain library defaults,
+            # instead of reporting a selection that is not in effect
+            tunable.enable(False)
             return None
     return path
+
+
+def _remove(path):
+    try:
+        os.remove(path)
+    except OSError:
+        pass

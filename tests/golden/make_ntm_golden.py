@@ -17,6 +17,7 @@ anywhere: the fixtures hold seeded inputs, the outputs and the autograd gradient
     ntm_ref_losses.npz       threeD_space_loss, feature_space_loss, Idenyity_loss    utils/insT_loss.py:9-132
     poly1_ref.npz            Poly1FocalLoss, Poly1FocalLoss_U_corr    openpoints/loss/build.py:183-258, 799-892
     blocks_ref.npz           Mlp / Attention / Block / TransformerEncoder_h / Encoder   transformer.py:16-136, 389-421
+    param_groups_ref.npz     get_parameter_groups (AdamW decay / no-decay split)   openpoints/optim/optim_factory.py:66-119
     dgcnn_ref.npz            DGCNN_Propagation                        transformer.py:304-384
                              (``knn_cuda.KNN`` is NOT in the reference tree; a stand-in with OUR tie rule,
                              exact fp32 (d2, index) order, is supplied and the fixture's metadata says so)
@@ -440,6 +441,30 @@ def gen_dgcnn(ns):
                                   "gradients are stored as flat[::41]."), **out)
 
 
+def gen_param_groups(ns):
+    """openpoints/optim/optim_factory.py get_parameter_groups executed in place on the package's model mirrors (the
+    function only walks named_parameters()): which parameter names land in the decay / no-decay AdamW groups."""
+    import json
+    import logging
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd.ntm import sig_t_mean
+    env = dict(ns, json=json, logging=logging)
+    ref_defs("openpoints/optim/optim_factory.py", ["get_parameter_groups"], env)
+    small = dict(trans_dim=384, depth=2, num_heads=4, group_size=16, num_group=32, encoder_dims=256, nclasses=17,
+                 drop_path_rate=0.0, downsample_targets=[256, 128, 64], extract_layers=[1, 2])
+    out = {}
+    for tag, model in (("seg", PointTransformer_seg_T(**small)), ("pred", sig_t_mean(17))):
+        ids = {id(p): n for n, p in model.named_parameters()}
+        groups = env["get_parameter_groups"](model, 1e-4, ())
+        out[tag + "_n_groups"] = np.int32(len(groups))
+        for i, g in enumerate(groups):
+            out["%s_g%d_names" % (tag, i)] = np.array([ids[id(p)] for p in g["params"]])
+            out["%s_g%d_weight_decay" % (tag, i)] = np.float64(g["weight_decay"])
+            out["%s_g%d_lr_scale" % (tag, i)] = np.float64(g["lr_scale"])
+    np.savez_compressed(os.path.join(HERE, "param_groups_ref.npz"), meta=meta("weight_decay 1e-4, empty skip list "
+                        "(cfgs/tooth_semi/default.yaml:66-68; the model defines no no_weight_decay())"), **out)
+
+
 if __name__ == "__main__":
     assert os.path.isdir(REF), "run in the build container"
     torch.manual_seed(0)
@@ -451,6 +476,7 @@ if __name__ == "__main__":
     gen_poly1(space)
     gen_blocks(space)
     gen_dgcnn(space)
+    gen_param_groups(space)
     for f in sorted(os.listdir(HERE)):
         if f.endswith("_ref.npz") or f.startswith("ntm_ref"):
             print("%8.1f KB  %s" % (os.path.getsize(os.path.join(HERE, f)) / 1024, f))

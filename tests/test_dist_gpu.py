@@ -1,0 +1,151 @@
+"""GPU suite, N-rank control flow on the one-GPU test box: two ranks share GPU 0 and talk over gloo (the RCCL path
+itself needs >= 2 GPUs, which only the driver's 8-GPU node has).
+
+* bench.py's own N > 1 tail, started the way the driver starts it (fresh child processes): rendezvous, SyncBatchNorm +
+  DDP step, barriers, MAX over ranks, rank-0 JSON with the audit block (`comm`: ranks in the collective, exposed
+  all-reduce time) -- for the configs[3] and the configs[4] workload.
+* one full FixMatch+NTM iteration (train.py:455-602: frozen teacher, DDP student, DDP T_predictor, SyncBatchNorm through
+  fused_norm.bn_act, anchor-row all-gather) on two ranks against the same iteration on the concatenated batch in one
+  process: same losses, same EMA matrix, same averaged gradients."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = dict(trans_dim=384, depth=2, num_heads=4, group_size=16, num_group=64, encoder_dims=256, nclasses=17,
+             drop_path_rate=0.0, downsample_targets=[1024, 512, 256], extract_layers=[1, 2])
+N = 2048
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("workload", ["model", "fixmatch"])
+def test_bench_two_rank_rehearsal_emits_an_auditable_line(workload):
+    env = dict(os.environ, GEOT_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clouds", "1", "--steps", "2",
+                        "--warmup", "1", "--workload", workload, "--points", "8192"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["warmup"] == 1 and rec["scaling"] == "weak"
+    assert rec["value"] > 0 and np.isfinite(rec["ms_per_step"]) and "REHEARSAL" in rec["data"]
+    assert rec["config"]["parallelism"].startswith("dp2") and rec["config"]["points"] == 8192
+    clouds = {"model": 1, "fixmatch": 2}[workload]
+    assert rec["config"]["clouds_per_gpu"] == clouds
+    assert abs(rec["value"] - 2 * clouds * 2 / (rec["ms_per_step"] * 2 / 1e3)) < 1e-6 * rec["value"]   # whole-job clouds / max time
+    comm = rec["comm"]
+    assert comm["ranks_in_collective"] == 2 and comm["backend"] == "gloo"
+    assert comm["gradient_allreduce_mb_per_step"] > 100            # 27 M fp32 parameters
+    assert np.isfinite(comm["exposed_allreduce_ms"]) and comm["ms_per_step_without_gradient_allreduce"] > 0
+    assert "cpu_baseline" not in rec
+
+
+# ---- FixMatch + NTM iteration: 2 ranks == 1 process -------------------------------------------------------------------
+def _fixmatch_inputs(dev):
+    from geot_amd.synth import make_batch, region_labels
+    xyz_l = make_batch(2, N, start_index=11)[0]
+    xyz_u = make_batch(2, N, start_index=31)[0]
+    scale = np.array([[[0.9, 1.1, 1.05]], [[1.1, 0.95, 0.9]]], np.float32)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    lab, unl, strong = T(xyz_l), T(xyz_u), T(xyz_u * scale)
+    data = {"pos": lab, "x": lab.transpose(1, 2).contiguous(), "cls": torch.tensor([[0], [1]], device=dev),
+            "y": T(region_labels(xyz_l))}
+    data_u = {"pos_w": unl, "x_w": unl.transpose(1, 2).contiguous(), "cls_w": torch.tensor([[1], [0]], device=dev),
+              "pos_s": strong, "x_s": strong.transpose(1, 2).contiguous(), "cls_s": torch.tensor([[1], [0]], device=dev),
+              "raw_pos": unl}
+    return data, data_u
+
+
+def _shard(d, r):
+    return {k: v[r:r + 1].contiguous() for k, v in d.items()}
+
+
+def _run_iteration(dev, rank=None):
+    """One FixMatch+NTM iteration; returns (losses, ema_t, gradients of a few student / predictor parameters as they
+    stand when optimizer.step() is called -- after DDP's averaging)."""
+    import torch.distributed as dist
+    from geot_amd import train_step as ts
+    torch.manual_seed(77)
+    cfg = dict(ts.NTM_CFG, threed_k=8)
+    step = ts.build_fixmatch(dev, seg_cfg=SMALL, cfg=cfg, use_ddp=rank is not None,
+                             group=dist.group.WORLD if rank is not None else None)
+    inner = step.model.module if hasattr(step.model, "module") else step.model
+    inner.segmentor.seg_head[2].p = 0.0                          # no dropout: the draws differ with the batch split
+    data, data_u = _fixmatch_inputs(dev)
+    if rank is not None:
+        data, data_u = _shard(data, rank), _shard(data_u, rank)
+    grads = {}
+
+    def capture(opt, tag):
+        orig = opt.step
+
+        def stepper(*a, **k):
+            mod = step.model if tag == "s" else step.T_predictor
+            inner = mod.module if hasattr(mod, "module") else mod
+            for n, p in inner.named_parameters():
+                if p.grad is not None and (tag == "t" or n.endswith(("seg_head.3.weight", "reduce_dim.weight", "sigma",
+                                                                     "propogation_0.mlp.layer0.conv.weight",
+                                                                     "encoder.first_conv.1.weight", "blocks.blocks.1.attn.qkv.weight"))):
+                    grads[tag + ":" + n] = p.grad.detach().cpu().numpy().copy()
+            return orig(*a, **k)
+        opt.step = stepper
+    capture(step.optimizer, "s")
+    capture(step.T_optimizer, "t")
+    out = step(data, data_u)
+    torch.cuda.synchronize()
+    return {k: float(v) for k, v in out.items()}, step.ema_t.cpu().numpy(), grads
+
+
+def _fixmatch_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    losses, ema, grads = _run_iteration(torch.device("cuda:0"), rank)
+    q.put((rank, losses, ema, grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fixmatch_iteration_on_two_ranks_equals_the_single_process_iteration():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fixmatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    losses, ema, grads = _run_iteration(torch.device("cuda:0"))
+    (_, l0, e0, g0), (_, l1, e1, g1) = res
+    # every rank holds the whole batch's class anchors -> the same EMA matrix as the single process
+    np.testing.assert_allclose(e0, ema, rtol=1e-5, atol=1e-7)
+    np.testing.assert_array_equal(e0, e1)
+    # per-rank losses are means over the rank's clouds: their average is the single-process loss
+    for k in losses:
+        avg = 0.5 * (l0[k] + l1[k])
+        assert abs(avg - losses[k]) <= 2e-4 * max(abs(losses[k]), 1e-3), (k, l0[k], l1[k], losses[k])
+    assert set(g0) == set(grads) and len(grads) >= 6
+    for k, w in grads.items():
+        np.testing.assert_array_equal(g0[k], g1[k])                 # DDP: both ranks step with the same averaged gradient
+        err = np.linalg.norm(g0[k] - w) / (np.linalg.norm(w) + 1e-12)
+        assert err <= 2e-3, (k, err)                                # fp32: batch-size dependent GEMM blocking / summation order

@@ -14,20 +14,20 @@ pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("m", [6000, 8192])
-def test_fps_k1_full_size_vs_oracle(m, oracle):
+@pytest.mark.parametrize("n,m", [(24000, 6000), (24000, 8192), (16000, 4000), (16000, 8192)])
+def test_fps_k1_full_size_vs_oracle(n, m, oracle):
     """configs[1]'s own call: pointnet2 FPS (K1: <= 512-thread tie rule, origin skip) 24 000 -> 6000 / 8192, indices
-    AND the final min-distance array."""
+    AND the final min-distance array; the same at the authors' 16 000-point operating point (default.yaml:6)."""
     from geot_amd.ext import pointnet2_ext as p2
-    xyz = make_batch(2, 24000, start_index=100, dup_frac=0.01)[0]
+    xyz = make_batch(2, n, start_index=100, dup_frac=0.01)[0]
     x = torch.from_numpy(xyz).to(DEV)
     want, wtemp = oracle.fps_dense(xyz, m, 512, True, return_temp=True)
     got = p2.furthest_point_sampling(x, m)
     assert np.array_equal(got.cpu().numpy(), want)
     from geot_amd.ext import pointnet2_batch_cuda as p2b            # K1' exposes temp: same kernel family, cap 1024
     out = torch.empty(2, m, dtype=torch.int32, device=DEV)
-    temp = torch.full((2, 24000), 1e10, device=DEV)
-    p2b.furthest_point_sampling_wrapper(2, 24000, m, x, temp, out)
+    temp = torch.full((2, n), 1e10, device=DEV)
+    p2b.furthest_point_sampling_wrapper(2, n, m, x, temp, out)
     w2, t2 = oracle.fps_dense(xyz, m, 1024, False, return_temp=True)
     assert np.array_equal(out.cpu().numpy(), w2) and np.array_equal(temp.cpu().numpy(), t2)
     assert wtemp.shape == t2.shape
@@ -231,8 +231,10 @@ def test_gather_gradients_of_the_model_are_bit_reproducible():
     assert all(torch.equal(a, b) for a, b in zip(*outs))
 
 
-def test_fixmatch_iteration_at_the_configured_sizes():
-    """BASELINE configs[4] as bench.py runs it: the full PointTransformer_seg_T (depth 12, 512 x 32 groups, targets
+@pytest.mark.parametrize("npts", [24000, 16000])
+def test_fixmatch_iteration_at_the_configured_sizes(npts):
+    """(16 000 points, B_l = B_u = 2: the sizes the authors train at, default.yaml:6, ...fixmatch_ntm.yaml:72-73.)
+    BASELINE configs[4] as bench.py runs it: the full PointTransformer_seg_T (depth 12, 512 x 32 groups, targets
     8192 / 4096 / 2048) as student and frozen teacher, B_l = B_u = 2 clouds of 24 000 points, two FixMatch+NTM
     iterations: every loss finite, the 3-D loss non-negative, the EMA transition matrix a row-stochastic mixture, both
     optimisers stepped; and the same two iterations with the teacher on the main stream give the same losses."""
@@ -240,9 +242,9 @@ def test_fixmatch_iteration_at_the_configured_sizes():
     from geot_amd import train_step as ts
     from geot_amd.synth import make_batch
     dev = torch.device("cuda:0")
-    xyz, lab = make_batch(2, 24000, start_index=0)
+    xyz, lab = make_batch(2, npts, start_index=0)
     pos, target = torch.from_numpy(xyz).to(dev), torch.from_numpy(lab).long().to(dev)
-    xu = torch.from_numpy(make_batch(2, 24000, start_index=7)[0]).to(dev)
+    xu = torch.from_numpy(make_batch(2, npts, start_index=7)[0]).to(dev)
     xs = (xu * 1.05).contiguous()
     z = torch.zeros(2, 1, dtype=torch.long, device=dev)
     data = {"pos": pos, "x": pos.transpose(1, 2).contiguous(), "cls": z, "y": target}

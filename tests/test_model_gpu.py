@@ -50,23 +50,25 @@ def test_factored_dense_equals_reference_order():
         assert err < 1e-2, (k, err)     # fp32 summation order + max ties after normalisation, through 30 layers
 
 
-def test_model_sampling_steps_match_oracle_full_size(oracle):
+@pytest.mark.parametrize("npts", [24000, 16000])
+def test_model_sampling_steps_match_oracle_full_size(oracle, npts):
     """The index-producing steps of one forward at the configs[2] shapes (B=2 of the 8 clouds to keep the oracle in
-    seconds): Group's FPS(K1, origin-skip)+kNN, pointops.fps prefixes (K2), three_nn of every FP module, DGCNN kNN."""
+    seconds): Group's FPS(K1, origin-skip)+kNN, pointops.fps prefixes (K2), three_nn of every FP module, DGCNN kNN.
+    16 000 points = the authors' own operating point (cfgs/tooth_semi/default.yaml:6 num_points)."""
     from geot_amd.openpoints.models.backbone import transformer as tr
     from geot_amd.pointops.functions import pointops
     from geot_amd.pointnet2 import pointnet2_utils as pu
     dev = torch.device("cuda:0")
-    xyz_np, pos, _ = _batch(2, 24000, dev)
+    xyz_np, pos, _ = _batch(2, npts, dev)
     group = tr.Group(512, 32)
     neighborhood, center, flat = group(pos)
     want_c = oracle.fps_dense(xyz_np, 512, 512, True)
     c_np = np.take_along_axis(xyz_np, want_c[..., None].astype(np.int64).repeat(3, -1), 1)
     assert np.array_equal(center.cpu().numpy(), c_np)
     want_nn = oracle.knn_sorted(c_np, xyz_np, 32)[0]
-    got_nn = flat.view(2, 512, 32).cpu().numpy() - (np.arange(2) * 24000)[:, None, None]
+    got_nn = flat.view(2, 512, 32).cpu().numpy() - (np.arange(2) * npts)[:, None, None]
     assert np.array_equal(got_nn, want_nn)
-    off = (np.arange(1, 3) * 24000).astype(np.int32)
+    off = (np.arange(1, 3) * npts).astype(np.int32)
     want8 = oracle.fps_offset(xyz_np.reshape(-1, 3), off, (np.arange(1, 3) * 8192).astype(np.int32)).reshape(2, 8192)
     c8 = pointops.fps(pos, 8192)
     c4 = pointops.fps(pos, 4096)
@@ -537,3 +539,37 @@ def test_max_last_equals_torch_max(shape):
         (y * up).sum().backward()
         res.append((y.detach(), x.grad))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
+def test_poly1_loss_contract_on_bad_labels_and_soft_masks(monkeypatch):
+    """The reference's F.one_hot raises on a label outside [0, C); its mask is multiplied in by VALUE.  The fused kernel
+    cannot raise: it returns NaN (never a silently different loss), GEOT_CHECK_LABELS=1 restores the exception, and a
+    float mask takes the op-by-op path."""
+    from geot_amd.openpoints.loss import Poly1FocalLoss, Poly1FocalLoss_U_corr
+    g = torch.Generator(device="cpu").manual_seed(5)
+    logits = torch.randn(2, 17, 300, generator=g).to(DEV)
+    labels = torch.randint(0, 17, (2, 300), generator=g).to(DEV)
+    conf = torch.rand(2, 300, generator=g).to(DEV)
+    assert torch.isfinite(Poly1FocalLoss()(logits, labels))
+    for bad_value in (-1, 17, 255):
+        bad = labels.clone()
+        bad[1, 7] = bad_value
+        assert torch.isnan(Poly1FocalLoss()(logits, bad))
+        assert torch.isnan(Poly1FocalLoss_U_corr()(logits, bad, conf, thresh=0.0))
+    monkeypatch.setenv("GEOT_CHECK_LABELS", "1")
+    bad = labels.clone()
+    bad[0, 0] = 17
+    with pytest.raises(RuntimeError, match="smaller than num_classes"):
+        Poly1FocalLoss()(logits, bad)
+    bad[0, 0] = -1
+    with pytest.raises(RuntimeError, match="non-negative"):
+        Poly1FocalLoss_U_corr()(logits, bad, conf)
+    monkeypatch.delenv("GEOT_CHECK_LABELS")
+    soft = torch.rand(2, 300, generator=g).to(DEV)
+    got = Poly1FocalLoss_U_corr()(logits, labels, conf, mask=soft)
+    crit = Poly1FocalLoss_U_corr()
+    want = Poly1FocalLoss_U_corr.forward(crit, logits.double(), labels, conf.double(), mask=soft.double())
+    assert abs(got.item() - want.item()) <= 1e-5 * abs(want.item())
+    hard = soft > 0.5
+    assert abs(Poly1FocalLoss_U_corr()(logits, labels, conf, mask=hard).item()
+               - Poly1FocalLoss_U_corr.forward(crit, logits.double(), labels, conf.double(), mask=hard).item()) <= 1e-5

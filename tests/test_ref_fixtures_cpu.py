@@ -193,3 +193,28 @@ def test_package_transformer_blocks_reference_order_equal_the_reference(golden, 
         with torch.no_grad():
             y = mod.eval()(t64(g["groups"]))
         assert np.abs(y.numpy() - g["encoder_eval_y0_f64"]).max() < 1e-12
+
+
+def test_optimizer_parameter_groups_equal_the_reference_factory(golden):
+    """openpoints/optim/optim_factory.py:66-119 executed in place on the model mirrors -> train_step.parameter_groups:
+    the same parameters in the no-decay (1-D, *.bias) and the decay group, in the same order, same weight decay."""
+    from geot_amd.train_step import parameter_groups, make_optimizer
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd.ntm import sig_t_mean
+    g = golden("param_groups_ref.npz")
+    small = dict(trans_dim=384, depth=2, num_heads=4, group_size=16, num_group=32, encoder_dims=256, nclasses=17,
+                 drop_path_rate=0.0, downsample_targets=[256, 128, 64], extract_layers=[1, 2])
+    for tag, model in (("seg", PointTransformer_seg_T(**small)), ("pred", sig_t_mean(17))):
+        ids = {id(p): n for n, p in model.named_parameters()}
+        groups = parameter_groups(model, 1e-4)
+        assert len(groups) == int(g[tag + "_n_groups"])
+        for i, grp in enumerate(groups):
+            assert [ids[id(p)] for p in grp["params"]] == [str(n) for n in g["%s_g%d_names" % (tag, i)]]
+            assert grp["weight_decay"] == float(g["%s_g%d_weight_decay" % (tag, i)])
+            assert grp["lr_scale"] == float(g["%s_g%d_lr_scale" % (tag, i)])
+        opt = make_optimizer(model, 1e-3, 1e-4)
+        decays = {ids[id(p)]: grp["weight_decay"] for grp in opt.param_groups for p in grp["params"]}
+        assert len(decays) == len(ids)
+        if tag == "seg":
+            assert decays["sigma"] == 0.0 and decays["norm.weight"] == 0.0 and decays["seg_head.0.bias"] == 0.0
+            assert decays["blocks.blocks.0.attn.qkv.weight"] == 1e-4 and decays["T_linear.weight"] == 1e-4

@@ -3,6 +3,7 @@ command into the per-kernel JSON summaries kept under profiles/.
 
     python tools/pmc_summary.py traffic <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<command>"
     python tools/pmc_summary.py mfma <counter_collection.csv> <out.json> "<command>" <kernel substring>
+    python tools/pmc_summary.py sq <out.json> "<command>" <kernel substring> <counter_collection.csv> [more csv ...]
 
 traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB per launch: FETCH doubled per the gfx950 rule of
 MI355X_MICROARCH.md (HBM section).  Warm-up launches are included in the averages (they move the same bytes).
@@ -46,6 +47,26 @@ def main():
         json.dump({"command": cmd, "commit": commit, "unit": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes); traffic_bytes = "
                    "(2 x FETCH_SIZE + WRITE_SIZE) KB: FETCH doubled per the gfx950 rule in MI355X_MICROARCH.md (HBM section)",
                    "kernels": kernels}, open(out, "w"), indent=1)
+    elif sys.argv[1] == "sq":
+        # issue-side counters of the kernels matching a substring (one or more --pmc passes): what the occupied CUs do
+        out, cmd, sub = sys.argv[2:5]
+        kernels = {}
+        for path in sys.argv[5:]:
+            for k, ctrs in per_kernel(path).items():
+                if sub in k:
+                    rec = kernels.setdefault(short(k), {"launches": 0})
+                    for n, v in ctrs.items():
+                        rec[n] = sum(v) / len(v)
+                        rec["launches"] = max(rec["launches"], len(v))
+        for rec in kernels.values():
+            if rec.get("SQ_WAVES") and rec.get("SQ_WAVE_CYCLES"):
+                rec["cycles_per_wave"] = rec["SQ_WAVE_CYCLES"] / rec["SQ_WAVES"]
+            if rec.get("SQ_INSTS_VALU") and rec.get("SQ_WAVE_CYCLES"):
+                rec["valu_insts_per_wave_cycle"] = rec["SQ_INSTS_VALU"] / rec["SQ_WAVE_CYCLES"]
+            if rec.get("SQ_ACTIVE_INST_VALU") and rec.get("SQ_BUSY_CU_CYCLES"):
+                rec["valu_active_share_of_busy_cu_cycles"] = rec["SQ_ACTIVE_INST_VALU"] / rec["SQ_BUSY_CU_CYCLES"]
+        json.dump({"command": cmd, "unit": "per-launch averages of rocprofv3 --pmc counters (summed over XCDs / SEs as rocprofv3 "
+                   "reports them)", "kernels": kernels}, open(out, "w"), indent=1)
     else:
         path, out, cmd, sub = sys.argv[2:6]
         M = per_kernel(path)

@@ -21,4 +21,16 @@ done
 cd $ROOT
 GEOT_COMMIT=${GEOT_COMMIT:-} python3 tools/pmc_summary.py traffic $OUT/pmc_${TAG}_FETCH_SIZE/pmc_counter_collection.csv $OUT/pmc_${TAG}_WRITE_SIZE/pmc_counter_collection.csv $OUT/${TAG}_pmc_traffic.json "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py $* --steps 2 --warmup 1 --no-cpu-baseline (two separate passes)" > /dev/null 2>$OUT/${TAG}_pmc.err
 rm -rf $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
+# SQ_KERNEL=<substring>: issue-side counters of that kernel (what the CUs it occupies actually do), two passes
+if [ -n "${SQ_KERNEL:-}" ]; then
+  cd /tmp
+  P=1
+  for SET in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS"; do
+    rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/sq_${TAG}_$P -o pmc -- python3 $ROOT/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_sq_$P.log 2>&1
+    P=$((P+1))
+  done
+  cd $ROOT
+  python3 tools/pmc_summary.py sq $OUT/${TAG}_sq_counters.json "rocprofv3 --pmc {SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES | SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_LDS} --kernel-trace -- python3 bench.py $* --steps 2 --warmup 1 --no-cpu-baseline" "$SQ_KERNEL" $OUT/sq_${TAG}_1/pmc_counter_collection.csv $OUT/sq_${TAG}_2/pmc_counter_collection.csv > /dev/null 2>>$OUT/${TAG}_pmc.err
+  rm -rf $OUT/sq_${TAG}_1 $OUT/sq_${TAG}_2
+fi
 head -3 $OUT/${TAG}_window.txt
