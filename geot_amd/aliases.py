@@ -18,8 +18,16 @@ import sys
 import types
 
 
-def install(force=False):
+def install(force=False, binding="ctypes"):
+    """binding: how `pointnet2._ext` reaches the C ABI -- "ctypes" (geot_amd/ext/pointnet2_ext.py, no compiler needed)
+    or "cpp" (the host-only PyTorch cpp_extension geot_amd/csrc_torch/pointnet2_ext_bindings.cpp, built in-tree by
+    geot_amd.build_torch_ext: pybind11 functions taking at::Tensor, as the reference's bindings.cpp:9-22)."""
     from .ext import pointnet2_ext, pointops_cuda, pointnet2_batch_cuda
+    if binding == "cpp":
+        from . import build_torch_ext
+        pointnet2_ext = build_torch_ext.load()
+    elif binding != "ctypes":
+        raise ValueError("binding must be 'ctypes' or 'cpp'")
     from . import knn_cuda
     from .pointnet2 import pointnet2_utils
 

@@ -41,7 +41,8 @@ def enable(tune=False, path=None):
     tunable.tuning_enable(bool(tune))
     tunable.set_filename(work, insert_device_ordinal=False)     # one selection for every rank: the shapes are per rank
     if not tune:
-        tunable.write_file_on_exit(False)                       # nothing was tuned: nothing to write back
+        if hasattr(tunable, "write_file_on_exit"):              # (not in every torch build: the private copy absorbs a
+            tunable.write_file_on_exit(False)                   #  rewrite at exit and is removed afterwards either way)
         ok = False
         try:
             ok = bool(tunable.read_file(work))                  # False on a Validator mismatch (other torch / ROCm / GPU)
