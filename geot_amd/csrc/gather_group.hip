@@ -743,6 +743,267 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
     }
 }
 
+// ---- the same gradient with BALANCED list walks: SELL-64 layout per (batch, part) --------------------------------
+// Where the time of the kernel above goes (tools/gg_lab.py knock-outs at 8 x 1536 x 24000 -> 8192, profiles/
+// r03_gg_lab_knockouts.txt): staging + stores 295 us, the list walk 575 us -- and the walk is lock-step waste, not
+// arithmetic: a (target, part) list has 2.9 entries on average but the longest of the 256 lists a wave walks together
+// has ~9, every lane pays for it (~25 % useful slots), each step costs two per-lane index gathers behind a per-lane
+// offset load, and four 4-byte LDS reads.  Here the lists of one (batch, part) are SORTED BY LENGTH once per call
+// (sell_build_kernel) and stored sliced-ELL: task = 64 lists of (nearly) equal length, entry k of lane l at
+// base + 64 k + l.  A wave walks a task with a wave-uniform trip count, ONE coalesced 8-byte load per step (source
+// id + weight) and ONE 16-byte LDS read (the CH = 4 channels of a source are interleaved in LDS: rows[e][4]).  The
+// sorted order differs from part to part, so the per-target accumulators cannot follow the lists: every lane keeps the
+// sums of its 8 lists of this part in registers, and after the walk the staging buffer -- free until the next part
+// arrives -- carries them to the threads that own the targets (one 16-byte LDS write + read per target and part).
+// RESULT (round 3, MI355X): the walk drops from 558 to 330 us, but the index build grows by 45 us and the exchange costs
+// 85 us, and staging (300 us), walk and exchange still run one after the other (one 144-KB workgroup per CU): 897 us
+// per call against 922 us.  The kernel is therefore NOT the default (GEOT_GATHER_IMPL=sell selects it).
+// Lists longer than SELL_LMAX (never at the model's shapes; a hub target in adversarial input) are walked by a whole
+// wave each, before the exchange.  One writer and one fixed summation order per output: bit-reproducible.
+constexpr int SELL_LMAX = 32;         // longest list stored in the sliced layout (bounds the padding: < 64 * 32 entries)
+constexpr int SELL_MAX_M = 8 * TLDS_THREADS;   // 128 tasks of 64 lists
+constexpr int SELL_THREADS = 1024;    // the gather kernel: 16 waves x 8 tasks (512 threads x 16 tasks: 966 vs 781 us)
+constexpr int SELL_LONG_CAP = 1024;   // long-list results per part kept in LDS (16 KB): >= partlen * nt / (SELL_LMAX + 1), checked by the caller
+struct SellView {
+    const uint2 *ent;   // [bq][cap]   (source id within the part, weight bits)
+    const int *tgt;     // [bq][mp]    target of sorted position p (mp = m rounded up to 64; -1 = padding)
+    const int *tbase;   // [bq][ntask] first entry of a task
+    const int *tlen;    // [bq][ntask] entries per lane of a task
+    const int *nlong;   // [bq]        lists longer than SELL_LMAX
+    const int *longid;  // [bq][m]     their targets
+    int cap, mp, ntask;
+};
+
+// one workgroup per (batch, part): lengths -> counting sort by length (descending) -> task table -> entries
+template <bool WEIGHTED>
+__global__ __launch_bounds__(TLDS_THREADS) void sell_build_kernel(int m, const int *__restrict__ off,
+                                                                  const int *__restrict__ rev, const float *__restrict__ revw,
+                                                                  uint2 *__restrict__ ent, int *__restrict__ tgt,
+                                                                  int *__restrict__ tbase, int *__restrict__ tlen,
+                                                                  int *__restrict__ nlong, int *__restrict__ longid, int cap,
+                                                                  int mp, int ntask)
+{
+    __shared__ int hist[SELL_LMAX + 1], start[SELL_LMAX + 1], nl;
+    __shared__ int tl[SELL_MAX_M / 64], tb[SELL_MAX_M / 64 + 1];
+    __shared__ unsigned char cls_sorted[SELL_MAX_M];
+    const int bq = blockIdx.x, tid = threadIdx.x;
+    const int *offp = off + (size_t)bq * m;
+    if (tid <= SELL_LMAX) hist[tid] = 0;
+    if (tid == 0) nl = 0;
+    for (int p = tid; p < mp; p += TLDS_THREADS) cls_sorted[p] = 0;
+    __syncthreads();
+    constexpr int TPT = SELL_MAX_M / TLDS_THREADS;
+    int a[TPT], len[TPT], cls[TPT], rk[TPT];
+#pragma unroll
+    for (int s = 0; s < TPT; ++s) {
+        const int j = tid + s * TLDS_THREADS;
+        a[s] = j < m ? offp[j] : 0;
+        len[s] = j < m ? offp[j + 1] - a[s] : 0;
+        cls[s] = len[s] > SELL_LMAX ? 0 : len[s];
+        rk[s] = -1;
+        if (j < m) {
+            rk[s] = atomicAdd(&hist[cls[s]], 1);                    // rank inside its length class (any order will do)
+            if (len[s] > SELL_LMAX) longid[(size_t)bq * m + atomicAdd(&nl, 1)] = j;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {                                                 // longest class first
+        int acc = 0;
+        for (int c = SELL_LMAX; c >= 0; --c) { start[c] = acc; acc += hist[c]; }
+        nlong[bq] = nl;
+    }
+    __syncthreads();
+    int pos[TPT];
+#pragma unroll
+    for (int s = 0; s < TPT; ++s) {
+        const int j = tid + s * TLDS_THREADS;
+        pos[s] = j < m ? start[cls[s]] + rk[s] : -1;
+        if (j < m) {
+            tgt[(size_t)bq * mp + pos[s]] = j;
+            cls_sorted[pos[s]] = (unsigned char)cls[s];
+        }
+    }
+    for (int p = m + tid; p < mp; p += TLDS_THREADS) tgt[(size_t)bq * mp + p] = -1;    // padding lanes of the last task
+    __syncthreads();
+    if (tid < ntask) tl[tid] = cls_sorted[tid * 64];                // sorted descending: the first list of a task is its longest
+    __syncthreads();
+    if (tid == 0) {     // entry bases in WAVE-MAJOR order: the tasks of gather wave w (w, w + W, w + 2W, ...) are contiguous
+        constexpr int W = SELL_THREADS / 64;
+        int acc = 0;
+        for (int w = 0; w < W; ++w)
+            for (int t = w; t < ntask; t += W) { tb[t] = acc; acc += 64 * tl[t]; }
+        tb[ntask] = acc;
+    }
+    __syncthreads();
+    if (tid < ntask) {
+        tbase[(size_t)bq * ntask + tid] = tb[tid];
+        tlen[(size_t)bq * ntask + tid] = tb[ntask] <= cap ? tl[tid] : 0;   // (cannot happen: the padding is < 64 * SELL_LMAX)
+    }
+    if (tb[ntask] > cap) return;
+    uint2 *dst = ent + (size_t)bq * cap;
+#pragma unroll
+    for (int s = 0; s < TPT; ++s) {
+        if (pos[s] < 0) continue;
+        const int task = pos[s] >> 6, lane = pos[s] & 63, L = tl[task];
+        for (int k = 0; k < L; ++k) {
+            const bool in = k < cls[s];
+            dst[tb[task] + k * 64 + lane] = make_uint2(in ? (unsigned)rev[a[s] + k] : 0u,
+                                                       in ? __float_as_uint(WEIGHTED ? revw[a[s] + k] : 1.f) : 0u);
+        }
+    }
+}
+
+template <bool WEIGHTED>
+__global__ __launch_bounds__(SELL_THREADS) void table_gather_sell_kernel(
+    int c, int m, int L, int Q, int partlen, const float *__restrict__ grad_out, size_t src_bstride,
+    const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw, SellView sv,
+    float *__restrict__ grad_table, int set)
+{
+    constexpr int CH = 4, TPT = SELL_MAX_M / SELL_THREADS, WAVES = SELL_THREADS / 64;
+    extern __shared__ float tlds_rows[];                 // [partlen][CH] staged sources; afterwards [mp][CH] list sums
+    __shared__ float longres[SELL_LONG_CAP][CH];
+    float4 *rows4 = reinterpret_cast<float4 *>(tlds_rows);
+    const int bi = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, c - c0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float acc[TPT][CH];
+#pragma unroll
+    for (int p = 0; p < TPT; ++p)
+#pragma unroll
+        for (int l = 0; l < CH; ++l) acc[p][l] = 0.f;
+    for (int part = 0; part < Q; ++part) {
+        const int bq = bi * Q + part, p0 = part * partlen, plen = min(partlen, L - p0);
+        if (part) __syncthreads();                       // the exchange of the previous part has been read
+        // stage CH rows of this part interleaved: rows4[e] = (g[c0][e], g[c0+1][e], g[c0+2][e], g[c0+3][e])
+#ifndef GEOT_SELL_LAB_NOSTAGE
+        {
+            const float *g0 = grad_out + (size_t)bi * src_bstride + (size_t)c0 * L + p0;
+            if (nch == CH && (L & 3) == 0 && (p0 & 3) == 0 && (((uintptr_t)g0) & 15) == 0) {
+                // 16-byte loads from each of the four rows, a 4 x 4 transpose in registers, 16-byte LDS stores
+                const int quads = plen >> 2;
+                for (int q4 = tid; q4 < quads; q4 += SELL_THREADS) {
+                    const float4 a0 = reinterpret_cast<const float4 *>(g0)[q4];
+                    const float4 a1 = reinterpret_cast<const float4 *>(g0 + (size_t)L)[q4];
+                    const float4 a2 = reinterpret_cast<const float4 *>(g0 + 2 * (size_t)L)[q4];
+                    const float4 a3 = reinterpret_cast<const float4 *>(g0 + 3 * (size_t)L)[q4];
+                    rows4[4 * q4 + 0] = make_float4(a0.x, a1.x, a2.x, a3.x);
+                    rows4[4 * q4 + 1] = make_float4(a0.y, a1.y, a2.y, a3.y);
+                    rows4[4 * q4 + 2] = make_float4(a0.z, a1.z, a2.z, a3.z);
+                    rows4[4 * q4 + 3] = make_float4(a0.w, a1.w, a2.w, a3.w);
+                }
+                for (int e = (quads << 2) + tid; e < plen; e += SELL_THREADS)
+                    rows4[e] = make_float4(g0[e], g0[(size_t)L + e], g0[2 * (size_t)L + e], g0[3 * (size_t)L + e]);
+            } else {
+                for (int e = tid; e < plen; e += SELL_THREADS) {
+                    float4 v;
+                    v.x = g0[e];
+                    v.y = nch > 1 ? g0[(size_t)L + e] : 0.f;
+                    v.z = nch > 2 ? g0[2 * (size_t)L + e] : 0.f;
+                    v.w = nch > 3 ? g0[3 * (size_t)L + e] : 0.f;
+                    rows4[e] = v;
+                }
+            }
+        }
+#endif
+        __syncthreads();
+        // Walk this wave's TPT tasks (task = wave + 16 s: the sorted order puts the long tasks first, so every wave gets a
+        // mix): wave-uniform trip counts, one coalesced 8-byte load and one 16-byte LDS read per entry.
+        // (Measured alternatives, profiles/r03_gg_lab_sell.txt: all tasks advanced together one entry per round, and one
+        // flattened stream per wave with 8 loads in flight -- both slower: 24-50 spilled registers under the 128-register
+        // budget of a 1024-thread workgroup, 512 threads x 16 tasks leave too few waves to hide the round trips.)
+        float res[TPT][CH];
+        const uint2 *ent = sv.ent + (size_t)bq * sv.cap;
+#pragma unroll
+        for (int s = 0; s < TPT; ++s) {
+            const int task = wave + s * WAVES;
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            if (task < sv.ntask) {
+                const int base = sv.tbase[(size_t)bq * sv.ntask + task];
+                int len = sv.tlen[(size_t)bq * sv.ntask + task];
+#ifdef GEOT_SELL_LAB_NOWALK
+                len = 0;
+#endif
+                const uint2 *q = ent + base + lane;
+                int k = 0;
+                for (; k + 4 <= len; k += 4) {           // 4 independent 8-byte loads + 4 LDS reads in flight
+                    const uint2 e0 = q[(k + 0) * 64], e1 = q[(k + 1) * 64], e2 = q[(k + 2) * 64], e3 = q[(k + 3) * 64];
+                    const float4 v0 = rows4[e0.x], v1 = rows4[e1.x], v2 = rows4[e2.x], v3 = rows4[e3.x];
+                    float w = __uint_as_float(e0.y);
+                    r0 = fmaf(w, v0.x, r0); r1 = fmaf(w, v0.y, r1); r2 = fmaf(w, v0.z, r2); r3 = fmaf(w, v0.w, r3);
+                    w = __uint_as_float(e1.y);
+                    r0 = fmaf(w, v1.x, r0); r1 = fmaf(w, v1.y, r1); r2 = fmaf(w, v1.z, r2); r3 = fmaf(w, v1.w, r3);
+                    w = __uint_as_float(e2.y);
+                    r0 = fmaf(w, v2.x, r0); r1 = fmaf(w, v2.y, r1); r2 = fmaf(w, v2.z, r2); r3 = fmaf(w, v2.w, r3);
+                    w = __uint_as_float(e3.y);
+                    r0 = fmaf(w, v3.x, r0); r1 = fmaf(w, v3.y, r1); r2 = fmaf(w, v3.z, r2); r3 = fmaf(w, v3.w, r3);
+                }
+                for (; k < len; ++k) {
+                    const uint2 e0 = q[k * 64];
+                    const float4 v0 = rows4[e0.x];
+                    const float w = __uint_as_float(e0.y);
+                    r0 = fmaf(w, v0.x, r0); r1 = fmaf(w, v0.y, r1); r2 = fmaf(w, v0.z, r2); r3 = fmaf(w, v0.w, r3);
+                }
+            }
+            res[s][0] = r0; res[s][1] = r1; res[s][2] = r2; res[s][3] = r3;
+        }
+        // hub targets (more than SELL_LMAX sources in this part): one wave per list, straight from the CSR arrays
+        const int nlong = sv.nlong[bq];
+        for (int li = wave; li < nlong; li += WAVES) {
+            const int j = sv.longid[(size_t)bq * m + li];
+            const int a = off[(size_t)bq * m + j], z = off[(size_t)bq * m + j + 1];
+            float r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
+            for (int q = a + lane; q < z; q += 64) {
+                const float4 v = rows4[rev[q]];
+                const float w = WEIGHTED ? revw[q] : 1.f;
+                r0 = fmaf(w, v.x, r0); r1 = fmaf(w, v.y, r1); r2 = fmaf(w, v.z, r2); r3 = fmaf(w, v.w, r3);
+            }
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                r0 += __shfl_xor(r0, o); r1 += __shfl_xor(r1, o); r2 += __shfl_xor(r2, o); r3 += __shfl_xor(r3, o);
+            }
+            if (lane == 0 && li < SELL_LONG_CAP) {       // (li < cap always: the caller bounds partlen * nt)
+                longres[li][0] = r0; longres[li][1] = r1; longres[li][2] = r2; longres[li][3] = r3;
+            }
+        }
+        __syncthreads();                                 // every wave is done reading the staged rows
+        // the exchange: sum of the list of target j -> rows4[j]
+#pragma unroll
+        for (int s = 0; s < TPT; ++s) {
+            const int task = wave + s * WAVES;
+            if (task < sv.ntask) {
+                const int j = sv.tgt[(size_t)bq * sv.mp + task * 64 + lane];
+                if (j >= 0) rows4[j] = make_float4(res[s][0], res[s][1], res[s][2], res[s][3]);
+            }
+        }
+        __syncthreads();
+        for (int li = tid; li < min(nlong, SELL_LONG_CAP); li += SELL_THREADS) {
+            const int j = sv.longid[(size_t)bq * m + li];                    // its sliced list is empty: rows4[j] holds 0
+            rows4[j] = make_float4(longres[li][0], longres[li][1], longres[li][2], longres[li][3]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < TPT; ++p) {
+            const int j = tid + p * SELL_THREADS;
+            if (j < m) {
+                const float4 v = rows4[j];
+                acc[p][0] += v.x; acc[p][1] += v.y; acc[p][2] += v.z; acc[p][3] += v.w;
+            }
+        }
+    }
+    // exactly one writer per output element
+#pragma unroll
+    for (int p = 0; p < TPT; ++p) {
+        const int j = tid + p * SELL_THREADS;
+        if (j < m) {
+#pragma unroll
+            for (int l = 0; l < CH; ++l)
+                if (l < nch) {
+                    float *dst = grad_table + ((size_t)bi * c + c0 + l) * m + j;
+                    *dst = set ? acc[p][l] : *dst + acc[p][l];
+                }
+        }
+    }
+}
+
 // ints needed in the workspace for the reverse index of (b, L, nt) pairs onto m targets per batch
 // Parts: with whole rows in LDS only TLDS_FLOATS / L channels share a workgroup, and each of them re-reads the
 // whole index (8 bytes per pair): at L = 24 000 that is one channel per workgroup and 4.4x more index than
@@ -768,6 +1029,22 @@ static inline long long rix_ws_ints(int b, int c, int m, long long L, int nt)
 {
     const long long t = (long long)b * rix_plan(c, L).Q * m, pairs = (long long)b * L * nt;
     return (t + 1) + scan_blocks(t) + 4 * pairs + 8;   // counts, scan scratch, rank, rev, revw, pair ids
+}
+// extra ints for the sliced (SELL) copy of the index: entries (8 bytes each, padded per (batch, part)), sorted targets,
+// task table, hub lists
+struct SellPlan {
+    int cap, mp, ntask;
+    long long ints;
+};
+static inline SellPlan sell_plan(int b, int Q, int m, int partlen, int nt)
+{
+    SellPlan p;
+    p.cap = partlen * nt + 64 * SELL_LMAX;
+    p.mp = (m + 63) & ~63;
+    p.ntask = p.mp / 64;
+    const long long bq = (long long)b * Q;
+    p.ints = bq * (2LL * p.cap + p.mp + 2LL * p.ntask + 1 + m) + 16;
+    return p;
 }
 
 static bool csr_applies(int b, int c, int m, long long L, int nt, long long ws_floats)
@@ -815,6 +1092,33 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     if (overwrite && !set) {
         e = zero_words(grad_table, (long long)b * c * m, s);
         if (e != hipSuccess) return e;
+    }
+    if (parts_inside && ch == 4 && m <= SELL_MAX_M && impl && impl[0] == 's' &&
+        (long long)rp.partlen * NT / (SELL_LMAX + 1) <= SELL_LONG_CAP) {
+        // GEOT_GATHER_IMPL=sell: balanced walk over a sliced copy of the index (table_gather_sell_kernel), when the
+        // workspace has room for it.  Opt-in: measured 897 us against 922 us for the per-target walk below at the model's
+        // largest shape and 314 against 292 us at C = 384 (profiles/r03_gg_lab_sell.txt) -- not a win worth a second
+        // index format; kept because it isolates what the walk costs once its lock-step waste is gone.
+        const SellPlan sp = sell_plan(b, Q, m, rp.partlen, NT);
+        const long long used = rix_ws_ints(b, c, m, L, NT);
+        const size_t lds_sell = (size_t)(rp.partlen > sp.mp ? rp.partlen : sp.mp) * 4 * sizeof(float);
+        if (ws_floats >= used + sp.ints && lds_sell + SELL_LONG_CAP * 4 * sizeof(float) + 64 <= 160 * 1024) {
+            int *base = (int *)workspace + ((used + 1) & ~1LL);          // 8-byte aligned entries
+            uint2 *ent = (uint2 *)base;
+            int *tgt = base + 2LL * b * Q * sp.cap;
+            int *tbase = tgt + (long long)b * Q * sp.mp;
+            int *tlen = tbase + (long long)b * Q * sp.ntask;
+            int *nlong = tlen + (long long)b * Q * sp.ntask;
+            int *longid = nlong + (long long)b * Q;
+            hipLaunchKernelGGL((sell_build_kernel<WEIGHTED>), dim3(b * Q), dim3(TLDS_THREADS), 0, s, m, off, rev, revw, ent, tgt,
+                               tbase, tlen, nlong, longid, sp.cap, sp.mp, sp.ntask);
+            e = tlds_set_lds(table_gather_sell_kernel<WEIGHTED>, lds_sell);
+            if (e != hipSuccess) return e;
+            const SellView sv{ent, tgt, tbase, tlen, nlong, longid, sp.cap, sp.mp, sp.ntask};
+            hipLaunchKernelGGL((table_gather_sell_kernel<WEIGHTED>), dim3(1, chunks, b), dim3(SELL_THREADS), lds_sell, s, c, m, L,
+                               Q, rp.partlen, grad_out, src_bstride, off, rev, revw, sv, grad_table, set);
+            return hipGetLastError();
+        }
     }
     if (parts_inside) {
         // parts looped inside the workgroup: one writer per output, no atomics, reproducible

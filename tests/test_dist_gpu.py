@@ -19,8 +19,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = dict(trans_dim=384, depth=2, num_heads=4, group_size=16, num_group=64, encoder_dims=256, nclasses=17,
-             drop_path_rate=0.0, downsample_targets=[1024, 512, 256], extract_layers=[1, 2])
+SMALL = dict(trans_dim=384, depth=3, num_heads=4, group_size=16, num_group=64, encoder_dims=256, nclasses=17,
+             drop_path_rate=0.0, downsample_targets=[1024, 512, 256], extract_layers=[1, 2, 3])
 N = 2048
 
 
@@ -102,7 +102,7 @@ def _run_iteration(dev, rank=None):
             for n, p in inner.named_parameters():
                 if p.grad is not None and (tag == "t" or n.endswith(("seg_head.3.weight", "reduce_dim.weight", "sigma",
                                                                      "propogation_0.mlp.layer0.conv.weight",
-                                                                     "encoder.first_conv.1.weight", "blocks.blocks.1.attn.qkv.weight"))):
+                                                                     "encoder.first_conv.1.weight", "blocks.blocks.2.attn.qkv.weight"))):
                     grads[tag + ":" + n] = p.grad.detach().cpu().numpy().copy()
             return orig(*a, **k)
         opt.step = stepper
@@ -131,7 +131,18 @@ def test_fixmatch_iteration_on_two_ranks_equals_the_single_process_iteration():
     procs = [ctx.Process(target=_fixmatch_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
+    import queue
+    res = []
+    while len(res) < len(procs):                     # a rank that dies must fail the test, not leave it waiting
+        try:
+            res.append(q.get(timeout=5))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead:
+                for p in procs:
+                    p.terminate()
+                pytest.fail("a rank exited with %s" % dead)
+    res.sort(key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -148,4 +159,4 @@ def test_fixmatch_iteration_on_two_ranks_equals_the_single_process_iteration():
     for k, w in grads.items():
         np.testing.assert_array_equal(g0[k], g1[k])                 # DDP: both ranks step with the same averaged gradient
         err = np.linalg.norm(g0[k] - w) / (np.linalg.norm(w) + 1e-12)
-        assert err <= 2e-3, (k, err)                                # fp32: batch-size dependent GEMM blocking / summation order
+        assert err <= 5e-3, (k, err)                                # fp32: batch-size dependent GEMM blocking / summation order

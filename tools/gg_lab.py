@@ -19,7 +19,13 @@ VARIANTS = {
     "noidx": ["-DGEOT_GG_LAB_NOIDX"],
     "noldsread": ["-DGEOT_GG_LAB_NOLDSREAD"],
     "walk_noidx_nolds": ["-DGEOT_GG_LAB_NOSTAGE", "-DGEOT_GG_LAB_NOIDX", "-DGEOT_GG_LAB_NOLDSREAD"],
+    "sell_nostage": ["-DGEOT_SELL_LAB_NOSTAGE"],
+    "sell_nowalk": ["-DGEOT_SELL_LAB_NOWALK"],
+    "sell_neither": ["-DGEOT_SELL_LAB_NOSTAGE", "-DGEOT_SELL_LAB_NOWALK"],
 }
+ONLY = os.environ.get("VARIANTS")
+if ONLY:
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in ONLY.split(",")}
 for extra in sys.argv[2:]:
     if "=" in extra:
         k, v = extra.split("=", 1)
