@@ -52,7 +52,10 @@ def test_cpp_binding_equals_the_ctypes_binding():
         known = torch.randn(2, 24, 1500, generator=g).to(DEV)
         assert torch.equal(mod_a.three_interpolate(known, na, w), mod_b.three_interpolate(known, nb, w))
         up2 = torch.randn(2, 24, 6000, generator=g).to(DEV)
-        assert torch.equal(mod_a.three_interpolate_grad(up2, na, w, 1500), mod_b.three_interpolate_grad(up2, nb, w, 1500))
+        # (24 channels x 1500 targets: too small a workspace for the reverse index -> the channels-last atomic scatter,
+        # whose fp32 sums are not bit-reproducible from call to call)
+        assert torch.allclose(mod_a.three_interpolate_grad(up2, na, w, 1500), mod_b.three_interpolate_grad(up2, nb, w, 1500),
+                              rtol=1e-5, atol=1e-5)
         assert torch.equal(mod_a.gather_points_grad(ca, ia, 6000), mod_b.gather_points_grad(cb, ib, 6000))
     # launches follow torch's current stream
     s = torch.cuda.Stream()

@@ -151,8 +151,8 @@ def test_whole_model_both_orders_against_the_fp64_reference_order(oracle):
     from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
     from geot_amd.synth import make_batch, region_labels
     from oracle import torch_cpu_ref
-    cfg = dict(trans_dim=384, depth=2, num_heads=4, group_size=32, num_group=128, encoder_dims=256, nclasses=17,
-               drop_path_rate=0.0, downsample_targets=[2048, 1024, 512], extract_layers=[1, 2])
+    cfg = dict(trans_dim=384, depth=3, num_heads=4, group_size=32, num_group=128, encoder_dims=256, nclasses=17,
+               drop_path_rate=0.0, downsample_targets=[2048, 1024, 512], extract_layers=[1, 2, 3])
     xyz = make_batch(2, 4096, start_index=5)[0]
     target = torch.from_numpy(region_labels(xyz))
     cls = torch.tensor([[0], [1]])

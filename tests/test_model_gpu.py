@@ -546,6 +546,7 @@ def test_poly1_loss_contract_on_bad_labels_and_soft_masks(monkeypatch):
     cannot raise: it returns NaN (never a silently different loss), GEOT_CHECK_LABELS=1 restores the exception, and a
     float mask takes the op-by-op path."""
     from geot_amd.openpoints.loss import Poly1FocalLoss, Poly1FocalLoss_U_corr
+    DEV = torch.device("cuda:0")
     g = torch.Generator(device="cpu").manual_seed(5)
     logits = torch.randn(2, 17, 300, generator=g).to(DEV)
     labels = torch.randint(0, 17, (2, 300), generator=g).to(DEV)
