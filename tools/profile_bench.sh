@@ -11,15 +11,15 @@ mkdir -p $OUT
 cd $ROOT
 python3 bench.py "$@" > $OUT/$TAG.json 2> $OUT/$TAG.err || { echo "bench failed"; tail -5 $OUT/$TAG.err; exit 1; }
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o kt -- python3 $ROOT/bench.py "$@" --steps 3 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o kt -- python3 $ROOT/bench.py "$@" --steps 4 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_kt.log 2>&1
 cp $OUT/prof_$TAG/kt_kernel_stats.csv $OUT/${TAG}_kernel_stats.csv
-python3 $ROOT/tools/trace_window.py $OUT/prof_$TAG/kt_kernel_trace.csv --skip 2 --steps 3 -o $OUT/${TAG}_window.csv --per-launch $OUT/${TAG}_launches.csv > $OUT/${TAG}_window.txt 2>&1
+python3 $ROOT/tools/trace_window.py $OUT/prof_$TAG/kt_kernel_trace.csv --skip 2 --steps 3 --anchors-per-step ${ANCHORS_PER_STEP:-1} -o $OUT/${TAG}_window.csv --per-launch $OUT/${TAG}_launches.csv > $OUT/${TAG}_window.txt 2>&1
 rm -rf $OUT/prof_$TAG
 for CTR in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$CTR -o pmc -- python3 $ROOT/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$CTR.log 2>&1
 done
 cd $ROOT
-GEOT_COMMIT=${GEOT_COMMIT:-} python3 tools/pmc_summary.py traffic $OUT/pmc_${TAG}_FETCH_SIZE/pmc_counter_collection.csv $OUT/pmc_${TAG}_WRITE_SIZE/pmc_counter_collection.csv $OUT/${TAG}_pmc_traffic.json "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py $* --steps 2 --warmup 1 --no-cpu-baseline (two separate passes)" > /dev/null 2>$OUT/${TAG}_pmc.err
+GEOT_COMMIT=${GEOT_COMMIT:-unknown (set GEOT_COMMIT when profiling from a snapshot without .git)} python3 tools/pmc_summary.py traffic $OUT/pmc_${TAG}_FETCH_SIZE/pmc_counter_collection.csv $OUT/pmc_${TAG}_WRITE_SIZE/pmc_counter_collection.csv $OUT/${TAG}_pmc_traffic.json "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py $* --steps 2 --warmup 1 --no-cpu-baseline (two separate passes)" > /dev/null 2>$OUT/${TAG}_pmc.err
 rm -rf $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
 # SQ_KERNEL=<substring>: issue-side counters of that kernel (what the CUs it occupies actually do), two passes
 if [ -n "${SQ_KERNEL:-}" ]; then

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--min-us", type=float, default=1000.0, help="anchor launches shorter than this are ignored")
     ap.add_argument("--skip", type=int, default=2)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--anchors-per-step", type=int, default=1,
+                    help="anchor launches per step (the FixMatch iteration runs the 8192-sample FPS twice: teacher + student)")
     ap.add_argument("-o", "--out", default=None)
     ap.add_argument("--top", type=int, default=60)
     ap.add_argument("--per-launch", default=None, help="also write every launch of the first window step, in start order")
@@ -34,8 +36,9 @@ def main():
     full = rows
     rows = [r[:3] for r in rows]
     anchors = [s for s, e, n in rows if a.anchor in n and (e - s) >= a.min_us * 1e3]
-    assert len(anchors) > a.skip + a.steps, "only %d anchor launches" % len(anchors)
-    t0, t1 = anchors[a.skip], anchors[a.skip + a.steps]
+    k = a.anchors_per_step
+    assert len(anchors) > (a.skip + a.steps) * k, "only %d anchor launches" % len(anchors)
+    t0, t1 = anchors[a.skip * k], anchors[(a.skip + a.steps) * k]
     agg = collections.defaultdict(lambda: [0, 0])
     for s, e, n in rows:
         if t0 <= s < t1:
@@ -55,7 +58,7 @@ def main():
             w = csv.writer(f)
             w.writerow(("start_us", "dur_us", "grid_x", "wg_x", "lds", "stream", "kernel"))
             for s, e, n, g, wg, lds, st in full:
-                if t0 <= s < anchors[a.skip + 1]:
+                if t0 <= s < anchors[(a.skip + 1) * k]:
                     w.writerow(("%.1f" % ((s - t0) / 1e3), "%.1f" % ((e - s) / 1e3), g, wg, lds, st, n[:110]))
     if a.out:
         with open(a.out, "w", newline="") as f:
