@@ -155,9 +155,12 @@ hipError_t gen_sig_t_mean(bool backward, int b, int n, int c, const float *p, co
     const void *fn = backward ? (const void *)gen_sig_t_mean_kernel<true> : (const void *)gen_sig_t_mean_kernel<false>;
     hipError_t e = allow_big_lds(fn, lds);
     if (e != hipSuccess) return e;
-    // few, fat workgroups: each stages the (C+1) C^2 weight floats once
+    // persistent workgroups, as many per CU as the staged weights ((C+1) C^2 floats each) leave room for in LDS:
+    // the inner loop is a chain of LDS reads, it needs waves to hide behind (2 per SIMD measured 0.23 TB/s at C = 16)
     long long blocks = ((long long)b * n + 3) / 4;
-    const long long cap = lds > 64 * 1024 ? 256 : 512;
+    long long per_cu = (160 * 1024) / (long long)(lds + 512);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+    const long long cap = per_cu * device_cus();
     if (blocks > cap) blocks = cap;
     if (backward)
         hipLaunchKernelGGL(gen_sig_t_mean_kernel<true>, dim3((int)blocks), dim3(256), lds, s, b * n, n, c, p, W, cm, grad_out, out);

@@ -268,3 +268,21 @@ def test_fixmatch_iteration_at_the_configured_sizes(npts):
         runs.append([float(v) for o in out for v in o.values()])
     for a, b in zip(*runs):
         assert abs(a - b) <= 5e-5 * abs(a) + 1e-7, runs
+
+
+@pytest.mark.parametrize("n", [24576, 24577, 32768])
+def test_fps_at_the_switch_between_the_pruned_and_the_streaming_kernel(n, oracle):
+    """n <= 24 576 points live in the registers of one workgroup (bucket-pruned kernel); one point more and the
+    unpruned / streaming kernels take over.  Both sides of the wall against the oracle: K1 (origin skip, 512-thread tie
+    rule), K1' (1024) and the offset-batched K2, with duplicates."""
+    from geot_amd.ext import pointnet2_ext as p2
+    from geot_amd.pointops.functions import pointops
+    from geot_amd.openpoints.models.layers import subsample
+    xyz = make_batch(2, n, start_index=300, dup_frac=0.01)[0]
+    x = torch.from_numpy(xyz).to(DEV)
+    m = 1500
+    assert np.array_equal(p2.furthest_point_sampling(x, m).cpu().numpy(), oracle.fps_dense(xyz, m, 512, True))
+    assert np.array_equal(subsample.furthest_point_sample(x, m).cpu().numpy(), oracle.fps_dense(xyz, m, 1024, False))
+    off = (np.arange(1, 3) * n).astype(np.int32)
+    want = oracle.fps_offset(xyz.reshape(-1, 3), off, (np.arange(1, 3) * m).astype(np.int32)).reshape(2, m)
+    assert np.array_equal(pointops.fps(x, m).cpu().numpy(), xyz.reshape(-1, 3)[want])

@@ -19,7 +19,7 @@ for CTR in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $CTR --kernel-trace --output-format csv -d $OUT/pmc_${TAG}_$CTR -o pmc -- python3 $ROOT/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_pmc_$CTR.log 2>&1
 done
 cd $ROOT
-GEOT_COMMIT=${GEOT_COMMIT:-unknown (set GEOT_COMMIT when profiling from a snapshot without .git)} python3 tools/pmc_summary.py traffic $OUT/pmc_${TAG}_FETCH_SIZE/pmc_counter_collection.csv $OUT/pmc_${TAG}_WRITE_SIZE/pmc_counter_collection.csv $OUT/${TAG}_pmc_traffic.json "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py $* --steps 2 --warmup 1 --no-cpu-baseline (two separate passes)" > /dev/null 2>$OUT/${TAG}_pmc.err
+GEOT_COMMIT="${GEOT_COMMIT:-unknown}" python3 tools/pmc_summary.py traffic $OUT/pmc_${TAG}_FETCH_SIZE/pmc_counter_collection.csv $OUT/pmc_${TAG}_WRITE_SIZE/pmc_counter_collection.csv $OUT/${TAG}_pmc_traffic.json "rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace -- python3 bench.py $* --steps 2 --warmup 1 --no-cpu-baseline (two separate passes)" > /dev/null 2>$OUT/${TAG}_pmc.err
 rm -rf $OUT/pmc_${TAG}_FETCH_SIZE $OUT/pmc_${TAG}_WRITE_SIZE
 # SQ_KERNEL=<substring>: issue-side counters of that kernel (what the CUs it occupies actually do), two passes
 if [ -n "${SQ_KERNEL:-}" ]; then
