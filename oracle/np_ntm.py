@@ -5,9 +5,10 @@ Follows, line by line:
   * class-T / prior / EMA block   examples/segmentation/train.py:505-545, 556-557, 835-836 (+ LABEL_PROJ :48)
   * logit correction              examples/segmentation/train.py:547-552
   * threeD_space_loss.forward     utils/insT_loss.py:68-110
-The reference hard-codes .cuda() in all of these, so it cannot run in the build container
-(SURVEY.md section 8c); parity is therefore pinned by these restatements, which are checked
-against autograd / finite differences in tests/test_ntm_cpu.py.
+Pinned (round 3): tests/golden/make_ntm_golden.py executes the reference's own class bodies / statement ranges
+in place on the CPU (Tensor.cuda made the identity) in fp32 and fp64 and stores inputs, outputs and autograd
+gradients; tests/test_ref_fixtures_cpu.py holds every function below to the fp64 runs at 1e-13.
+tests/test_ntm_cpu.py additionally checks them against autograd / finite differences of literal transcriptions.
 """
 import numpy as np
 
