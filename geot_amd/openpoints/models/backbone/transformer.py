@@ -305,7 +305,7 @@ class DGCNN_Propagation(nn.Module):
         """(B, 2C, Nq, k) = cat(x_k[nbr] - x_q, x_q), one fused kernel (transformer.py:343-364)."""
         return graph_feature(x_q, x_k, _knn_idx(coor_q, coor_k, self.k))
 
-    def _edge(self, layer, coor_q, x_q, coor_k, x_k):
+    def _edge(self, layer, coor_q, x_q, coor_k, x_k, idx=None):
         conv, norm, act = layer[0], layer[1], layer[2]
         if self.dense != "factored":
             y = conv(self.get_graph_feature(coor_q, x_q, coor_k, x_k))
@@ -313,7 +313,8 @@ class DGCNN_Propagation(nn.Module):
             c = x_q.shape[1]
             w = conv.weight.view(conv.out_channels, 2 * c)
             w_d, w_q = w[:, :c], w[:, c:]
-            idx = _knn_idx(coor_q, coor_k, self.k)
+            if idx is None:      # (the model hands in the ids it searched on its side stream, see _index_plan)
+                idx = _knn_idx(coor_q, coor_k, self.k)
             p = pointwise(w_d, x_k)                                      # (B, Cout, Nk)
             q = pointwise(w_q - w_d, x_q)                                # (B, Cout, Nq)
             if (self.fused_tail and p.is_cuda and isinstance(norm, nn.GroupNorm) and norm.affine and isinstance(act, nn.LeakyReLU)
@@ -322,27 +323,35 @@ class DGCNN_Propagation(nn.Module):
             y = pt_utils.grouping_operation(p.contiguous(), idx) + q.unsqueeze(-1)
         return act(norm(y)).max(dim=-1, keepdim=False)[0]
 
-    def forward(self, coor, f, coor_q, f_q):
-        """coor, f: (B,3,G), (B,C,G) source; coor_q, f_q: (B,3,N), (B,C,N) target."""
-        f_q = self._edge(self.layer1, coor_q, f_q, coor, f)
-        return self._edge(self.layer2, coor_q, f_q, coor_q, f_q)
+    def forward(self, coor, f, coor_q, f_q, idx=None):
+        """coor, f: (B,3,G), (B,C,G) source; coor_q, f_q: (B,3,N), (B,C,N) target.  idx (optional): the two kNN id
+        tensors (queries among the sources, queries among themselves), when the caller has searched them already."""
+        i1, i2 = idx if idx is not None else (None, None)
+        f_q = self._edge(self.layer1, coor_q, f_q, coor, f, i1)
+        return self._edge(self.layer2, coor_q, f_q, coor_q, f_q, i2)
 
 
-def _fp_factored(fp, unknown, known, unknow_feats, known_feats):
+def _fp_factored(fp, unknown, known, unknow_feats, known_feats, nn3=None):
     """forward of a PointnetFPModule (pointnet2_modules.py:597-642) with the first 1x1 convolution moved in
-    front of the interpolation (see the module docstring); the parameters are ``fp``'s own."""
+    front of the interpolation (see the module docstring); the parameters are ``fp``'s own.  nn3 (optional): the
+    (idx, weight) pair of three_nn + the inverse-distance weights, when the caller has computed them already."""
     layers = list(fp.mlp.children())
     first = layers[0]
     conv = first.conv
     c = known_feats.shape[1]
     w = conv.weight.view(conv.out_channels, -1)
     a = pointwise(w[:, :c], known_feats)                                 # (B, Cout, m): GEMM on the known points
-    dist2, idx = pt_utils._ext.three_nn(unknown.contiguous(), known.contiguous())
+    if nn3 is None:
+        dist2, idx = pt_utils._ext.three_nn(unknown.contiguous(), known.contiguous())
+        weight = None
+    else:
+        idx, weight = nn3
     has_bn = any(name == "bn" for name, _ in first.named_children())
     post_act = next(iter(first.named_children()))[0] == "conv"            # conv -> BatchNorm -> ReLU order
     if conv.bias is None and has_bn and post_act and fp_front_eligible(a, unknow_feats):
         # interpolation + skip channels + the BatchNorm sums in one kernel, then BatchNorm + ReLU in one pass
-        weight = pt_utils._ext.fp_weights(dist2)
+        if weight is None:
+            weight = pt_utils._ext.fp_weights(dist2)
         y, partial = fp_front(a, idx, weight, unknow_feats, None if unknow_feats is None else w[:, c:])
         relu = any(isinstance(mod, nn.ReLU) for _, mod in first.named_children())
         y = bn_act(first.bn.bn, y, relu=relu, partial=partial)
@@ -350,7 +359,7 @@ def _fp_factored(fp, unknown, known, unknow_feats, known_feats):
             if name not in ("conv", "bn") and not isinstance(mod, nn.ReLU):
                 y = mod(y)
         return shared_mlp_nd(layers[1:], y)
-    y = pt_utils.three_interpolate(a, idx, pt_utils._ext.fp_weights(dist2))
+    y = pt_utils.three_interpolate(a, idx, weight if weight is not None else pt_utils._ext.fp_weights(dist2))
     if unknow_feats is not None:
         y = y + pointwise(w[:, c:], unknow_feats)
     if conv.bias is not None:
@@ -432,10 +441,29 @@ class PointTransformer_seg_T(nn.Module):
             self._side[key] = torch.cuda.Stream(device=device)
         return self._side[key]
 
-    def _fp(self, module, unknown, known, unknow_feats, known_feats):
+    def _fp(self, module, unknown, known, unknow_feats, known_feats, nn3=None):
         if self.dense == "factored":
-            return _fp_factored(module, unknown, known, unknow_feats, known_feats)
+            return _fp_factored(module, unknown, known, unknow_feats, known_feats, nn3)
         return module(unknown, known, unknow_feats, known_feats)
+
+    @torch.no_grad()
+    def _index_plan(self, pts, center):
+        """Everything the decoder needs that depends on the COORDINATES only: the sampled clouds, the three_nn ids +
+        inverse-distance weights of the three FP modules and the four kNN graphs of the EdgeConv stages (the same calls,
+        in the same order, the modules would make themselves).  The model runs this on its side stream behind the long
+        FPS, beside the transformer blocks: 0.73 ms of 8-to-100-CU kernels leave the critical path of the step."""
+        center_pts = [pointops.fps(pts, t) for t in self.downsample_targets]
+        trans = [pt.transpose(-1, -2).contiguous() for pt in center_pts]
+        center_trans = center.transpose(-1, -2).contiguous()
+
+        def nn3(unknown, known):
+            dist2, idx = pt_utils._ext.three_nn(unknown.contiguous(), known.contiguous())
+            return idx, pt_utils._ext.fp_weights(dist2)
+        k2, k1 = self.dgcnn_pro_2.k, self.dgcnn_pro_1.k
+        return {"center_pts": center_pts, "center_pts_trans": trans, "center_trans": center_trans,
+                "fp2": nn3(center_pts[1], center), "fp1": nn3(center_pts[0], center), "fp0": nn3(pts, center_pts[0]),
+                "dg2": (_knn_idx(trans[1], center_trans, k2), _knn_idx(trans[1], trans[1], k2)),
+                "dg1": (_knn_idx(trans[0], trans[1], k1), _knn_idx(trans[0], trans[0], k1))}
 
     def forward(self, pts, x=None, cls_label=None, T=None):
         with pointops.fps_prefix_scope():       # the three pointops.fps targets are prefixes of one FPS run
@@ -454,6 +482,13 @@ class PointTransformer_seg_T(nn.Module):
                 pointops.fps_indices(pts, top)
 
         neighborhood, center, idx = self.group_divider(pts)
+        plan = None
+        if side is not None and self.dense == "factored" and os.environ.get("GEOT_INDEX_PLAN", "side") == "side":
+            grouped = torch.cuda.Event()
+            grouped.record(main)                 # `center` (the 512 group centres) is the one input the plan needs from main
+            with torch.cuda.stream(side):
+                side.wait_event(grouped)
+                plan = self._index_plan(pts, center)
         group_input_tokens = self.reduce_dim(self.encoder(neighborhood))
         pos = self.pos_embed(center)
         inter_feats = self.blocks(group_input_tokens, pos)
@@ -468,15 +503,23 @@ class PointTransformer_seg_T(nn.Module):
             "the length of the cardinality and the features should be the same"
         if side is not None:
             main.wait_stream(side)
-        center_pts = [pointops.fps(pts, t) for t in self.downsample_targets]
-        center_pts_trans = [pt.transpose(-1, -2).contiguous() for pt in center_pts]
+        if plan is not None:
+            center_pts, center_pts_trans = plan["center_pts"], plan["center_pts_trans"]
+        else:
+            plan = {}
+            center_pts = [pointops.fps(pts, t) for t in self.downsample_targets]
+            center_pts_trans = [pt.transpose(-1, -2).contiguous() for pt in center_pts]
 
         f_l3 = inter_feats[2]
-        f_l2 = self._fp(self.propogation_2, center_pts[1], center, center_pts_trans[1], inter_feats[1])
-        f_l1 = self._fp(self.propogation_1, center_pts[0], center, center_pts_trans[0], inter_feats[0])
-        f_l2 = self.dgcnn_pro_2(center_trans, f_l3, center_pts_trans[1], f_l2)
-        f_l1 = self.dgcnn_pro_1(center_pts_trans[1], f_l2, center_pts_trans[0], f_l1)
-        f_l0 = self._fp(self.propogation_0, center_original, center_pts[0], f_l0, f_l1)
+        f_l2 = self._fp(self.propogation_2, center_pts[1], center, center_pts_trans[1], inter_feats[1], plan.get("fp2"))
+        f_l1 = self._fp(self.propogation_1, center_pts[0], center, center_pts_trans[0], inter_feats[0], plan.get("fp1"))
+        if plan.get("dg2") is not None:
+            f_l2 = self.dgcnn_pro_2(center_trans, f_l3, center_pts_trans[1], f_l2, plan["dg2"])
+            f_l1 = self.dgcnn_pro_1(center_pts_trans[1], f_l2, center_pts_trans[0], f_l1, plan["dg1"])
+        else:
+            f_l2 = self.dgcnn_pro_2(center_trans, f_l3, center_pts_trans[1], f_l2)
+            f_l1 = self.dgcnn_pro_1(center_pts_trans[1], f_l2, center_pts_trans[0], f_l1)
+        f_l0 = self._fp(self.propogation_0, center_original, center_pts[0], f_l0, f_l1, plan.get("fp0"))
 
         head = self.seg_head                     # conv -> BatchNorm1d -> Dropout -> conv; the BatchNorm as one fused op
         if self.dense != "reference" and isinstance(head[0], PointwiseConv1d):

@@ -574,3 +574,35 @@ def test_poly1_loss_contract_on_bad_labels_and_soft_masks(monkeypatch):
     hard = soft > 0.5
     assert abs(Poly1FocalLoss_U_corr()(logits, labels, conf, mask=hard).item()
                - Poly1FocalLoss_U_corr.forward(crit, logits.double(), labels, conf.double(), mask=hard).item()) <= 1e-5
+
+
+def test_side_stream_index_plan_changes_nothing_but_the_schedule(monkeypatch):
+    """The decoder's coordinate-only work (sampled clouds, three_nn + weights of the FP modules, the EdgeConv kNN graphs)
+    runs on the side stream behind the long FPS (PointTransformer_seg_T._index_plan): same calls, same results -- logits
+    and every gradient bit-identical to the in-line schedule; also under hipGraph-free repeated calls."""
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    dev = torch.device("cuda:0")
+    _, pos, target = _batch(2, 6000, dev)
+    cls = torch.tensor([[0], [1]], device=dev)
+    torch.manual_seed(0)
+    init = PointTransformer_seg_T(**SMALL).state_dict()
+    res = {}
+    for mode in ("side", "off", "side"):
+        monkeypatch.setenv("GEOT_INDEX_PLAN", mode)
+        m = PointTransformer_seg_T(**SMALL).to(dev).train()
+        m.load_state_dict(init)
+        m.seg_head[2].p = 0.0
+        outs = []
+        for _ in range(2):                       # twice: the second forward re-uses the side stream right after a backward
+            m.zero_grad(set_to_none=True)
+            logit = m(pos, pos.transpose(1, 2).contiguous(), cls, torch.eye(17, device=dev))[0]
+            torch.nn.functional.cross_entropy(logit, target).backward()
+            outs.append((logit.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+        torch.cuda.synchronize()
+        res.setdefault(mode, []).append(outs)
+    a, b = res["side"][0], res["off"][0]
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert torch.equal(la, lb)
+        assert set(ga) == set(gb) and all(torch.equal(ga[k], gb[k]) for k in ga)
+    for (la, ga), (lc, gc) in zip(a, res["side"][1]):
+        assert torch.equal(la, lc) and all(torch.equal(ga[k], gc[k]) for k in ga)
