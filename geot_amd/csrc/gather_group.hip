@@ -657,8 +657,8 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_lds_kernel(
 // bit-reproducible from run to run (the per-part kernel above adds Q partial sums per output with memory-side
 // atomics, in whatever order the parts finish), grad_out is read once, and L is unbounded.  Same speed as the atomic
 // form for the prop0 gradient (340 vs 354 us at 8 clouds): the walk over the per-target lists is the cost of both.
-template <bool WEIGHTED, int CH, int TPT>
-__global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
+template <bool WEIGHTED, int CH, int TPT, int TP = 4, int MINB = 1>
+__global__ __launch_bounds__(TLDS_THREADS, MINB) void table_gather_csr_parts_kernel(
     int c, int m, int L, int Q, int partlen, const float *__restrict__ grad_out, size_t src_bstride,
     const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw,
     float *__restrict__ grad_table, int set)
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(TLDS_THREADS) void table_gather_csr_parts_kernel(
     for (int p = 0; p < TPT; ++p)
 #pragma unroll
         for (int l = 0; l < CH; ++l) acc[p][l] = 0.f;
-    constexpr int RU = 4, TP = 4; // RU 2 -> 4: 1229 -> 1181 us at (8, 1536, 24000 -> 8192); 8: 1269 (registers)
+    constexpr int RU = 4;        // RU 2 -> 4: 1229 -> 1181 us at (8, 1536, 24000 -> 8192); 8: 1269 (registers)
     for (int part = 0; part < Q; ++part) {
         const int p0 = part * partlen, plen = min(partlen, L - p0);
         if (part) __syncthreads(); // the previous part's rows have been read by everyone
@@ -1123,6 +1123,18 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     if (parts_inside) {
         // parts looped inside the workgroup: one writer per output, no atomics, reproducible
         const int tpt = m <= 8 * TLDS_THREADS ? 8 : 16;
+        const char *two = getenv("GEOT_GATHER_CH2");
+        if (two && two[0] == '1' && ch == 4 && tpt == 8) {
+            // LAB (measured, slower: 1177 vs 942 us, profiles/r03_gg_lab_sell.txt D): two channels per workgroup at the same
+            // part length -> 64 KB of LDS, 64 registers: TWO workgroups per CU, one staging while the other walks; twice
+            // the index walks cost more than the overlap buys
+            const size_t lds2 = (size_t)2 * rp.partlen * sizeof(float);
+            e = tlds_set_lds(table_gather_csr_parts_kernel<WEIGHTED, 2, 8, 2, 8>, lds2);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((table_gather_csr_parts_kernel<WEIGHTED, 2, 8, 2, 8>), dim3(1, (c + 1) / 2, b), dim3(TLDS_THREADS),
+                               lds2, s, c, m, L, Q, rp.partlen, grad_out, src_bstride, off, rev, revw, grad_table, set);
+            return hipGetLastError();
+        }
         const dim3 grid(1, chunks, b);
 #define GEOT_PARTS_LAUNCH(CHV, TPTV)                                                                                \
     {                                                                                                               \
