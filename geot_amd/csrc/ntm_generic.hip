@@ -76,6 +76,105 @@ __global__ __launch_bounds__(256) void gen_sig_t_mean_kernel(int total_pts, int 
     }
 }
 
+// ---- sig_t_mean, second form: lane = point ------------------------------------------------------------------------
+// The wave-per-point kernel above reads a weight from LDS for every multiply and leaves C/32 of its lanes idle
+// (0.5 TB/s at C = 16).  Here a wave takes 64 consecutive points, one per lane: the point's probabilities sit in CP
+// registers (CP = C rounded up to 8, a template parameter so that the arrays are statically indexed), the weights are
+// wave-uniform and come through the SCALAR path (s_load), the clamp / L1 norm / dot product of a row are lane-local --
+// no shuffles -- and a row of 64 x C results crosses a wave-private LDS tile so that global memory sees 4C-byte
+// segments instead of one 4-byte store per lane.  d raw (BACKWARD) takes its incoming gradient through the same tile.
+template <int CP, bool BACKWARD>
+__global__ __launch_bounds__(256) void gen_sig_t_mean_rows_kernel(int total_pts, int n, int c, const float *__restrict__ p,
+                                                                  const float *__restrict__ W, const float *__restrict__ cm,
+                                                                  const float *__restrict__ grad_out, float *__restrict__ out)
+{
+    extern __shared__ float gen_lds[];
+    const int cc = c * c, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *bias = gen_lds;                                           // [kk*c + o] = sum_j cm[kk][j] W[kk][o][c + j]
+    float *tile = gen_lds + ((cc + 3) & ~3) + wave * 64 * (CP + 1);  // [point][CP + 1]: odd stride, conflict-free rows
+    for (int col = threadIdx.x; col < cc; col += 256) {
+        const int kk = col / c;
+        float acc = 0.f;
+        for (int j = 0; j < c; ++j) acc += cm[kk * c + j] * W[(size_t)col * 2 * c + c + j];
+        bias[col] = acc;
+    }
+    __syncthreads();
+    const int jmax = 2 * c - 1;                                      // last valid column of a weight row (padded reads stay inside it)
+    for (long long i0 = ((long long)blockIdx.x * 4 + wave) * 64; i0 < total_pts; i0 += (long long)gridDim.x * 256) {
+        const long long i = i0 + lane;
+        const bool ok = i < total_pts;
+        const int b = ok ? (int)(i / n) : 0, ni = ok ? (int)(i - (long long)b * n) : 0;
+        float pv[CP];
+#pragma unroll
+        for (int j = 0; j < CP; ++j) pv[j] = (ok && j < c) ? p[((size_t)b * c + j) * n + ni] : 0.f;
+        const int cnt = (int)min((long long)64, total_pts - i0);    // points of this wave's tile
+        for (int kk = 0; kk < c; ++kk) {
+            float *gdst = out + (size_t)i0 * cc + (size_t)kk * c;    // + point * cc + o
+            float g[CP];
+            if (BACKWARD) {
+                // incoming gradient of row kk: coalesced segments -> tile -> one row per lane
+                const float *gsrc = grad_out + (size_t)i0 * cc + (size_t)kk * c;
+                int pt = lane / c, o = lane - pt * c;
+                const int dp = 64 / c, dq = 64 - dp * c;
+                for (int e = lane; e < cnt * c; e += 64) {
+                    tile[pt * (CP + 1) + o] = gsrc[(size_t)pt * cc + o];
+                    pt += dp; o += dq;
+                    if (o >= c) { o -= c; ++pt; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+#pragma unroll
+                for (int o2 = 0; o2 < CP; ++o2) g[o2] = (o2 < c) ? tile[lane * (CP + 1) + o2] : 0.f;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+            float raw[CP], s = 0.f;
+#pragma unroll
+            for (int o = 0; o < CP; ++o) {
+                raw[o] = 0.f;
+                if (o < c) {                                         // wave-uniform
+                    const float *wrow = W + ((size_t)kk * c + o) * 2 * c;
+                    float acc = bias[kk * c + o];
+#pragma unroll
+                    for (int j = 0; j < CP; ++j) acc = fmaf(pv[j], wrow[min(j, jmax)], acc);   // pv[j] = 0 beyond c
+                    raw[o] = acc;
+                    s += fminf(fmaxf(acc, 1e-5f), 1.f - 1e-5f);      // clamped values are positive
+                }
+            }
+            const float rden = 1.f / fmaxf(s, 1e-12f);
+            if (!BACKWARD) {
+#pragma unroll
+                for (int o = 0; o < CP; ++o)
+                    if (o < c) tile[lane * (CP + 1) + o] = fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) * rden;
+            } else {
+                float dot = 0.f;
+#pragma unroll
+                for (int o = 0; o < CP; ++o)
+                    if (o < c) dot += g[o] * (fminf(fmaxf(raw[o], 1e-5f), 1.f - 1e-5f) * rden);
+#pragma unroll
+                for (int o = 0; o < CP; ++o)
+                    if (o < c) {
+                        const bool inside = raw[o] >= 1e-5f && raw[o] <= 1.f - 1e-5f;
+                        tile[lane * (CP + 1) + o] = inside ? (g[o] - dot) * rden : 0.f;
+                    }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            {
+                int pt = lane / c, o = lane - pt * c;
+                const int dp = 64 / c, dq = 64 - dp * c;
+                for (int e = lane; e < cnt * c; e += 64) {
+                    gdst[(size_t)pt * cc + o] = tile[pt * (CP + 1) + o];
+                    pt += dp; o += dq;
+                    if (o >= c) { o -= c; ++pt; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
+}
+
 // ---- logit correction (train.py:549-552) --------------------------------------------------------------------
 // v = lam*E + (1-lam)*T_i;  tn = v / max(sum_c |v|, eps);  out[c] = sum_r logit[r] * tn[r][c]
 __global__ __launch_bounds__(256) void gen_correct_fwd_kernel(int total_pts, int n, int c, float lam,
@@ -148,9 +247,33 @@ static inline int gen_blocks(long long total_pts)
     return (int)(blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks));   // 8 workgroups per CU, grid-stride beyond
 }
 
+template <int CP>
+static hipError_t launch_sig_rows(bool backward, int b, int n, int c, const float *p, const float *W, const float *cm,
+                                  const float *grad_out, float *out, hipStream_t s)
+{
+    const size_t lds = (size_t)(((c * c + 3) & ~3) + 4 * 64 * (CP + 1)) * sizeof(float);    // <= 38 KB
+    long long blocks = ((long long)b * n + 255) / 256;
+    const long long cap = 8LL * device_cus();
+    if (blocks > cap) blocks = cap;
+    if (backward)
+        hipLaunchKernelGGL((gen_sig_t_mean_rows_kernel<CP, true>), dim3((int)blocks), dim3(256), lds, s, b * n, n, c, p, W, cm,
+                           grad_out, out);
+    else
+        hipLaunchKernelGGL((gen_sig_t_mean_rows_kernel<CP, false>), dim3((int)blocks), dim3(256), lds, s, b * n, n, c, p, W, cm,
+                           grad_out, out);
+    return hipGetLastError();
+}
+
 hipError_t gen_sig_t_mean(bool backward, int b, int n, int c, const float *p, const float *W, const float *cm,
                           const float *grad_out, float *out, hipStream_t s)
 {
+    const char *impl = getenv("GEOT_NTM_GENERIC");      // "wave": the wave-per-point kernel (A/B tests)
+    if (!(impl && impl[0] == 'w') && (long long)b * n * c * c < 0x7fffffffLL * 4LL) {
+        if (c <= 8) return launch_sig_rows<8>(backward, b, n, c, p, W, cm, grad_out, out, s);
+        if (c <= 16) return launch_sig_rows<16>(backward, b, n, c, p, W, cm, grad_out, out, s);
+        if (c <= 24) return launch_sig_rows<24>(backward, b, n, c, p, W, cm, grad_out, out, s);
+        return launch_sig_rows<32>(backward, b, n, c, p, W, cm, grad_out, out, s);
+    }
     const size_t lds = (size_t)(c + 1) * c * c * sizeof(float);        // 135 KB at C = 32
     const void *fn = backward ? (const void *)gen_sig_t_mean_kernel<true> : (const void *)gen_sig_t_mean_kernel<false>;
     hipError_t e = allow_big_lds(fn, lds);
