@@ -203,7 +203,10 @@ __global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int 
     float s[CH], ss[CH];
 #pragma unroll
     for (int l = 0; l < CH; ++l) s[l] = ss[l] = 0.f;
-    constexpr int U = 2;
+#ifndef GEOT_FP_LAB_U
+#define GEOT_FP_LAB_U 2
+#endif
+    constexpr int U = GEOT_FP_LAB_U;
     for (int eb = e0 + threadIdx.x; eb < e1; eb += U * FP_THREADS) {
         int ii[U][3];
         float ww[U][3], sk[U][FP_MAX_SKIP];
