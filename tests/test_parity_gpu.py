@@ -765,3 +765,33 @@ def test_fps_exhausted_valid_points_repeat_the_smallest_key(ext, oracle, fps_imp
     xyz2[:, far] = (rng.random((2, 9, 3)).astype(np.float32) + 0.5)
     got = fps_k1(ext, xyz2, 40)
     assert np.array_equal(got, oracle.fps_dense(xyz2, 40, 512, True))
+
+
+def test_sliced_index_gather_gradient_matches_the_per_target_walk(monkeypatch):
+    """GEOT_GATHER_IMPL=sell (opt-in: length-sorted sliced copy of the reverse index, csrc/gather_group.hip
+    table_gather_sell_kernel) against the default per-target walk and a float64 scatter-add, at a shape that cuts the
+    sources into parts, with hub targets (thousands of sources: the one-wave-per-list path), targets without sources,
+    a ragged channel count; bit-identical from call to call."""
+    from geot_amd.ext import pointnet2_ext as p2
+    from geot_amd.synth import make_batch
+    b, c, n, m = 2, 70, 24000, 8000
+    xyz = torch.from_numpy(make_batch(b, n, start_index=41)[0]).to(DEV)
+    _, idx = p2.three_nn(xyz, xyz[:, :m].contiguous())
+    idx = idx.clone()
+    idx[:, ::7, 0] = 5                      # ~3400 sources on one target
+    idx[0, :, 2] = idx[0, :, 2] % 64        # 375 sources on each of 64 targets
+    idx[:, 1::50, 1] = m - 1
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    w = torch.rand(b, n, 3, device=DEV, generator=gen)
+    g = torch.randn(b, c, n, device=DEV, generator=gen)
+    ref = torch.zeros(b, c, m, dtype=torch.float64, device=DEV)
+    ref.scatter_add_(2, idx.long().reshape(b, 1, n * 3).expand(-1, c, -1),
+                     (g.double().unsqueeze(-1) * w.double().unsqueeze(1)).reshape(b, c, n * 3))
+    outs = {}
+    for impl in ("sell", "l"):
+        monkeypatch.setenv("GEOT_GATHER_IMPL", impl)
+        outs[impl] = p2.three_interpolate_grad(g, idx.contiguous(), w, m)
+        assert torch.equal(outs[impl], p2.three_interpolate_grad(g, idx.contiguous(), w, m)), impl
+        err = float((outs[impl].double() - ref).abs().max() / ref.abs().max())
+        assert err < 2e-6, (impl, err)
+    assert float((outs["sell"] - outs["l"]).abs().max() / outs["l"].abs().max()) < 2e-6
