@@ -286,3 +286,30 @@ def test_fps_at_the_switch_between_the_pruned_and_the_streaming_kernel(n, oracle
     off = (np.arange(1, 3) * n).astype(np.int32)
     want = oracle.fps_offset(xyz.reshape(-1, 3), off, (np.arange(1, 3) * m).astype(np.int32)).reshape(2, m)
     assert np.array_equal(pointops.fps(x, m).cpu().numpy(), xyz.reshape(-1, 3)[want])
+
+
+def test_validation_path_at_the_size_of_a_real_scan(oracle):
+    """train.py:781-800 get_pred_whole at full size: logits of the 24 000 sampled points carried to the ~1e5 vertices of
+    the whole scan by three_nn + inverse-distance interpolation -- neighbour ids and squared distances bit-exact against
+    the oracle at 100 003 x 24 000, the predicted labels identical wherever the two best classes are not numerically tied."""
+    from geot_amd.validation import get_pred_whole
+    from geot_amd.ext import pointnet2_ext as p2
+    rng = np.random.default_rng(21)
+    n, m, c = 24000, 100003, 17
+    pts = make_batch(1, n, start_index=55)[0]
+    whole = (make_cloud(m, 56)[0] * np.float32(1.02)).astype(np.float32)[None]          # another scan of the same arch, denser
+    d2, idx = p2.three_nn(torch.from_numpy(whole).to(DEV), torch.from_numpy(pts).to(DEV))
+    wd2, widx = oracle.three_nn(whole, pts)
+    assert np.array_equal(idx.cpu().numpy(), widx) and np.array_equal(d2.cpu().numpy(), wd2)
+    logits = (rng.normal(size=(1, c, n)) * 3).astype(np.float32)
+    center, scale = [np.zeros((1, 3), np.float32)], [np.float32(1.0)]
+    pred = get_pred_whole(torch.from_numpy(logits).to(DEV), torch.from_numpy(pts).to(DEV), [torch.from_numpy(whole[0])],
+                          [torch.from_numpy(center[0])], [torch.tensor(scale[0])])[0][0].cpu().numpy()
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    sm = (e / e.sum(1, keepdims=True)).astype(np.float32)
+    r = 1.0 / (np.sqrt(wd2) + np.float32(1e-8))
+    lw = oracle.three_interpolate(sm, widx, (r / r.sum(2, keepdims=True)).astype(np.float32))[0]
+    top2 = np.sort(lw, 0)[-2:]
+    clear = (top2[1] - top2[0]) > 1e-5
+    assert pred.shape == (m,) and clear.mean() > 0.99
+    assert np.array_equal(pred[clear], lw.argmax(0)[clear])
