@@ -249,6 +249,10 @@ def hot_path_attribution(step, steps=2):
     return {k: sum(a.elapsed_time(b) for a, b in v) / steps for k, v in rec.items()}
 
 
+HOST_ISSUE = {}     # seconds the host needed to queue the timed steps (the last call of timed_steps)
+HOST_ISSUE_MAIN = {}
+
+
 def timed_steps(step, steps, dev, rehearsal):
     """barrier + synchronize, `steps` steps, synchronize + barrier; MAX over ranks of the elapsed seconds."""
     import torch
@@ -259,6 +263,7 @@ def timed_steps(step, steps, dev, rehearsal):
     t0 = time.perf_counter()
     for _ in range(steps):
         out = step()
+    HOST_ISSUE["s"] = time.perf_counter() - t0          # the host has queued every step; the GPU may still be running
     torch.cuda.synchronize()
     dist_utils.barrier()
     torch.cuda.synchronize()
@@ -453,6 +458,7 @@ def main():
         elapsed, out = timed_steps(dealt_step, args.steps, dev, rehearsal)
     else:
         elapsed, out = timed_steps(step, args.steps, dev, rehearsal)
+    HOST_ISSUE_MAIN["ms"] = 1e3 * HOST_ISSUE["s"] / max(args.steps, 1)
     if patch_owner is not None:
         setattr(patch_owner, patch_name, orig_fn)
     if workload == "sa" and not args.graph:
@@ -483,6 +489,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "host_issue_ms_per_step": HOST_ISSUE_MAIN.get("ms"),   # host time to queue a step (rank 0): << ms_per_step = GPU-bound
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

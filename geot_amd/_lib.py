@@ -103,6 +103,17 @@ PROTOTYPES.update({
     "geot_bn_bwd_reduce": [_c_int] * 4 + [_P] * 7 + [_c_void_p],
     "geot_bn_bwd_apply": [_c_int] * 4 + [_P] * 10 + [_c_void_p],
     "geot_fp_front": [_c_int] * 5 + [_P] * 7 + [_c_void_p],
+    "geot_fp_front_cl": [_c_int] * 5 + [_P] * 8 + [_c_void_p],
+    "geot_bn_stats_cl": [ctypes.c_longlong, _c_int, _P, _P, _c_void_p],
+    "geot_bn_apply_cl": [ctypes.c_longlong, _c_int, _c_int] + [_P] * 4 + [_c_void_p],
+    "geot_bn_bwd_reduce_cl": [ctypes.c_longlong, _c_int, _c_int] + [_P] * 7 + [_c_void_p],
+    "geot_bn_bwd_apply_cl": [ctypes.c_longlong, _c_int, _c_int] + [_P] * 10 + [_c_void_p],
+    "geot_bn_sums_cl": [_c_int, _c_int, _P, _P, _c_void_p],
+    "geot_rix_build": [_c_int] * 4 + [_P] * 4 + [ctypes.c_longlong, _c_void_p],
+    "geot_gather_rows_csr_cl": [_c_int] * 5 + [_P] * 4 + [_c_void_p],
+    "geot_bn_sums_k_cl": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
+    "geot_bn_bwd_reduce_skip_cl": [_c_int] * 5 + [_P] * 8 + [_c_void_p],
+    "geot_gather_rows_csr_bn_cl": [_c_int] * 6 + [_P] * 11 + [_c_void_p],
     "geot_segment_max": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_segment_sum": [ctypes.c_longlong, _c_int, _P, _P, _c_void_p],
     "geot_bn_pool": [_c_int] * 5 + [_P] * 6 + [_c_void_p],
@@ -130,6 +141,9 @@ PLAIN = {
     "geot_edgeconv_eligible": ([_c_int] * 6, _c_int),
     "geot_bn_slices": ([_c_int] * 3, _c_int),
     "geot_fp_front_slices": ([_c_int] * 4, _c_int),
+    "geot_cl_tiles": ([_c_int, ctypes.c_longlong, _c_int], _c_int),
+    "geot_fp_front_cl_tiles": ([_c_int] * 4, _c_int),
+    "geot_rix_ws_ints": ([_c_int, ctypes.c_longlong, _c_int, _c_int], ctypes.c_longlong),
     "geot_edgeconv_ws_bytes": ([_c_int] * 5, ctypes.c_longlong),
     "geot_poly1_focal_ws_doubles": ([_c_int] * 3, ctypes.c_longlong),
     "geot_res_ln_supported": ([_c_int], _c_int),

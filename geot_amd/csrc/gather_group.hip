@@ -521,26 +521,30 @@ static hipError_t tlds_gather(const TldsPlan &p, int b, int c, int m, int L, con
 // (batch, part, target), so that a workgroup holding the rows of ONE part in LDS finds exactly its entries.
 __global__ __launch_bounds__(256) void rix_count_kernel(long long total, long long per_batch, int m, int nt, int Q,
                                                         int partlen, const int *__restrict__ idx,
-                                                        int *__restrict__ cnt, int *__restrict__ rank)
-{
+                                                        int *__restrict__ cnt, int *__restrict__ rank,
+                                                        const int *__restrict__ remap = nullptr)
+{   // remap (b, m), Q == 1 only: the number under which a target is filed (the point-major walk's target order)
     const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
     if (x >= total) return;
     const int bi = (int)(x / per_batch);
     const int e = (int)((x - (long long)bi * per_batch) / nt), part = e / partlen;
-    rank[x] = atomicAdd(&cnt[((size_t)bi * Q + part) * m + idx[x]], 1);
+    const int j = remap ? remap[(size_t)bi * m + idx[x]] : idx[x];
+    rank[x] = atomicAdd(&cnt[((size_t)bi * Q + part) * m + j], 1);
 }
 template <bool WEIGHTED>
 __global__ __launch_bounds__(256) void rix_fill_kernel(long long total, long long per_batch, int m, int nt, int Q,
                                                        int partlen, const int *__restrict__ idx,
                                                        const float *__restrict__ weight, const int *__restrict__ off,
                                                        const int *__restrict__ rank, int *__restrict__ rev,
-                                                       float *__restrict__ revw, int *__restrict__ tmp)
+                                                       float *__restrict__ revw, int *__restrict__ tmp,
+                                                       const int *__restrict__ remap = nullptr)
 {
     const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
     if (x >= total) return;
     const int bi = (int)(x / per_batch);
     const int e = (int)((x - (long long)bi * per_batch) / nt), part = e / partlen;
-    const int pos = off[((size_t)bi * Q + part) * m + idx[x]] + rank[x];
+    const int j = remap ? remap[(size_t)bi * m + idx[x]] : idx[x];
+    const int pos = off[((size_t)bi * Q + part) * m + j] + rank[x];
     if (tmp) { tmp[pos] = (int)x; return; } // reproducible build: pair ids first, placed by rix_place_kernel
     rev[pos] = e - part * partlen; // source element within its part
     if (WEIGHTED) revw[pos] = weight[x];
@@ -1177,6 +1181,266 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
     return hipGetLastError();
 }
 
+// ---- gradient of a POINT-MAJOR gather: whole rows gathered through the reverse index --------------------------------
+// out[b, j, :] = sum over the pairs (e, t) with idx[b, e, t] == j of w[b, e, t] * g[b, e, :]   (g, out: (B, L, C), (B, m, C)).
+// The channels-first kernels above walk the lists once per 4 channels (rev + revw = 8 B per pair against 16 B of
+// payload); here the lanes of a workgroup are the channels: a list entry is wave-uniform and read ONCE, every source is
+// one contiguous 4 C-byte row.  The index is built for this walk (geot_rix_build): targets are numbered in the order
+// the kernel takes them (`order`: a spatial order keeps the sources of neighbouring targets in the XCD's L2), the
+// pairs of all targets form ONE flat stream (source row, weight, target | last-of-list flag), and a workgroup takes an
+// equal share of the STREAM, snapped to list boundaries -- lists of 0 to 30 pairs cost what they hold.  A run of the
+// stream is staged in LDS, then walked with the loads of the next 4 pairs in flight under the arithmetic of the current
+// 4.  One writer per output row, pairs in ascending pair order: bit-reproducible.  (csrc/channels_last.hip: the forward.)
+typedef float cl_f4 __attribute__((ext_vector_type(4)));
+constexpr int GR_CAP = 512;          // pairs staged per pass
+#ifndef GEOT_GR_LAB_U
+#define GEOT_GR_LAB_U 8
+#endif
+constexpr int GR_U = GEOT_GR_LAB_U;   // row loads in flight per half of the software pipeline
+constexpr unsigned GR_LAST = 0x80000000u;
+
+// placement for the point-major walk: pair x of target rank k goes to its slot (ascending pair id within the list) as
+// (global source row, weight, k | last flag)
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void rix_place_cl_kernel(long long total, long long per_batch, int m, int nt, int L,
+                                                           const int *__restrict__ idx, const float *__restrict__ weight,
+                                                           const int *__restrict__ rank_of, const int *__restrict__ off,
+                                                           const int *__restrict__ rank, const int *__restrict__ tmp,
+                                                           int *__restrict__ rev, float *__restrict__ revw,
+                                                           unsigned *__restrict__ rtgt)
+{
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= total) return;
+    const int bi = (int)(x / per_batch);
+    const int e = (int)((x - (long long)bi * per_batch) / nt);
+    const int j = idx[x];
+    const size_t k = (size_t)bi * m + (rank_of ? rank_of[(size_t)bi * m + j] : j);
+    const int a = off[k], z = off[k + 1];
+    const int pos = a + rix_sorted_position(tmp, a, z, (int)x, rank[x]);
+    rev[pos] = bi * L + e;
+    revw[pos] = WEIGHTED ? weight[x] : 1.f;
+    rtgt[pos] = (unsigned)k | (pos + 1 == z ? GR_LAST : 0u);
+}
+// rank_of[b, order[b, r]] = r
+__global__ __launch_bounds__(256) void invert_order_kernel(long long total, int m, const int *__restrict__ order,
+                                                           int *__restrict__ rank_of)
+{
+    const long long x = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (x >= total) return;
+    const long long bi = x / m;
+    rank_of[bi * m + order[x]] = (int)(x - bi * m);
+}
+
+__global__ __launch_bounds__(1024) void gather_rows_csr_cl_kernel(int c4, int T, int P, const cl_f4 *__restrict__ g,
+                                                                  const int *__restrict__ off, const int *__restrict__ rev,
+                                                                  const float *__restrict__ revw,
+                                                                  const unsigned *__restrict__ rtgt, const int *__restrict__ order,
+                                                                  int m, cl_f4 *__restrict__ out)
+{
+    __shared__ int s_src[GR_CAP + 3 * GR_U];            // + the pairs the software pipeline loads past the end
+    __shared__ float s_w[GR_CAP];
+    __shared__ unsigned s_tgt[GR_CAP];       // output row | last flag
+    __shared__ int s_empty[GR_CAP];
+    __shared__ int s_nempty;
+    const bool on = (int)threadIdx.x < c4;
+    const int q = on ? threadIdx.x : c4 - 1;
+    const cl_f4 zero = {0.f, 0.f, 0.f, 0.f};
+    // rows of targets without pairs: this workgroup's share of the target range
+    {
+        const int per = (T + gridDim.x - 1) / gridDim.x;
+        const int k0 = min(T, (int)blockIdx.x * per), k1 = min(T, k0 + per);
+        for (int kb = k0; kb < k1; kb += GR_CAP) {
+            if (threadIdx.x == 0) s_nempty = 0;
+            __syncthreads();
+            for (int k = kb + threadIdx.x; k < min(k1, kb + GR_CAP); k += blockDim.x)
+                if (off[k] == off[k + 1]) s_empty[atomicAdd(&s_nempty, 1)] = order ? (k / m) * m + order[k] : k;
+            __syncthreads();
+            const int ne = s_nempty;
+            for (int i = 0; i < ne; ++i)
+                if (on) out[(size_t)s_empty[i] * c4 + q] = zero;
+            __syncthreads();
+        }
+    }
+    // this workgroup's share of the pair stream: the lists that START in [s0, s1)
+    auto snap = [&](long long s) -> int {
+        if (s <= 0) return 0;
+        if (s >= P) return P;
+        const int k = (int)(rtgt[s] & ~GR_LAST);
+        return off[k] == (int)s ? (int)s : off[k + 1];
+    };
+    const int p0 = snap((long long)P * blockIdx.x / gridDim.x), p1 = snap((long long)P * (blockIdx.x + 1) / gridDim.x);
+    cl_f4 acc = zero;
+    for (int base = p0; base < p1; base += GR_CAP) {
+        const int cnt = min(GR_CAP, p1 - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const unsigned t = rtgt[base + i];
+            const int k = (int)(t & ~GR_LAST);
+            s_src[i] = rev[base + i];
+            s_w[i] = revw[base + i];
+            s_tgt[i] = (unsigned)(order ? (k / m) * m + order[k] : k) | (t & GR_LAST);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 3 * GR_U) s_src[cnt + threadIdx.x] = s_src[cnt - 1];   // padding: valid rows, results unused
+        __syncthreads();
+        // two-stage software pipeline over the flat pair stream; every load unconditional so that the waits can be counted
+        auto load = [&](int i, cl_f4(&v)[GR_U]) {
+#pragma unroll
+            for (int u = 0; u < GR_U; ++u) v[u] = (g + (size_t)__builtin_amdgcn_readfirstlane(s_src[i + u]) * c4)[q];
+        };
+        auto walk = [&](int i, const cl_f4(&v)[GR_U]) {
+#pragma unroll
+            for (int u = 0; u < GR_U; ++u) {
+                if (i + u < cnt) {
+                    const float w = s_w[i + u];
+                    acc.x = fmaf(w, v[u].x, acc.x);
+                    acc.y = fmaf(w, v[u].y, acc.y);
+                    acc.z = fmaf(w, v[u].z, acc.z);
+                    acc.w = fmaf(w, v[u].w, acc.w);
+                    const unsigned t = __builtin_amdgcn_readfirstlane(s_tgt[i + u]);
+                    if (t & GR_LAST) {
+                        if (on) __builtin_nontemporal_store(acc, out + (size_t)(t & ~GR_LAST) * c4 + q);
+                        acc = zero;
+                    }
+                }
+            }
+        };
+        cl_f4 va[GR_U], vb[GR_U];
+        load(0, va);
+        for (int i = 0; i < cnt; i += 2 * GR_U) {
+            load(i + GR_U, vb);
+            walk(i, va);
+            load(i + 2 * GR_U, va);
+            walk(i + GR_U, vb);
+        }
+    }
+}
+
+// The same walk with the BatchNorm (+ ReLU) backward of the gathered tensor folded in: the rows that arrive are y (the
+// BatchNorm's input) and dz (the gradient of its output); the gradient of y,
+//     gy = k0 (g - c1 - xhat c2),   g = dz [y scale + shift > 0],   xhat = (y - mean) rstd        (bnrelu.hip bn_bwd_apply)
+// is linear in (g, y - mean, 1), so a target's sum  sum_p w_p gy_p  =  k0 G + A Y - k0 c1 W  with  G = sum w g,
+// Y = sum w (y - mean), W = sum w, A = -k0 rstd c2: three running sums per list, the constants applied once per target.
+// gy is never written or read (1.18 GB each way at 8 x 24000 x 1536) and the bn_bwd_apply pass disappears.
+#ifndef GEOT_GRB_LAB_U
+#define GEOT_GRB_LAB_U 3
+#endif
+constexpr int GRB_U = GEOT_GRB_LAB_U;    // pairs (2 row loads each) in flight per half of the software pipeline
+__global__ __launch_bounds__(1024) void gather_rows_csr_bn_cl_kernel(
+    int c4, int T, int P, int relu, const cl_f4 *__restrict__ y, const cl_f4 *__restrict__ dz, const cl_f4 *__restrict__ scale,
+    const cl_f4 *__restrict__ shift, const cl_f4 *__restrict__ mean, const cl_f4 *__restrict__ rstd, const cl_f4 *__restrict__ c1,
+    const cl_f4 *__restrict__ c2, const int *__restrict__ off, const int *__restrict__ rev, const float *__restrict__ revw,
+    const unsigned *__restrict__ rtgt, const int *__restrict__ order, int m, cl_f4 *__restrict__ out)
+{
+    __shared__ int s_src[GR_CAP + 3 * GRB_U];
+    __shared__ float s_w[GR_CAP];
+    __shared__ unsigned s_tgt[GR_CAP];
+    __shared__ int s_empty[GR_CAP];
+    __shared__ int s_nempty;
+    const bool on = (int)threadIdx.x < c4;
+    const int q = on ? threadIdx.x : c4 - 1;
+    const cl_f4 zero = {0.f, 0.f, 0.f, 0.f};
+    const cl_f4 k0 = scale[q], sh = shift[q], mu = mean[q];
+    const cl_f4 A = -(k0 * rstd[q] * c2[q]), k0c1 = k0 * c1[q];
+    {   // targets without pairs: sum over nothing = 0
+        const int per = (T + gridDim.x - 1) / gridDim.x;
+        const int k0t = min(T, (int)blockIdx.x * per), k1t = min(T, k0t + per);
+        for (int kb = k0t; kb < k1t; kb += GR_CAP) {
+            if (threadIdx.x == 0) s_nempty = 0;
+            __syncthreads();
+            for (int k = kb + threadIdx.x; k < min(k1t, kb + GR_CAP); k += blockDim.x)
+                if (off[k] == off[k + 1]) s_empty[atomicAdd(&s_nempty, 1)] = order ? (k / m) * m + order[k] : k;
+            __syncthreads();
+            const int ne = s_nempty;
+            for (int i = 0; i < ne; ++i)
+                if (on) out[(size_t)s_empty[i] * c4 + q] = zero;
+            __syncthreads();
+        }
+    }
+    auto snap = [&](long long s) -> int {
+        if (s <= 0) return 0;
+        if (s >= P) return P;
+        const int k = (int)(rtgt[s] & ~GR_LAST);
+        return off[k] == (int)s ? (int)s : off[k + 1];
+    };
+    const int p0 = snap((long long)P * blockIdx.x / gridDim.x), p1 = snap((long long)P * (blockIdx.x + 1) / gridDim.x);
+    cl_f4 G = zero, Y = zero;
+    float W = 0.f;
+    for (int base = p0; base < p1; base += GR_CAP) {
+        const int cnt = min(GR_CAP, p1 - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const unsigned t = rtgt[base + i];
+            const int k = (int)(t & ~GR_LAST);
+            s_src[i] = rev[base + i];
+            s_w[i] = revw[base + i];
+            s_tgt[i] = (unsigned)(order ? (k / m) * m + order[k] : k) | (t & GR_LAST);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 3 * GRB_U) s_src[cnt + threadIdx.x] = s_src[cnt - 1];   // padding: valid rows, results unused
+        __syncthreads();
+        auto load = [&](int i, cl_f4(&vy)[GRB_U], cl_f4(&vg)[GRB_U]) {
+#pragma unroll
+            for (int u = 0; u < GRB_U; ++u) {
+                const size_t row = (size_t)__builtin_amdgcn_readfirstlane(s_src[i + u]) * c4;
+                vy[u] = (y + row)[q];
+                vg[u] = (dz + row)[q];
+            }
+        };
+        auto walk = [&](int i, const cl_f4(&vy)[GRB_U], const cl_f4(&vg)[GRB_U]) {
+#pragma unroll
+            for (int u = 0; u < GRB_U; ++u) {
+                if (i + u < cnt) {
+                    const float w = s_w[i + u];
+                    cl_f4 g;
+                    g.x = (!relu || fmaf(vy[u].x, k0.x, sh.x) > 0.f) ? vg[u].x : 0.f;
+                    g.y = (!relu || fmaf(vy[u].y, k0.y, sh.y) > 0.f) ? vg[u].y : 0.f;
+                    g.z = (!relu || fmaf(vy[u].z, k0.z, sh.z) > 0.f) ? vg[u].z : 0.f;
+                    g.w = (!relu || fmaf(vy[u].w, k0.w, sh.w) > 0.f) ? vg[u].w : 0.f;
+                    G = __builtin_elementwise_fma((cl_f4)(w), g, G);
+                    Y = __builtin_elementwise_fma((cl_f4)(w), vy[u] - mu, Y);
+                    W += w;
+                    const unsigned t = __builtin_amdgcn_readfirstlane(s_tgt[i + u]);
+                    if (t & GR_LAST) {
+                        const cl_f4 r = __builtin_elementwise_fma(k0, G, __builtin_elementwise_fma(A, Y, -(k0c1 * W)));
+                        if (on) __builtin_nontemporal_store(r, out + (size_t)(t & ~GR_LAST) * c4 + q);
+                        G = Y = zero;
+                        W = 0.f;
+                    }
+                }
+            }
+        };
+        cl_f4 ya[GRB_U], ga[GRB_U], yb[GRB_U], gb[GRB_U];
+        load(0, ya, ga);
+        for (int i = 0; i < cnt; i += 2 * GRB_U) {
+            load(i + GRB_U, yb, gb);
+            walk(i, ya, ga);
+            load(i + 2 * GRB_U, ya, ga);
+            walk(i + GRB_U, yb, gb);
+        }
+    }
+}
+
+struct RixLayout {
+    long long t, pairs, off, bsum, rank, rev, revw, rtgt, tmp, rank_of, ints;
+};
+static inline RixLayout rix_layout(int b, long long L, int m, int nt)
+{
+    RixLayout r;
+    r.t = (long long)b * m;
+    r.pairs = (long long)b * L * nt;
+    r.off = 0;
+    r.bsum = r.t + 1;
+    r.rank = r.bsum + scan_blocks(r.t);
+    r.rev = r.rank + r.pairs;
+    r.revw = r.rev + r.pairs;
+    r.rtgt = r.revw + r.pairs;
+    r.tmp = r.rtgt + r.pairs;
+    r.rank_of = r.tmp + r.pairs;
+    r.ints = r.rank_of + r.t + 8;
+    return r;
+}
+
 static inline dim3 grid3(long long inner, int c, int b)
 {
     return dim3((unsigned)((inner + GG_THREADS - 1) / GG_THREADS), (unsigned)((c + GG_CCHUNK - 1) / GG_CCHUNK),
@@ -1374,6 +1638,116 @@ GEOT_EXPORT int geot_three_interpolate_grad_from(int b, int c, int n, int m, con
     if (grad_bstride < 0) return hipErrorInvalidValue;
     return three_interpolate_grad_launch(b, c, n, m, grad_out, (size_t)grad_bstride, idx, weight, grad_points, workspace,
                                          (hipStream_t)stream);
+}
+
+// ---- reverse index as an object of its own + the point-major gradient over it ---------------------------------------
+// The index depends on the neighbour ids alone: a caller that knows them early (the model's index plan, side stream)
+// builds it once, off the critical path, and every gradient that needs it finds it ready.
+// Workspace layout (ints): offsets [b m + 1] | scan scratch | ranks | sources | weights | pair ids.
+GEOT_EXPORT long long geot_rix_ws_ints(int b, long long L, int m, int nt)
+{
+    if (b < 1 || L < 1 || m < 1 || nt < 1) return 0;
+    return rix_layout(b, L, m, nt).ints;
+}
+
+GEOT_EXPORT int geot_rix_build(int b, int L, int m, int nt, const int *idx, const float *weight, const int *order, int *ws,
+                               long long ws_ints, void *stream)
+{
+    if (b < 0 || L < 0 || m < 1 || nt < 1 || !ws) return hipErrorInvalidValue;
+    const RixLayout r = rix_layout(b, L, m, nt);
+    if (ws_ints < r.ints || r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL || (long long)b * L > 0x7fffffffLL)
+        return hipErrorInvalidValue;
+    hipStream_t s = (hipStream_t)stream;
+    int *off = ws + r.off;
+    hipError_t e = zero_words(off, r.t + 1, s);
+    if (e != hipSuccess || r.pairs == 0) return e;
+    int *rank_of = nullptr;
+    if (order) {
+        rank_of = ws + r.rank_of;
+        hipLaunchKernelGGL(invert_order_kernel, dim3((unsigned)((r.t + 255) / 256)), dim3(256), 0, s, r.t, m, order, rank_of);
+    }
+    const int pb = (int)((r.pairs + 255) / 256);
+    const long long pbatch = (long long)L * nt;
+    hipLaunchKernelGGL(rix_count_kernel, dim3(pb), dim3(256), 0, s, r.pairs, pbatch, m, nt, 1, L, idx, off, ws + r.rank, rank_of);
+    exclusive_scan_i32((int)r.t, off, ws + r.bsum, nullptr, s);
+    float *revw = (float *)(ws + r.revw);
+    // pair ids into the lists first (any order), then every pair to its slot in ascending pair order
+    hipLaunchKernelGGL((rix_fill_kernel<false>), dim3(pb), dim3(256), 0, s, r.pairs, pbatch, m, nt, 1, L, idx, nullptr, off,
+                       ws + r.rank, ws + r.rev, revw, ws + r.tmp, rank_of);
+    if (weight)
+        hipLaunchKernelGGL((rix_place_cl_kernel<true>), dim3(pb), dim3(256), 0, s, r.pairs, pbatch, m, nt, L, idx, weight, rank_of,
+                           off, ws + r.rank, ws + r.tmp, ws + r.rev, revw, (unsigned *)(ws + r.rtgt));
+    else
+        hipLaunchKernelGGL((rix_place_cl_kernel<false>), dim3(pb), dim3(256), 0, s, r.pairs, pbatch, m, nt, L, idx, weight, rank_of,
+                           off, ws + r.rank, ws + r.tmp, ws + r.rev, revw, (unsigned *)(ws + r.rtgt));
+    return hipGetLastError();
+}
+
+// g_cl (B, L, C) -> out_cl (B, m, C) through the index geot_rix_build left in `ws` (same b, L, m, nt and the SAME
+// `order` it was built with)
+GEOT_EXPORT int geot_gather_rows_csr_cl(int b, int c, int L, int m, int nt, const float *g_cl, const int *ws, const int *order,
+                                        float *out_cl, void *stream)
+{
+    if (b < 0 || c < 0 || L < 0 || m < 0 || nt < 1 || !ws) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || m == 0) return hipSuccess;
+    if (c % 4 || c / 4 > 1024) return hipErrorInvalidValue;
+    const RixLayout r = rix_layout(b, L, m, nt);
+    if (r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL) return hipErrorInvalidValue;
+    const int c4 = c / 4, waves = (c4 + 63) / 64;
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
+    static int per_cu_of[1024 / 64 + 1];                       // [waves] -> resident workgroups per CU
+    int &per_cu = per_cu_of[waves];
+    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_rows_csr_cl_kernel, waves * 64, 0) != hipSuccess || per_cu < 1))
+        per_cu = 1;
+    long long grid = (long long)cus * per_cu;                 // one round of co-resident workgroups, equal shares of the stream
+    if (const char *mult = getenv("GEOT_CL_TILES_MULT")) grid *= atoi(mult) > 0 ? atoi(mult) : 1;   // lab
+    if (grid > r.t) grid = r.t;
+    hipLaunchKernelGGL(gather_rows_csr_cl_kernel, dim3((unsigned)grid), dim3((c4 + 63) & ~63), 0, (hipStream_t)stream, c4, (int)r.t,
+                       (int)r.pairs, (const cl_f4 *)g_cl, ws + r.off, ws + r.rev, (const float *)(ws + r.revw),
+                       (const unsigned *)(ws + r.rtgt), order, m, (cl_f4 *)out_cl);
+    return hipGetLastError();
+}
+
+// out_cl (b, m, c) = the interpolation gradient of gy = BatchNorm(+ReLU)-backward(y_cl, dz_cl) without forming gy:
+// scale = gamma rstd (also the k0 of geot_bn_bwd_apply), shift, mean, rstd of the forward, c1 / c2 from geot_bn_bwd_coef
+GEOT_EXPORT int geot_gather_rows_csr_bn_cl(int b, int c, int L, int m, int nt, int relu, const float *y_cl, const float *dz_cl,
+                                           const float *scale, const float *shift, const float *mean, const float *rstd,
+                                           const float *c1, const float *c2, const int *ws, const int *order, float *out_cl,
+                                           void *stream)
+{
+    if (b < 0 || c < 0 || L < 0 || m < 0 || nt < 1 || !ws) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || m == 0) return hipSuccess;
+    if (c % 4 || c / 4 > 1024) return hipErrorInvalidValue;
+    const RixLayout r = rix_layout(b, L, m, nt);
+    if (r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL) return hipErrorInvalidValue;
+    const int c4 = c / 4, waves = (c4 + 63) / 64;
+    int cus = 256;
+    {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        static int cached = 0;
+        if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cached = prop.multiProcessorCount;
+        if (cached) cus = cached;
+    }
+    static int per_cu_of[1024 / 64 + 1];
+    int &per_cu = per_cu_of[waves];
+    if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_rows_csr_bn_cl_kernel, waves * 64, 0) != hipSuccess || per_cu < 1))
+        per_cu = 1;
+    long long grid = (long long)cus * per_cu;
+    if (const char *mult = getenv("GEOT_CL_TILES_MULT")) grid *= atoi(mult) > 0 ? atoi(mult) : 1;   // lab
+    if (grid > r.t) grid = r.t;
+    hipLaunchKernelGGL(gather_rows_csr_bn_cl_kernel, dim3((unsigned)grid), dim3(waves * 64), 0, (hipStream_t)stream, c4, (int)r.t,
+                       (int)r.pairs, relu, (const cl_f4 *)y_cl, (const cl_f4 *)dz_cl, (const cl_f4 *)scale, (const cl_f4 *)shift,
+                       (const cl_f4 *)mean, (const cl_f4 *)rstd, (const cl_f4 *)c1, (const cl_f4 *)c2, ws + r.off, ws + r.rev,
+                       (const float *)(ws + r.revw), (const unsigned *)(ws + r.rtgt), order, m, (cl_f4 *)out_cl);
+    return hipGetLastError();
 }
 
 GEOT_EXPORT int geot_group_points_grad_ws(int b, int c, int n, int npoints, int nsample,

@@ -84,22 +84,32 @@ def _covered(bn, x):
             and x.dim() == 3 and x.shape[0] <= 65535 and x.shape[1] <= 65535 and x.numel() > 0)
 
 
-def _batch_statistics(bn, x, gamma, beta, partial, pre_bias):
-    """Training-mode statistics of x (B, C, L) for the module `bn`: the stats pass (unless `partial` came with x), the
-    all-reduce under SyncBatchNorm, mean / rstd / scale / shift and the running-statistics update.
+def _batch_statistics(bn, x, gamma, beta, partial, pre_bias, cl=False):
+    """Training-mode statistics of x (B, C, L) -- or, with cl, of the point-major x (B, L, C) -- for the module `bn`: the
+    stats pass (unless `partial` came with x), the all-reduce under SyncBatchNorm, mean / rstd / scale / shift and the
+    running-statistics update.
     -> (stats (4, C) = mean, rstd, scale, shift; count (python float, or a 1-element device double); group)."""
-    b, c, l = x.shape
+    if cl:
+        b, l, c = x.shape
+    else:
+        b, c, l = x.shape
     dev = x.device
     group = _sync_group(bn)
     with torch.no_grad():
-        if partial is None:
-            slices = int(_lib.load().geot_bn_slices(b, c, l))
-            partial = torch.empty((b, c, slices, 2), dtype=torch.float32, device=dev)
-            call("geot_bn_stats", dev, b, c, l, ptr(x), ptr(partial))
-        slices = partial.shape[2]
-        # everything between the two passes in two launches (csrc/bnrelu.hip; ~13 torch launches per layer otherwise)
         sums = torch.empty((c, 2), dtype=torch.float64, device=dev)
-        call("geot_bn_sums", dev, b, c, slices, ptr(partial), ptr(sums))
+        if cl:
+            if partial is None:
+                partial = torch.empty((int(_lib.load().geot_cl_tiles(1, b * l, c)), 2, c), dtype=torch.float32, device=dev)
+                call("geot_bn_stats_cl", dev, b * l, c, ptr(x), ptr(partial))
+            call("geot_bn_sums_cl", dev, partial.shape[0], c, ptr(partial), ptr(sums))
+        else:
+            if partial is None:
+                slices = int(_lib.load().geot_bn_slices(b, c, l))
+                partial = torch.empty((b, c, slices, 2), dtype=torch.float32, device=dev)
+                call("geot_bn_stats", dev, b, c, l, ptr(x), ptr(partial))
+            slices = partial.shape[2]
+            # everything between the two passes in two launches (csrc/bnrelu.hip; ~13 torch launches per layer otherwise)
+            call("geot_bn_sums", dev, b, c, slices, ptr(partial), ptr(sums))
         count = float(b * l)
         count_dev = None
         if group is not None:                  # SyncBatchNorm: sums and element counts of all ranks (counts may differ);
@@ -205,6 +215,298 @@ def fp_front(a, idx, weight, skip, wb):
     or None, wb (C,Cs) -> (y (B,C,n), partial): the first conv of a PointnetFPModule's SharedMLP, ready for bn_act."""
     return _FpFrontFn.apply(a.contiguous(), idx.contiguous(), weight.contiguous(),
                             None if skip is None else skip.contiguous().float(), wb)
+
+
+# ---- the FP front end on point-major activations (csrc/channels_last.hip) ----------------------------------------------
+# (B, N, C): a point's channels are one contiguous row.  Only the first stage of a PointnetFPModule runs in this layout
+# -- the interpolation, its BatchNorm + ReLU and the gradients of both -- between two GEMMs that take the layout as a
+# transpose flag: nothing is ever transposed in memory.
+class _PointwiseToClFn(Function):
+    """w (Cout, Cin), x (B, Cin, L) channels-first -> (B, L, Cout) point-major: the 1x1 convolution as x^T w^T."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        ctx.save_for_backward(w, x)
+        return torch.bmm(x.transpose(1, 2), w.t().unsqueeze(0).expand(x.shape[0], -1, -1))
+
+    @staticmethod
+    def backward(ctx, g):
+        w, x = ctx.saved_tensors
+        gw = gx = None
+        if ctx.needs_input_grad[0]:
+            gw = torch.bmm(g.transpose(1, 2), x.transpose(1, 2)).sum(0)
+        if ctx.needs_input_grad[1]:
+            gx = torch.bmm(w.t().unsqueeze(0).expand(x.shape[0], -1, -1), g.transpose(1, 2))
+        return gw, gx
+
+
+class _PointwiseFromClFn(Function):
+    """w (Cout, Cin), z (B, L, Cin) point-major -> (B, Cout, L) channels-first; the gradient of z comes out point-major."""
+
+    @staticmethod
+    def forward(ctx, w, z):
+        ctx.save_for_backward(w, z)
+        return torch.bmm(w.unsqueeze(0).expand(z.shape[0], -1, -1), z.transpose(1, 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        w, z = ctx.saved_tensors
+        gw = gz = None
+        if ctx.needs_input_grad[0]:
+            gw = torch.bmm(g, z).sum(0)
+        if ctx.needs_input_grad[1]:
+            gz = torch.bmm(g.transpose(1, 2), w.unsqueeze(0).expand(z.shape[0], -1, -1))
+        return gw, gz
+
+
+def pointwise_to_cl(w, x):
+    return _PointwiseToClFn.apply(w, x.contiguous())
+
+
+def pointwise_from_cl(w, z):
+    return _PointwiseFromClFn.apply(w, z)
+
+
+def fp_front_cl_eligible(a, skip):
+    """a (B, C, m) channels-first (shape only): does the point-major front end cover it?  Wide layers only: below 256
+    channels a row is shorter than a wave and the channels-first kernels are the better fit."""
+    if not (a.is_cuda and a.dtype == torch.float32 and a.dim() == 3):
+        return False
+    b, c, m = a.shape
+    cs = 0 if skip is None else skip.shape[1]
+    return c >= 256 and cs <= 8 and _lib.load().geot_fp_front_cl_tiles(b, c, 16, cs) > 0
+
+
+def local_spatial_order(pos):
+    """(B, N, 3) -> int32 (B, N): the points of every cloud in Morton-cell order (per-cloud ids).  The sequence in which the
+    point-major kernels take their rows: neighbouring rows of the sequence gather the same table rows."""
+    from . import ntm
+    b, n, _ = pos.shape
+    order = ntm.spatial_order(pos.contiguous())
+    if order is None:
+        return None
+    return (order.view(b, n) - torch.arange(b, device=pos.device, dtype=torch.int32).view(b, 1) * n).contiguous()
+
+
+class ReverseIndex:
+    """The (b, m)-target reverse index of idx (b, n, 3) + its inverse-distance weights for the point-major gradient
+    (geot_rix_build): depends on the coordinates only, so the model builds it on its side stream with the index plan."""
+
+    def __init__(self, idx, weight, m, order=None):
+        b, n, nt = idx.shape
+        self.b, self.n, self.m, self.nt, self.order = b, n, m, nt, order
+        lib = _lib.load()
+        self.ws_ints = int(lib.geot_rix_ws_ints(b, n, m, nt))
+        self.ws = torch.empty(self.ws_ints, dtype=torch.int32, device=idx.device)
+        call("geot_rix_build", idx.device, b, n, m, nt, ptr(idx), ptr(weight), ptr(order), ptr(self.ws), self.ws_ints)
+
+    def gather(self, g_cl):
+        b, n, c = g_cl.shape
+        assert (b, n) == (self.b, self.n)
+        out = torch.empty((b, self.m, c), dtype=torch.float32, device=g_cl.device)
+        call("geot_gather_rows_csr_cl", g_cl.device, b, c, n, self.m, self.nt, ptr(g_cl), ptr(self.ws), ptr(self.order), ptr(out))
+        return out
+
+
+class _FpFrontClFn(Function):
+    """y_cl = three_interpolate(A, idx, w) + skip^T Wb^T on point-major tensors, with the per-tile sums of y and y^2."""
+
+    @staticmethod
+    def forward(ctx, a_cl, idx, weight, skip, wb, order, rix):
+        b, m, c = a_cl.shape
+        n = idx.shape[1]
+        cs = 0 if skip is None else skip.shape[1]
+        tiles = int(_lib.load().geot_fp_front_cl_tiles(b, c, n, cs))
+        y = torch.empty((b, n, c), dtype=torch.float32, device=a_cl.device)
+        partial = torch.empty((tiles, 2, c), dtype=torch.float32, device=a_cl.device)
+        wbc = wb.contiguous() if cs else None
+        call("geot_fp_front_cl", a_cl.device, b, c, m, n, cs, ptr(a_cl), ptr(idx), ptr(weight), ptr(skip), ptr(wbc), ptr(order),
+             ptr(y), ptr(partial))
+        ctx.save_for_backward(idx, weight, skip, wbc)
+        ctx.m, ctx.rix = m, rix
+        ctx.mark_non_differentiable(partial)
+        return y, partial
+
+    @staticmethod
+    def backward(ctx, gy, _gp):
+        idx, weight, skip, wb = ctx.saved_tensors
+        gy = gy.contiguous()
+        ga = gskip = gwb = None
+        if ctx.needs_input_grad[0]:
+            rix = ctx.rix if ctx.rix is not None else ReverseIndex(idx, weight, ctx.m)
+            ga = rix.gather(gy)
+        if skip is not None:
+            if ctx.needs_input_grad[3]:
+                gskip = torch.matmul(gy, wb).transpose(1, 2)                  # (B, n, cs) -> (B, cs, n)
+            if ctx.needs_input_grad[4]:
+                gwb = torch.bmm(skip, gy).sum(0).t()                          # (B, cs, n) x (B, n, C)
+        return ga, None, None, gskip, gwb, None, None
+
+
+def fp_front_cl(a_cl, idx, weight, skip, wb, order=None, rix=None):
+    """a_cl (B,m,C) = known_feats^T W_a^T, idx / weight (B,n,3), skip (B,Cs,n) channels-first or None, wb (C,Cs) ->
+    (y_cl (B,n,C), partial): fp_front on point-major activations.  order (B,n): the row sequence of the launch (values do
+    not depend on it); rix: a ReverseIndex of (idx, weight) built ahead (else the backward builds one)."""
+    return _FpFrontClFn.apply(a_cl.contiguous(), idx.contiguous(), weight.contiguous(),
+                              None if skip is None else skip.contiguous().float(), wb, order, rix)
+
+
+class _BnActClFn(Function):
+    """_BnActFn on a point-major tensor (B, L, C)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, mean, rstd, scale, shift, relu, count, group, pre_bias=None):
+        b, l, c = x.shape
+        if scale is None:
+            scale = (gamma * rstd).contiguous()
+            shift = (beta - mean * scale).contiguous()
+        out = torch.empty_like(x)
+        call("geot_bn_apply_cl", x.device, b * l, c, int(relu), ptr(x), ptr(scale), ptr(shift), ptr(out))
+        ctx.save_for_backward(x, gamma, scale, shift, mean, rstd)
+        ctx.cfg = (bool(relu), count, group)
+        ctx.has_pre_bias = pre_bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, gamma, scale, shift, mean, rstd = ctx.saved_tensors
+        relu, count, group = ctx.cfg
+        b, l, c = x.shape
+        dev = x.device
+        dz = dz.contiguous()
+        partial = torch.empty((int(_lib.load().geot_cl_tiles(1, b * l, c)), 2, c), dtype=torch.float32, device=dev)
+        call("geot_bn_bwd_reduce_cl", dev, b * l, c, int(relu), ptr(x), ptr(dz), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+             ptr(partial))
+        local = torch.empty((c, 2), dtype=torch.float64, device=dev)
+        call("geot_bn_sums_cl", dev, partial.shape[0], c, ptr(partial), ptr(local))
+        sums = local
+        if group is not None:
+            import torch.distributed as dist
+            sums = local.clone()
+            dist.all_reduce(sums, group=group)
+        coef = torch.empty((4, c), dtype=torch.float32, device=dev)
+        on_dev = torch.is_tensor(count)
+        call("geot_bn_bwd_coef", dev, c, ptr(local), ptr(sums), 0.0 if on_dev else float(count), ptr(count) if on_dev else None,
+             ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]))
+        dx = torch.empty_like(x)
+        call("geot_bn_bwd_apply_cl", dev, b * l, c, int(relu), ptr(x), ptr(dz), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+             ptr(scale), ptr(coef[2]), ptr(coef[3]), ptr(dx))
+        g_pre = None
+        if ctx.has_pre_bias:
+            g_pre = scale * coef[1] if (not on_dev and float(count) == 0.0) else torch.zeros_like(scale)
+        return dx, coef[0], coef[1], None, None, None, None, None, None, None, g_pre
+
+
+def bn_act_cl(bn, x, relu=True, partial=None, pre_bias=None):
+    """bn_act for a point-major x (B, L, C) float32 on the GPU with C % 4 == 0 (geot_cl_tiles >= 0); `partial` (T, 2, C)
+    from fp_front_cl.  Same statistics, running buffers and SyncBatchNorm behaviour as bn_act."""
+    b, l, c = x.shape
+    if not (isinstance(bn, nn.modules.batchnorm._BatchNorm) and x.is_cuda and x.dtype == torch.float32
+            and _lib.load().geot_cl_tiles(1, b * l, c) > 0):
+        return bn_act(bn, x.transpose(1, 2).contiguous(), relu, None, pre_bias).transpose(1, 2).contiguous()
+    x = x.contiguous()
+    dev = x.device
+    gamma = bn.weight if bn.weight is not None else torch.ones(c, device=dev)
+    beta = bn.bias if bn.bias is not None else torch.zeros(c, device=dev)
+    use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+    if not use_batch:
+        with torch.no_grad():
+            mean = bn.running_mean.float() if pre_bias is None else bn.running_mean.float() - pre_bias.detach().float()
+            rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+        return _BnActClFn.apply(x, gamma, beta, mean, rstd, None, None, relu, 0.0, None, pre_bias)
+    stats, count, group = _batch_statistics(bn, x, gamma, beta, partial, pre_bias, cl=True)
+    return _BnActClFn.apply(x, gamma, beta, stats[0], stats[1], stats[2], stats[3], relu, count, group, pre_bias)
+
+
+class _FpStageClFn(Function):
+    """[fp_front_cl -> BatchNorm (+ ReLU)] as ONE node: z_cl = act(bn(three_interpolate(A) + skip^T Wb^T)).
+    Forward: the two launches of the separate ops.  Backward: two passes over (y, dz) instead of four over (y, dz, gy) --
+    geot_bn_bwd_reduce_skip_cl (BatchNorm sums + the sums of the skip-weight gradient) and geot_gather_rows_csr_bn_cl (the
+    interpolation gradient with gy = scale (g - c1 - xhat c2) formed on the fly): gy is never written."""
+
+    @staticmethod
+    def forward(ctx, a_cl, idx, weight, skip, wb, gamma, beta, bn, relu, order, rix):
+        b, m, c = a_cl.shape
+        n = idx.shape[1]
+        dev = a_cl.device
+        cs = 0 if skip is None else skip.shape[1]
+        tiles = int(_lib.load().geot_fp_front_cl_tiles(b, c, n, cs))
+        y = torch.empty((b, n, c), dtype=torch.float32, device=dev)
+        partial = torch.empty((tiles, 2, c), dtype=torch.float32, device=dev)
+        wbc = wb.contiguous() if cs else None
+        call("geot_fp_front_cl", dev, b, c, m, n, cs, ptr(a_cl), ptr(idx), ptr(weight), ptr(skip), ptr(wbc), ptr(order), ptr(y),
+             ptr(partial))
+        use_batch = bn.training or (bn.running_mean is None and bn.running_var is None)
+        if use_batch:
+            stats, count, group = _batch_statistics(bn, y, gamma, beta, partial, None, cl=True)
+            mean, rstd, scale, shift = stats[0], stats[1], stats[2], stats[3]
+        else:
+            mean = bn.running_mean.float()
+            rstd = torch.rsqrt(bn.running_var.float() + bn.eps)
+            scale = (gamma.detach() * rstd).contiguous()
+            shift = (beta.detach() - mean * scale).contiguous()
+            count, group = 0.0, None
+        z = torch.empty_like(y)
+        call("geot_bn_apply_cl", dev, b * n, c, int(relu), ptr(y), ptr(scale), ptr(shift), ptr(z))
+        ctx.save_for_backward(y, idx, weight, skip, wbc, scale, shift, mean, rstd)
+        ctx.cfg = (bool(relu), count, group, m, order, rix)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, idx, weight, skip, wb, scale, shift, mean, rstd = ctx.saved_tensors
+        relu, count, group, m, order, rix = ctx.cfg
+        b, n, c = y.shape
+        dev = y.device
+        cs = 0 if skip is None else skip.shape[1]
+        k = 2 + 2 * cs
+        dz = dz.contiguous()
+        lib = _lib.load()
+        partial = torch.empty((int(lib.geot_cl_tiles(1, b * n, c)), k, c), dtype=torch.float32, device=dev)
+        call("geot_bn_bwd_reduce_skip_cl", dev, b, n, c, cs, int(relu), ptr(y), ptr(dz), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+             ptr(skip), ptr(partial))
+        sums_k = torch.empty((c, k), dtype=torch.float64, device=dev)
+        call("geot_bn_sums_k_cl", dev, partial.shape[0], c, k, ptr(partial), ptr(sums_k))
+        local = sums_k[:, :2].contiguous()                                   # sum g, sum g xhat (this rank)
+        sums = local
+        if group is not None:
+            import torch.distributed as dist
+            sums = local.clone()
+            dist.all_reduce(sums, group=group)
+        coef = torch.empty((4, c), dtype=torch.float32, device=dev)          # g_gamma, g_beta, c1, c2
+        on_dev = torch.is_tensor(count)
+        call("geot_bn_bwd_coef", dev, c, ptr(local), ptr(sums), 0.0 if on_dev else float(count), ptr(count) if on_dev else None,
+             ptr(coef[0]), ptr(coef[1]), ptr(coef[2]), ptr(coef[3]))
+        ga = gskip = gwb = None
+        if ctx.needs_input_grad[0]:
+            if rix is None:
+                rix = ReverseIndex(idx, weight, m)
+            ga = torch.empty((b, m, c), dtype=torch.float32, device=dev)
+            call("geot_gather_rows_csr_bn_cl", dev, b, c, n, m, rix.nt, int(relu), ptr(y), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
+                 ptr(rstd), ptr(coef[2]), ptr(coef[3]), ptr(rix.ws), ptr(rix.order), ptr(ga))
+        if cs and ctx.needs_input_grad[4]:
+            # grad_wb[c, j] = sum_e gy[e, c] skip_j[e] = scale_c (sum g skip_j - c1_c sum skip_j - c2_c sum xhat skip_j)
+            s1, s3 = sums_k[:, 2:2 + cs], sums_k[:, 2 + cs:]
+            s2 = skip.sum((0, 2), dtype=torch.float64)
+            gwb = (scale.double().unsqueeze(1) * (s1 - coef[2].double().unsqueeze(1) * s2.unsqueeze(0)
+                                                   - coef[3].double().unsqueeze(1) * s3)).float()
+        if cs and ctx.needs_input_grad[3]:                                   # (never in the model: the skip tensor is input data)
+            gy = torch.empty_like(y)
+            call("geot_bn_bwd_apply_cl", dev, b * n, c, int(relu), ptr(y), ptr(dz), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),
+                 ptr(scale), ptr(coef[2]), ptr(coef[3]), ptr(gy))
+            gskip = torch.matmul(gy, wb).transpose(1, 2)
+        return ga, None, None, gskip, gwb, coef[0], coef[1], None, None, None, None
+
+
+def fp_stage_cl(bn, a_cl, idx, weight, skip, wb, relu=True, order=None, rix=None):
+    """act(bn(fp_front_cl(...))) for a BatchNorm module `bn` (training or eval mode, SyncBatchNorm included) as one
+    autograd node whose backward never materialises the gradient of the BatchNorm's input.  -> z_cl (B, n, C)."""
+    c = a_cl.shape[2]
+    dev = a_cl.device
+    gamma = bn.weight if bn.weight is not None else torch.ones(c, device=dev)
+    beta = bn.bias if bn.bias is not None else torch.zeros(c, device=dev)
+    return _FpStageClFn.apply(a_cl.contiguous(), idx.contiguous(), weight.contiguous(),
+                              None if skip is None else skip.contiguous().float(), wb, gamma, beta, bn, relu, order, rix)
 
 
 class _SegmentMaxFn(Function):

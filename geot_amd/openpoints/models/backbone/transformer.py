@@ -37,6 +37,8 @@ from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_gra
                               edgeconv_tail, edgeconv_tail_eligible)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
 from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
+from ....fused_norm import (fp_front_cl, fp_front_cl_eligible, bn_act_cl, fp_stage_cl, pointwise_to_cl, pointwise_from_cl,
+                            local_spatial_order, ReverseIndex)
 from ....fused_norm import linear as lean_linear, res_ln, res_ln_eligible, qkv_split, softmax_last
 
 
@@ -331,23 +333,52 @@ class DGCNN_Propagation(nn.Module):
         return self._edge(self.layer2, coor_q, f_q, coor_q, f_q, i2)
 
 
-def _fp_factored(fp, unknown, known, unknow_feats, known_feats, nn3=None):
+def _fp_factored(fp, unknown, known, unknow_feats, known_feats, nn3=None, layout="cf"):
     """forward of a PointnetFPModule (pointnet2_modules.py:597-642) with the first 1x1 convolution moved in
     front of the interpolation (see the module docstring); the parameters are ``fp``'s own.  nn3 (optional): the
-    (idx, weight) pair of three_nn + the inverse-distance weights, when the caller has computed them already."""
+    (idx, weight) pair of three_nn + the inverse-distance weights, when the caller has computed them already -- for the
+    point-major layout optionally followed by (order, rix): the Morton sequence of the unknown points
+    (fused_norm.local_spatial_order) and the ReverseIndex of (idx, weight) for the gradient.
+    layout "cl": the first stage runs on point-major (B, n, C) activations where the layer is wide enough."""
     layers = list(fp.mlp.children())
     first = layers[0]
     conv = first.conv
     c = known_feats.shape[1]
     w = conv.weight.view(conv.out_channels, -1)
-    a = pointwise(w[:, :c], known_feats)                                 # (B, Cout, m): GEMM on the known points
+    order = rix = None
     if nn3 is None:
         dist2, idx = pt_utils._ext.three_nn(unknown.contiguous(), known.contiguous())
         weight = None
     else:
-        idx, weight = nn3
+        idx, weight = nn3[:2]
+        if len(nn3) > 2:
+            order, rix = nn3[2:]
     has_bn = any(name == "bn" for name, _ in first.named_children())
     post_act = next(iter(first.named_children()))[0] == "conv"            # conv -> BatchNorm -> ReLU order
+    if (layout == "cl" and conv.bias is None and has_bn and post_act and len(layers) > 1
+            and [n for n, _ in first.named_children()][:2] == ["conv", "bn"]
+            and all(n in ("conv", "bn") or isinstance(mod, nn.ReLU) for n, mod in first.named_children())
+            and next(iter(layers[1].named_children()))[0] == "conv" and layers[1].conv.kernel_size in ((1,), (1, 1))
+            and known_feats.is_cuda and known_feats.dtype == torch.float32
+            and fp_front_cl_eligible(known_feats.new_empty((known_feats.shape[0], conv.out_channels, 0)), unknow_feats)):
+        # the first stage on point-major activations (csrc/channels_last.hip): GEMM -> (B, m, C), interpolation + skip
+        # + BatchNorm sums, BatchNorm + ReLU, and the second stage's convolution reads (B, n, C) as a transposed operand
+        if weight is None:
+            weight = pt_utils._ext.fp_weights(dist2)
+        a_cl = pointwise_to_cl(w[:, :c], known_feats)
+        relu = any(isinstance(mod, nn.ReLU) for _, mod in first.named_children())
+        wb = None if unknow_feats is None else w[:, c:]
+        if os.environ.get("GEOT_FP_CL_FUSED", "1") != "0":   # one node; its backward never writes the BatchNorm's input gradient
+            z_cl = fp_stage_cl(first.bn.bn, a_cl, idx, weight, unknow_feats, wb, relu, order, rix)
+        else:
+            y_cl, partial = fp_front_cl(a_cl, idx, weight, unknow_feats, wb, order, rix)
+            z_cl = bn_act_cl(first.bn.bn, y_cl, relu=relu, partial=partial)
+        conv2 = layers[1].conv
+        y2 = pointwise_from_cl(conv2.weight.view(conv2.out_channels, -1), z_cl)
+        if conv2.bias is not None:
+            y2 = y2 + conv2.bias.view(1, -1, 1)
+        return shared_mlp_nd(layers[1:], y2, first_conv_done=True)
+    a = pointwise(w[:, :c], known_feats)                                 # (B, Cout, m): GEMM on the known points
     if conv.bias is None and has_bn and post_act and fp_front_eligible(a, unknow_feats):
         # interpolation + skip channels + the BatchNorm sums in one kernel, then BatchNorm + ReLU in one pass
         if weight is None:
@@ -387,6 +418,9 @@ class PointTransformer_seg_T(nn.Module):
         self.num_group = num_group
         self.downsample_targets = downsample_targets
         self.dense = dense or os.environ.get("GEOT_DENSE", "factored")
+        # layout of the wide first stage of the FP modules (dense == "factored" only): "cl" = point-major (B, N, C)
+        # activations between two GEMMs (csrc/channels_last.hip), "cf" = the reference's (B, C, N) throughout
+        self.fp_layout = os.environ.get("GEOT_FP_LAYOUT", "cl")
         self.overlap = overlap
         self._side = {}
 
@@ -443,7 +477,7 @@ class PointTransformer_seg_T(nn.Module):
 
     def _fp(self, module, unknown, known, unknow_feats, known_feats, nn3=None):
         if self.dense == "factored":
-            return _fp_factored(module, unknown, known, unknow_feats, known_feats, nn3)
+            return _fp_factored(module, unknown, known, unknow_feats, known_feats, nn3, layout=self.fp_layout)
         return module(unknown, known, unknow_feats, known_feats)
 
     @torch.no_grad()
@@ -458,7 +492,17 @@ class PointTransformer_seg_T(nn.Module):
 
         def nn3(unknown, known):
             dist2, idx = pt_utils._ext.three_nn(unknown.contiguous(), known.contiguous())
-            return idx, pt_utils._ext.fp_weights(dist2)
+            weight = pt_utils._ext.fp_weights(dist2)
+            if self.fp_layout != "cl":
+                return idx, weight
+            # point-major FP stages: in training the reverse index of the gradient; where the table of known points is
+            # larger than an XCD's L2 (4 MB: m > 2048 rows at 384 channels in, 1536 out) also the Morton sequences in which
+            # the forward takes its points and the gradient its targets -- a small table is L2-resident in any order
+            # (prop1 / prop2: 80 us in memory order, 85 in Morton order), and the orders are not free: they run beside the
+            # transformer blocks
+            big = known.shape[1] > 2048
+            rix = ReverseIndex(idx, weight, known.shape[1], local_spatial_order(known) if big else None) if self.training else None
+            return idx, weight, local_spatial_order(unknown) if big else None, rix
         k2, k1 = self.dgcnn_pro_2.k, self.dgcnn_pro_1.k
         return {"center_pts": center_pts, "center_pts_trans": trans, "center_trans": center_trans,
                 "fp2": nn3(center_pts[1], center), "fp1": nn3(center_pts[0], center), "fp0": nn3(pts, center_pts[0]),

@@ -45,16 +45,20 @@ def batch_norm_nd(bn, x):
                                           bn.weight, bn.bias, use_batch, eaf, bn.eps)
 
 
-def shared_mlp_nd(layers, x):
+def shared_mlp_nd(layers, x, first_conv_done=False):
     """Run SharedMLP stages (conv -> BatchNorm -> activation, or pre-activation order) on (B, C, L) tensors; a
-    BatchNorm followed by ReLU is one fused op (geot_amd/fused_norm.py: 2 + 2 passes instead of 5 + 8)."""
+    BatchNorm followed by ReLU is one fused op (geot_amd/fused_norm.py: 2 + 2 passes instead of 5 + 8).
+    first_conv_done: x already is the output of the first stage's convolution (the caller evaluated it in its own way)."""
     from ..fused_norm import bn_act
-    for stage in layers:
+    for k, stage in enumerate(layers):
         mods = list(stage.named_children())
         i = 0
         while i < len(mods):
             name, mod = mods[i]
             if name == "conv":
+                if k == 0 and first_conv_done:
+                    i += 1
+                    continue
                 x = mod(x) if isinstance(mod, (PointwiseConv1d, PointwiseConv2d)) else conv1x1(mod, x)
             elif name == "bn":
                 fuse = i + 1 < len(mods) and isinstance(mods[i + 1][1], nn.ReLU)

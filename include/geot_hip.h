@@ -245,6 +245,55 @@ int geot_fp_front_slices(int b, int c, int m, int n);
 int geot_fp_front(int b, int c, int m, int n, int cs, const float *A, const int *idx, const float *weight,
                   const float *skip, const float *Wb, float *y, float *partial, void *stream);
 
+/* ---- the same FP front end and its BatchNorm on POINT-MAJOR activations (B, N, C), csrc/channels_last.hip ----------
+ * Behaviour replaced: three_interpolate + concat + the first Conv2d/BatchNorm2d/ReLU of PointnetFPModule.mlp
+ * (pointnet2/pointnet2_modules.py:619-640, pointnet2/_ext_src/src/interpolate_gpu.cu:88-146) and its gradient.
+ * A point's C channels are one contiguous row; the 1x1 convolutions on either side are GEMMs and take the layout as a
+ * transpose flag, so nothing is transposed in memory.  Needs C % 4 == 0 and C <= 4096 (geot_cl_tiles() >= 0).
+ *   geot_cl_tiles(batches, rows_per_batch, c)  rows T of the (T, 2, c) partial-sum buffer of a bn_*_cl reduction over
+ *                      batches x rows_per_batch rows;  geot_fp_front_cl_tiles(b, c, n, cs): the same for fp_front_cl
+ *   geot_fp_front_cl   y_cl (b,n,c) = sum_t weight[b,e,t] a_cl[b, idx[b,e,t], :] + wb (c,cs) skip (b,cs,n)[:, e];
+ *                      partial (T,2,c) = per-tile (sum y, sum y^2); order (b,n) or NULL = the sequence in which a
+ *                      workgroup takes its points (values do not depend on it; the partial sums' rounding does)
+ *   geot_bn_stats_cl / _apply_cl / _bwd_reduce_cl / _bwd_apply_cl   as geot_bn_* above on (rows, c) row-major
+ *   geot_bn_sums_cl    sums (c,2) fp64 = sum over the T tiles of partial (T,2,c), fixed order
+ *   geot_rix_build     reverse index of idx (b,L,nt) with values in [0,m): per target the (source, weight) pairs in
+ *                      ascending pair order, into ws (geot_rix_ws_ints ints); weight NULL = unit weights; order (b,m)
+ *                      or NULL = the sequence in which the gather takes the targets (a permutation per cloud)
+ *   geot_gather_rows_csr_cl   out_cl (b,m,c) = sum over the pairs of target j of weight * g_cl[b, source, :]
+ *                      (the gradient of a point-major gather; one writer per row, fixed order: reproducible); `order`
+ *                      must be the one the index was built with */
+int geot_cl_tiles(int batches, long long rows_per_batch, int c);
+int geot_fp_front_cl_tiles(int b, int c, int n, int cs);
+int geot_fp_front_cl(int b, int c, int m, int n, int cs, const float *a_cl, const int *idx, const float *weight,
+                     const float *skip, const float *wb, const int *order, float *y_cl, float *partial, void *stream);
+int geot_bn_stats_cl(long long rows, int c, const float *x, float *partial, void *stream);
+int geot_bn_apply_cl(long long rows, int c, int relu, const float *x, const float *scale, const float *shift, float *out,
+                     void *stream);
+int geot_bn_bwd_reduce_cl(long long rows, int c, int relu, const float *x, const float *dz, const float *scale,
+                          const float *shift, const float *mean, const float *rstd, float *partial, void *stream);
+int geot_bn_bwd_apply_cl(long long rows, int c, int relu, const float *x, const float *dz, const float *scale,
+                         const float *shift, const float *mean, const float *rstd, const float *k0, const float *c1,
+                         const float *c2, float *dx, void *stream);
+int geot_bn_sums_cl(int tiles, int c, const float *partial, double *sums, void *stream);
+long long geot_rix_ws_ints(int b, long long L, int m, int nt);
+int geot_rix_build(int b, int L, int m, int nt, const int *idx, const float *weight, const int *order, int *ws,
+                   long long ws_ints, void *stream);
+int geot_gather_rows_csr_cl(int b, int c, int L, int m, int nt, const float *g_cl, const int *ws, const int *order,
+                            float *out_cl, void *stream);
+/* The backward of [fp_front_cl -> BatchNorm (+ ReLU)] in two passes instead of four, the gradient gy of the BatchNorm's
+ * input never written:  geot_bn_bwd_reduce_skip_cl = geot_bn_bwd_reduce_cl + the sums sum g skip_k, sum xhat skip_k that
+ * give grad_wb = sum_e gy_e skip_e once the means are known (partial (T, 2 + 2 cs, c), T = geot_cl_tiles(1, b n, c);
+ * geot_bn_sums_k_cl adds the T tiles up: sums (c, K) fp64);  geot_gather_rows_csr_bn_cl = geot_gather_rows_csr_cl of
+ * gy = scale (g - c1 - xhat c2), formed on the fly from the rows of y_cl and dz_cl. */
+int geot_bn_sums_k_cl(int tiles, int c, int k, const float *partial, double *sums, void *stream);
+int geot_bn_bwd_reduce_skip_cl(int b, int n, int c, int cs, int relu, const float *x, const float *dz, const float *scale,
+                               const float *shift, const float *mean, const float *rstd, const float *skip, float *partial,
+                               void *stream);
+int geot_gather_rows_csr_bn_cl(int b, int c, int L, int m, int nt, int relu, const float *y_cl, const float *dz_cl,
+                               const float *scale, const float *shift, const float *mean, const float *rstd, const float *c1,
+                               const float *c2, const int *ws, const int *order, float *out_cl, void *stream);
+
 /* EdgeConv tail = the rest of DGCNN_Propagation's layer behind the (linear) 1x1 convolution
  * (openpoints/models/backbone/transformer.py:366-379: Conv2d -> GroupNorm(groups) -> LeakyReLU(slope) ->
  * max over the k neighbours), fused.  With P = W_d x_k (b,c,nk) and Q = (W_q - W_d) x_q (b,c,nq) from the caller's

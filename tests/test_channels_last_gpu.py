@@ -1,0 +1,251 @@
+"""GPU suite: the point-major (B, N, C) form of the PointnetFPModule front end (csrc/channels_last.hip,
+gather_group.hip gather_rows_csr_cl_kernel; pointnet2/pointnet2_modules.py:619-640 and interpolate_gpu.cu:88-146 are
+the behaviour) against the channels-first kernels, which the oracle tests pin, and against float64.
+
+* forward values: bit-identical to the channels-first kernel (same per-element arithmetic), with and without a row
+  sequence, ragged channel counts, no skip tensor
+* BatchNorm sums / passes: float64 referee at 1e-5, running statistics included
+* gradient: the reverse-index row gather == the channels-first gradient (same summation order: bit-identical where the
+  channels-first path is the reverse-index one), float64 referee, hub targets, empty targets, bit-reproducible
+* the FP module and the whole model in both layouts
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+def _cloud(b, n, seed=0):
+    from geot_amd.synth import make_batch
+    return torch.from_numpy(make_batch(b, n, start_index=seed)[0]).to(DEV)
+
+
+def _nn3(unknown, known):
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    d2, idx = pu._ext.three_nn(unknown.contiguous(), known.contiguous())
+    return idx, pu._ext.fp_weights(d2)
+
+
+def rel(got, want):
+    want = want.detach().double().cpu()
+    return float((got.detach().double().cpu() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("b,n,m,c,cs", [(2, 6000, 1500, 256, 5), (3, 4099, 517, 260, 0), (1, 2048, 64, 1536, 3), (2, 777, 3, 512, 8)])
+@pytest.mark.parametrize("ordered", [False, True])
+def test_fp_front_cl_equals_the_channels_first_kernel(b, n, m, c, cs, ordered):
+    from geot_amd import fused_norm as fn
+    pos = _cloud(b, n, 1)
+    known = pos[:, :m].contiguous()
+    idx, w = _nn3(pos, known)
+    torch.manual_seed(0)
+    a = torch.randn(b, c, m, device=DEV)
+    skip = torch.randn(b, cs, n, device=DEV) if cs else None
+    wb = torch.randn(c, cs, device=DEV) if cs else None
+    order = fn.local_spatial_order(pos) if ordered else None
+    if order is not None:                                    # a permutation of every cloud's points
+        assert torch.equal(order.long().sort(1)[0], torch.arange(n, device=DEV).expand(b, -1))
+    y_cf, _ = fn.fp_front(a, idx, w, skip, wb)
+    y_cl, partial = fn.fp_front_cl(a.transpose(1, 2).contiguous(), idx, w, skip, wb, order)
+    assert y_cl.shape == (b, n, c)
+    assert torch.equal(y_cl.transpose(1, 2), y_cf)
+    # the per-tile sums that go to the BatchNorm
+    want = torch.stack([y_cf.double().sum((0, 2)), (y_cf.double() ** 2).sum((0, 2))], 0)
+    got = partial.double().sum(0)
+    scale = torch.stack([y_cf.double().abs().sum((0, 2)), want[1]], 0)
+    assert float(((got - want).abs() / scale).max()) <= 1e-6
+
+
+def test_fp_front_cl_rejects_what_it_does_not_cover():
+    from geot_amd import _lib
+    lib = _lib.load()
+    assert lib.geot_fp_front_cl_tiles(2, 1538, 100, 3) == -1          # C % 4
+    assert lib.geot_fp_front_cl_tiles(2, 4100, 100, 3) == -1          # C > 4096
+    assert lib.geot_fp_front_cl_tiles(2, 512, 100, 9) == -1           # more than 8 skip channels
+    assert lib.geot_cl_tiles(1, 100, 6) == -1
+    assert lib.geot_fp_front_cl_tiles(2, 512, 100, 3) >= 1
+
+
+def _grad_case(b, n, m, c, adversarial):
+    pos = _cloud(b, n, 2)
+    known = pos[:, :m].contiguous()
+    idx, w = _nn3(pos, known)
+    if adversarial:                                          # a hub (every third pair on target 0) and untouched targets
+        idx = idx.clone()
+        idx[:, ::3, 0] = 0
+        idx[idx == m - 1] = 1
+    torch.manual_seed(1)
+    gy = torch.randn(b, c, n, device=DEV)
+    return pos, known, idx.contiguous(), w, gy
+
+
+@pytest.mark.parametrize("b,n,m,c", [(2, 6000, 1500, 256), (3, 4099, 517, 260), (1, 3000, 8, 1536)])
+@pytest.mark.parametrize("adversarial", [False, True])
+@pytest.mark.parametrize("ordered", [False, True])
+def test_reverse_index_row_gather_is_the_interpolation_gradient(b, n, m, c, adversarial, ordered):
+    from geot_amd import fused_norm as fn
+    from geot_amd.ext import pointnet2_ext as p2
+    pos, known, idx, w, gy = _grad_case(b, n, m, c, adversarial)
+    want64 = torch.zeros(b, c, m, dtype=torch.float64)
+    src = (gy.double().cpu().unsqueeze(-1) * w.double().cpu().unsqueeze(1)).reshape(b, c, n * 3)
+    want64.scatter_add_(2, idx.long().cpu().reshape(b, 1, n * 3).expand(-1, c, -1), src)
+    order = fn.local_spatial_order(known) if ordered else None
+    gy_cl = gy.transpose(1, 2).contiguous()
+    rix = fn.ReverseIndex(idx, w, m, order)
+    got = rix.gather(gy_cl)
+    assert got.shape == (b, m, c)
+    assert rel(got.transpose(1, 2), want64) <= 1e-5 * (30 if adversarial else 1)      # a hub sums 2000 terms in fp32
+    # the same index rebuilt, the same gather again: bit-identical (one writer per row, fixed summation order)
+    again = fn.ReverseIndex(idx, w, m, order).gather(gy_cl)
+    assert torch.equal(got, again)
+    # untouched targets are written (zeros), not left as they were
+    if adversarial:
+        assert float(got[:, m - 1].abs().max()) == 0.0
+    # and the channels-first gradient agrees
+    cf = p2.three_interpolate_grad(gy, idx, w, m)
+    assert rel(got.transpose(1, 2), cf) <= 2e-6 * (30 if adversarial else 1)
+
+
+def test_reverse_index_without_weights_and_single_slot():
+    """nt = 1, unit weights: the gradient of a plain row gather (group / gather_operation in point-major form)."""
+    from geot_amd import _lib
+    from geot_amd.ext._common import call, ptr
+    b, n, m, c = 2, 5000, 700, 128
+    torch.manual_seed(4)
+    idx = torch.randint(0, m, (b, n, 1), device=DEV, dtype=torch.int32)
+    g = torch.randn(b, n, c, device=DEV)
+    lib = _lib.load()
+    ints = int(lib.geot_rix_ws_ints(b, n, m, 1))
+    ws = torch.empty(ints, dtype=torch.int32, device=DEV)
+    call("geot_rix_build", DEV, b, n, m, 1, ptr(idx), None, None, ptr(ws), ints)
+    out = torch.full((b, m, c), float("nan"), device=DEV)
+    call("geot_gather_rows_csr_cl", DEV, b, c, n, m, 1, ptr(g), ptr(ws), None, ptr(out))
+    want = torch.zeros(b, m, c, dtype=torch.float64)
+    want.scatter_add_(1, idx.long().cpu().expand(-1, -1, c), g.double().cpu())
+    assert rel(out, want) <= 1e-6
+    # too small a workspace is refused, not overrun
+    with pytest.raises(RuntimeError):
+        call("geot_rix_build", DEV, b, n, m, 1, ptr(idx), None, None, ptr(ws), ints - 1)
+
+
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_act_cl_against_float64(relu, training):
+    from geot_amd import fused_norm as fn
+    b, l, c = 3, 2777, 260
+    torch.manual_seed(5)
+    x = (torch.randn(b, l, c, device=DEV) * 2 + 0.5)
+    up = torch.randn(b, l, c, device=DEV)
+    bn = torch.nn.BatchNorm1d(c).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2)
+        bn.running_var.uniform_(0.5, 1.5)
+    bn.train(training)
+    ref = copy.deepcopy(bn).double().cpu()
+    x64 = x.double().cpu().transpose(1, 2).contiguous().requires_grad_(True)          # (B, C, L) for the module
+    y64 = ref(x64)
+    y64 = torch.relu(y64) if relu else y64
+    (y64 * up.double().cpu().transpose(1, 2)).sum().backward()
+    xg = x.clone().requires_grad_(True)
+    y = fn.bn_act_cl(bn, xg, relu=relu)
+    (y * up).sum().backward()
+    assert rel(y.transpose(1, 2), y64) <= 1e-5
+    assert rel(xg.grad.transpose(1, 2), x64.grad) <= 2e-5
+    assert rel(bn.weight.grad, ref.weight.grad) <= 2e-5 and rel(bn.bias.grad, ref.bias.grad) <= 2e-5
+    assert rel(bn.running_mean, ref.running_mean) <= 1e-5 and rel(bn.running_var, ref.running_var) <= 1e-5
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked)
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("c_known,c_skip,widths", [(48, 5, [256, 32]), (96, 0, [512, 64])])
+def test_fp_module_point_major_against_float64(c_known, c_skip, widths, fused, monkeypatch):
+    """PointnetFPModule in training mode through _fp_factored(layout="cl") vs the reference op order in fp64 (as
+    tests/test_fp64_referee_gpu.py does for the channels-first forms), and vs the channels-first factored form."""
+    from geot_amd.pointnet2.pointnet2_modules import PointnetFPModule
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    from geot_amd.openpoints.models.backbone.transformer import _fp_factored
+    from geot_amd import fused_norm as fn
+    monkeypatch.setenv("GEOT_FP_CL_FUSED", fused)        # "1": one node, gy never written; "0": fp_front_cl + bn_act_cl
+    pos = _cloud(2, 5000, 3)
+    known = pos[:, ::5].contiguous()
+    torch.manual_seed(1)
+    fp = PointnetFPModule(mlp=[c_known + c_skip] + widths).to(DEV).train()
+    kf = torch.randn(2, c_known, known.shape[1], device=DEV)
+    sk = torch.randn(2, c_skip, 5000, device=DEV) if c_skip else None
+    up = torch.randn(2, widths[-1], 5000, device=DEV)
+    d2, idx = pu._ext.three_nn(pos, known)
+    dist = torch.sqrt(d2.double().cpu())
+    r = 1.0 / (dist + 1e-8)
+    w64 = r / r.sum(2, keepdim=True)
+    fp64 = copy.deepcopy(fp).double().cpu()
+    kf64 = kf.double().cpu().requires_grad_(True)
+    g = torch.gather(kf64, 2, idx.cpu().long().reshape(2, 1, -1).expand(-1, c_known, -1)).view(2, c_known, 5000, 3)
+    x64 = (g * w64.unsqueeze(1)).sum(-1)
+    if sk is not None:
+        x64 = torch.cat([x64, sk.double().cpu()], 1)
+    y64 = fp64.mlp(x64.unsqueeze(-1)).squeeze(-1)
+    (y64 * up.double().cpu()).sum().backward()
+    p64 = dict(fp64.named_parameters())
+    errs = {}
+    for mode in ("cf", "cl", "cl+plan"):
+        m = copy.deepcopy(fp)
+        k = kf.clone().requires_grad_(True)
+        nn3 = None
+        if mode == "cl+plan":
+            weight = pu._ext.fp_weights(d2)
+            nn3 = (idx, weight, fn.local_spatial_order(pos), fn.ReverseIndex(idx, weight, known.shape[1], fn.local_spatial_order(known)))
+        y = _fp_factored(m, pos, known, sk, k, nn3, layout=mode[:2])
+        (y * up).sum().backward()
+        errs[mode] = [rel(y, y64), rel(k.grad, kf64.grad)] + [rel(p.grad, p64[n].grad) for n, p in m.named_parameters()]
+        for n, buf in m.named_buffers():
+            if buf.dtype.is_floating_point:
+                assert rel(buf, dict(fp64.named_buffers())[n]) <= 1e-5, (mode, n)
+    for mode, e in errs.items():
+        assert e[0] <= 1e-5, (mode, "forward", e)
+        assert max(e[1:]) <= 5e-5, (mode, "gradients", e)
+    assert errs["cl"][0] <= 3 * errs["cf"][0] + 2e-6 and max(errs["cl"][1:]) <= 3 * max(errs["cf"][1:]) + 5e-6, errs
+
+
+def test_model_step_in_both_fp_layouts():
+    """PointTransformer_seg_T (small config, training step): logits, every gradient and every buffer with
+    fp_layout = "cl" against "cf" -- the same function, BatchNorm statistics summed in another order."""
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd.synth import make_batch, region_labels
+    cfg = dict(trans_dim=384, depth=3, num_heads=4, group_size=32, num_group=128, encoder_dims=256, nclasses=17,
+               drop_path_rate=0.0, downsample_targets=[2048, 1024, 512], extract_layers=[1, 2, 3])
+    xyz = make_batch(2, 4096, start_index=5)[0]
+    target = torch.from_numpy(region_labels(xyz)).to(DEV)
+    cls = torch.tensor([[0], [1]], device=DEV)
+    torch.manual_seed(3)
+    init = PointTransformer_seg_T(**cfg).state_dict()
+    res = {}
+    for layout in ("cf", "cl"):
+        m = PointTransformer_seg_T(**cfg)
+        m.load_state_dict(init)
+        m.fp_layout = layout
+        m = m.to(DEV).train()
+        m.seg_head[2].p = 0.0
+        pos = torch.from_numpy(xyz).to(DEV)
+        logit = m(pos, pos.transpose(1, 2).contiguous(), cls, torch.eye(17, device=DEV))[0]
+        torch.nn.functional.cross_entropy(logit, target).backward()
+        res[layout] = (logit.detach(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
+                       {n: b.detach().clone() for n, b in m.named_buffers()})
+        m.eval()                                             # and the eval forward (running statistics, no reverse index)
+        with torch.no_grad():
+            res[layout] += (m(pos, pos.transpose(1, 2).contiguous(), cls, torch.eye(17, device=DEV))[0],)
+    (l0, g0, b0, e0), (l1, g1, b1, e1) = res["cf"], res["cl"]
+    assert rel(l1, l0) <= 5e-5 and rel(e1, e0) <= 5e-5
+    assert set(g0) == set(g1)
+    zero_grad = ("encoder.first_conv.0.bias", "encoder.first_conv.3.bias", "encoder.second_conv.0.bias", "seg_head.0.bias")
+    for k in g0:
+        if k not in zero_grad:
+            err = float((g0[k] - g1[k]).norm() / (g0[k].norm() + 1e-30))
+            assert err <= 2e-3, (k, err)                     # fp32 through ~30 layers with max-pools (see test_fp64_referee)
+    for k in b0:
+        assert float((b0[k].float() - b1[k].float()).abs().max()) <= 1e-5 * max(1.0, float(b0[k].float().abs().max())), k
