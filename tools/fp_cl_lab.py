@@ -128,4 +128,23 @@ for name, n, m, cs in (("prop0", 24000, 8192, 5), ("prop1", 8192, 512, 3), ("pro
             print("bn bwd apply   cf %6.1f us  cl %6.1f us  identical %s" % (t1, t2, torch.equal(dx_cl.transpose(1, 2), dx_cf)))
             t1 = timed(lambda: call("geot_bn_sums_cl", DEV, tl, C, ptr(p_cl), ptr(s_cl)))
             print("bn sums cl (%d tiles) %6.1f us" % (tl, t1), flush=True)
+            # the fused backward: reduce + skip sums, and the gather that forms gy on the fly (against apply + gather above)
+            k = 2 + 2 * cs
+            p_k = torch.empty(tl, k, C, device=DEV)
+            t1 = timed(lambda: call("geot_bn_bwd_reduce_skip_cl", DEV, B, n, C, cs, 1, ptr(y_cl), ptr(gy_cl), ptr(scale), ptr(shift),
+                                    ptr(mean), ptr(rstd), ptr(skip), ptr(p_k)))
+            s_k = torch.empty(C, k, dtype=torch.float64, device=DEV)
+            t2 = timed(lambda: call("geot_bn_sums_k_cl", DEV, tl, C, k, ptr(p_k), ptr(s_k)))
+            order = local_order(known)
+            call("geot_rix_build", DEV, B, n, m, 3, ptr(idx), ptr(w), ptr(order), ptr(ws), ws_ints)
+            t3 = timed(lambda: call("geot_gather_rows_csr_bn_cl", DEV, B, C, n, m, 3, 1, ptr(y_cl), ptr(gy_cl), ptr(scale), ptr(shift),
+                                    ptr(mean), ptr(rstd), ptr(c1), ptr(c2), ptr(ws), ptr(order), ptr(ga_cl)))
+            call("geot_gather_rows_csr_cl", DEV, B, C, n, m, 3, ptr(dx_cl), ptr(ws), ptr(order), ptr(out_cl[:, :m].contiguous()))
+            ref = torch.empty(B, m, C, device=DEV)
+            call("geot_bn_bwd_apply_cl", DEV, R, C, 1, ptr(y_cl), ptr(gy_cl), ptr(scale), ptr(shift), ptr(mean), ptr(rstd), ptr(scale),
+                 ptr(c1), ptr(c2), ptr(dx_cl))
+            call("geot_gather_rows_csr_cl", DEV, B, C, n, m, 3, ptr(dx_cl), ptr(ws), ptr(order), ptr(ref))
+            err = float((ga_cl - ref).abs().max() / ref.abs().max())
+            print("fused backward: reduce + skip sums %6.1f us, sums (%d x %d) %5.1f us, gather with the BatchNorm backward inside "
+                  "%6.1f us (vs apply + gather: max rel %.1e)" % (t1, tl, k, t2, t3, err), flush=True)
     del a, a_cl, y_cf, y_cl, gy, gy_cl, ga_cf, ga_cl
