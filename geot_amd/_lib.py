@@ -96,6 +96,8 @@ PROTOTYPES.update({
     "geot_poly1_focal": [_c_int] * 3 + [_c_float] * 3 + [_P] * 5 + [_c_void_p],
     "geot_poly1_focal_grad": [_c_int] * 3 + [_c_float] * 3 + [_P] * 6 + [_c_void_p],
     "geot_bn_sums": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
+    "geot_bn_sums_shifted": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
+    "geot_bn_sums_shifted_cl": [_c_int, _c_int, _P, _P, _c_void_p],
     "geot_bn_finalize": [_c_int, _P, ctypes.c_double, _P, ctypes.c_double, ctypes.c_double] + [_P] * 9 + [_c_void_p],
     "geot_bn_bwd_coef": [_c_int, _P, _P, ctypes.c_double, _P] + [_P] * 4 + [_c_void_p],
     "geot_bn_stats": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
@@ -143,6 +145,7 @@ PLAIN = {
     "geot_fp_front_slices": ([_c_int] * 4, _c_int),
     "geot_cl_tiles": ([_c_int, ctypes.c_longlong, _c_int], _c_int),
     "geot_fp_front_cl_tiles": ([_c_int] * 4, _c_int),
+    "geot_cl_stat_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_rix_ws_ints": ([_c_int, ctypes.c_longlong, _c_int, _c_int], ctypes.c_longlong),
     "geot_edgeconv_ws_bytes": ([_c_int] * 5, ctypes.c_longlong),
     "geot_poly1_focal_ws_doubles": ([_c_int] * 3, ctypes.c_longlong),

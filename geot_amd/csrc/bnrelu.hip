@@ -42,7 +42,11 @@ __device__ __forceinline__ void bn_block_store2(float a, float b, float *__restr
     }
 }
 
-// grid (slices, C, B): partial[((b * C + c) * slices + s) * 2 + {0, 1}] = sum x, sum x^2 over the slice
+// Batch statistics are accumulated SHIFTED: a slice sums (x - p) and (x - p)^2 around a pivot p = its own first
+// element, in fp32, and hands over (s1, s2, p, count); the fp64 pass that adds the slices up rebuilds
+// sum x = s1 + n p and sum x^2 = s2 + 2 p s1 + n p^2 exactly.  With plain fp32 sums of x and x^2 the variance
+// E[x^2] - mean^2 loses (mean / std)^2 of its digits before any fp64 arithmetic sees them.
+// grid (slices, C, B): partial[((b * C + c) * slices + s) * 4 + {0..3}] = s1, s2, pivot, count of the slice
 __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int c, int l, const float *__restrict__ x,
                                                               float *__restrict__ partial)
 {
@@ -51,20 +55,24 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(int c, int l, cons
     const int per = (((l + gridDim.x - 1) / gridDim.x) + 3) & ~3;
     const int e0 = blockIdx.x * per, e1 = min(l, e0 + per);
     float s = 0.f, ss = 0.f;
+    const float p = e0 < e1 ? row[e0] : 0.f;
     if (e0 >= e1) {
         // empty slice (short rows): contributes zeros
     } else if ((((uintptr_t)row) & 15) == 0) {
         const int v0 = e0 >> 2, v1 = e1 >> 2;
         for (int v = v0 + threadIdx.x; v < v1; v += BN_THREADS) {
-            const float4 q = reinterpret_cast<const float4 *>(row)[v];
+            float4 q = reinterpret_cast<const float4 *>(row)[v];
+            q.x -= p; q.y -= p; q.z -= p; q.w -= p;
             s += (q.x + q.y) + (q.z + q.w);
             ss = fmaf(q.x, q.x, fmaf(q.y, q.y, fmaf(q.z, q.z, fmaf(q.w, q.w, ss))));
         }
-        for (int e = (v1 << 2) + threadIdx.x; e < e1; e += BN_THREADS) { s += row[e]; ss = fmaf(row[e], row[e], ss); }
+        for (int e = (v1 << 2) + threadIdx.x; e < e1; e += BN_THREADS) { const float d = row[e] - p; s += d; ss = fmaf(d, d, ss); }
     } else {
-        for (int e = e0 + threadIdx.x; e < e1; e += BN_THREADS) { s += row[e]; ss = fmaf(row[e], row[e], ss); }
+        for (int e = e0 + threadIdx.x; e < e1; e += BN_THREADS) { const float d = row[e] - p; s += d; ss = fmaf(d, d, ss); }
     }
-    bn_block_store2(s, ss, partial + (((size_t)bi * c + cc) * gridDim.x + blockIdx.x) * 2);
+    float *dst = partial + (((size_t)bi * c + cc) * gridDim.x + blockIdx.x) * 4;
+    bn_block_store2(s, ss, dst);
+    if (threadIdx.x == 0) { dst[2] = p; dst[3] = (float)max(e1 - e0, 0); }
 }
 
 // out = x * scale[c] + shift[c], clamped at 0 when relu; grid (gx, C, B)
@@ -202,9 +210,32 @@ __global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int 
     __syncthreads();
     const int per = (n + gridDim.x - 1) / gridDim.x;
     const int e0 = blockIdx.x * per, e1 = min(n, e0 + per);
-    float s[CH], ss[CH];
+    float s[CH], ss[CH], piv[CH];
 #pragma unroll
-    for (int l = 0; l < CH; ++l) s[l] = ss[l] = 0.f;
+    for (int l = 0; l < CH; ++l) s[l] = ss[l] = piv[l] = 0.f;
+    if (e0 < e1) {   // pivot of the shifted sums (see bn_stats_kernel): the slice's first value, formed by every thread
+        int i3[3];
+        float w3[3], sk0[FP_MAX_SKIP];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            i3[t] = idx[((size_t)bi * n + e0) * 3 + t];
+            w3[t] = w[((size_t)bi * n + e0) * 3 + t];
+        }
+#pragma unroll
+        for (int k = 0; k < FP_MAX_SKIP; ++k) sk0[k] = k < cs ? skip[((size_t)bi * cs + k) * n + e0] : 0.f;
+#pragma unroll
+        for (int l = 0; l < CH; ++l) {
+            if (l < nch) {
+                const float *R = fp_rows + (size_t)l * m;
+                float v = R[i3[0]] * w3[0];
+                v = v + R[i3[1]] * w3[1];
+                v = v + R[i3[2]] * w3[2];
+#pragma unroll
+                for (int k = 0; k < FP_MAX_SKIP; ++k) v = fmaf(wb[l][k], sk0[k], v);
+                piv[l] = v;
+            }
+        }
+    }
 #ifndef GEOT_FP_LAB_U
 #define GEOT_FP_LAB_U 2
 #endif
@@ -246,8 +277,9 @@ __global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int 
 #ifndef GEOT_FP_LAB_NOSTORE
                         y[((size_t)bi * c + c0 + l) * n + e] = v;
 #endif
-                        s[l] += v;
-                        ss[l] = fmaf(v, v, ss[l]);
+                        const float d = v - piv[l];
+                        s[l] += d;
+                        ss[l] = fmaf(d, d, ss[l]);
                     }
                 }
             }
@@ -265,7 +297,9 @@ __global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int 
         if (l < nch) {
             float t = 0.f;
             for (int v = 0; v < FP_THREADS / 64; ++v) t += red[v][l][q];
-            partial[(((size_t)bi * c + c0 + l) * gridDim.x + blockIdx.x) * 2 + q] = t;
+            float *dst = partial + (((size_t)bi * c + c0 + l) * gridDim.x + blockIdx.x) * 4;
+            dst[q] = t;
+            dst[2 + q] = q == 0 ? piv[l] : (float)max(e1 - e0, 0);       // (s1, s2, pivot, count)
         }
     }
 }
@@ -545,6 +579,31 @@ __global__ __launch_bounds__(64) void bn_sums_kernel(int b, int c, int s, const 
     }
 }
 
+// the same for the shifted statistics records (s1, s2, pivot, count) of bn_stats_kernel / fp_front_kernel: every record is
+// turned back into (sum x, sum x^2) in fp64 before it is added
+__global__ __launch_bounds__(64) void bn_sums_shifted_kernel(int b, int c, int s, const float *__restrict__ partial,
+                                                             double *__restrict__ sums)
+{
+    const int ch = blockIdx.x, lane = threadIdx.x;
+    double a0 = 0.0, a1 = 0.0;
+    for (int t = lane; t < b * s; t += 64) {
+        const int bi = t / s, sl = t - bi * s;
+        const float4 v = reinterpret_cast<const float4 *>(partial)[((size_t)bi * c + ch) * s + sl];
+        const double s1 = v.x, s2 = v.y, p = v.z, n = v.w;
+        a0 += s1 + n * p;
+        a1 += s2 + 2.0 * p * s1 + n * p * p;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        a0 += __shfl_xor(a0, o);
+        a1 += __shfl_xor(a1, o);
+    }
+    if (lane == 0) {
+        sums[2 * ch] = a0;
+        sums[2 * ch + 1] = a1;
+    }
+}
+
 // mean / biased variance from (sum x, sum x^2) and the element count, everything BatchNorm derives from them:
 // rstd, the affine pair of the apply pass, the running statistics (unbiased variance, factor eaf).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(int c, const double *__restrict__ sums, double count,
@@ -629,6 +688,14 @@ GEOT_EXPORT int geot_bn_bwd_apply(int b, int c, int l, int relu, const float *x,
     if (!bn_dims_ok(b, c, l)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bn_gx(l), c, b), dim3(BN_THREADS), 0, (hipStream_t)stream, c, l, relu, x, dz,
                        scale, shift, mean, rstd, k0, c1, c2, dx);
+    return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_bn_sums_shifted(int b, int c, int s, const float *partial, double *sums, void *stream)
+{
+    if (b < 0 || c < 0 || s < 0) return hipErrorInvalidValue;
+    if (c == 0) return hipSuccess;
+    hipLaunchKernelGGL(bn_sums_shifted_kernel, dim3(c), dim3(64), 0, (hipStream_t)stream, b, c, s, partial, sums);
     return hipGetLastError();
 }
 

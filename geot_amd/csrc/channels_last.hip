@@ -103,7 +103,7 @@ template <int CS, int U>
 __device__ __forceinline__ void fp_front_cl_rows(int i, int cnt, int c4, int q, bool on, cl_f4 *__restrict__ y,
                                                  const cl_f4 (&p)[U][3], const float (*s_w)[3],
                                                  const float (*s_sk)[CS > 0 ? CS : 1], const int *s_out, const cl_f4 *wbr,
-                                                 cl_f4 &s, cl_f4 &ss)
+                                                 cl_f4 &s, cl_f4 &ss, cl_f4 &piv, int &seen)
 {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -117,8 +117,11 @@ __device__ __forceinline__ void fp_front_cl_rows(int i, int cnt, int c4, int q, 
                 const int orow = __builtin_amdgcn_readfirstlane(s_out[i + u]);
                 CL_ST(v, y + (size_t)orow * c4 + q);
             }
-            s = s + v;
-            ss = __builtin_elementwise_fma(v, v, ss);
+            if (seen == 0) piv = v;                       // pivot of the shifted sums: this workgroup's first row
+            ++seen;
+            const cl_f4 d = v - piv;
+            s = s + d;
+            ss = __builtin_elementwise_fma(d, d, ss);
         }
     }
 }
@@ -168,7 +171,8 @@ __global__ __launch_bounds__(CL_MAX_THREADS) void fp_front_cl_kernel(
         wbr[k].z = wb[(size_t)(4 * q + 2) * CS + k];
         wbr[k].w = wb[(size_t)(4 * q + 3) * CS + k];
     }
-    cl_f4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    cl_f4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f}, piv = {0.f, 0.f, 0.f, 0.f};
+    int seen = 0;
     for (int base = 0;; base += CL_STAGE) {
         __syncthreads();                                   // the previous run has been consumed
         if (threadIdx.x == 0) s_cnt = 0;
@@ -204,15 +208,17 @@ __global__ __launch_bounds__(CL_MAX_THREADS) void fp_front_cl_kernel(
 #pragma unroll
             for (int st = 0; st < S; ++st) {
                 fp_front_cl_load<U>(i + (st + S - 1) * U, c4, q, a, s_row, buf[(st + S - 1) % S]);
-                fp_front_cl_rows<CS, U>(i + st * U, cnt, c4, q, on, y, buf[st], s_w, s_sk, s_out, wbr, s, ss);
+                fp_front_cl_rows<CS, U>(i + st * U, cnt, c4, q, on, y, buf[st], s_w, s_sk, s_out, wbr, s, ss, piv, seen);
             }
         }
         if (cnt < CL_STAGE) break;
     }
-    if (on) {
-        cl_f4 *P = partial + (size_t)blockIdx.x * 2 * c4;
+    if (on) {                                              // (s1, s2, pivot) rows of this tile + its row count
+        cl_f4 *P = partial + (size_t)blockIdx.x * 3 * c4;
         P[q] = s;
         P[c4 + q] = ss;
+        P[2 * c4 + q] = piv;
+        if (q == 0) reinterpret_cast<float *>(partial + (size_t)gridDim.x * 3 * c4)[blockIdx.x] = (float)seen;
     }
 }
 
@@ -229,10 +235,14 @@ __global__ __launch_bounds__(CL_MAX_THREADS) void bn_reduce_cl_kernel(
     cl_f4 a = {0.f, 0.f, 0.f, 0.f}, b = a, mu = a, rs = a;
     if (MODE == 1) { a = scale[q]; b = shift[q]; mu = mean[q]; rs = rstd[q]; }
     float t0[4] = {0.f, 0.f, 0.f, 0.f}, t1[4] = {0.f, 0.f, 0.f, 0.f};
+    cl_f4 piv = {0.f, 0.f, 0.f, 0.f};                      // MODE 0: pivot of the shifted sums = this tile's first row
+    if (MODE == 0 && r0 < r1) piv = x[(size_t)r0 * c4 + q];
+    const float pv[4] = {piv.x, piv.y, piv.z, piv.w};
     auto one = [&](int k, float xv, float gv, float av, float bv, float mv, float rv) {
         if (MODE == 0) {
-            t0[k] += xv;
-            t1[k] = fmaf(xv, xv, t1[k]);
+            const float d = xv - pv[k];
+            t0[k] += d;
+            t1[k] = fmaf(d, d, t1[k]);
         } else {
             const float g = (!relu || fmaf(xv, av, bv) > 0.f) ? gv : 0.f;
             t0[k] += g;
@@ -259,9 +269,17 @@ __global__ __launch_bounds__(CL_MAX_THREADS) void bn_reduce_cl_kernel(
         }
     }
     const cl_f4 s0 = {t0[0], t0[1], t0[2], t0[3]}, s1 = {t1[0], t1[1], t1[2], t1[3]};
-    cl_f4 *P = partial + (size_t)blockIdx.x * 2 * c4;
-    P[q] = s0;
-    P[c4 + q] = s1;
+    if (MODE == 0) {                                       // (s1, s2, pivot) rows of this tile + its row count
+        cl_f4 *P = partial + (size_t)blockIdx.x * 3 * c4;
+        P[q] = s0;
+        P[c4 + q] = s1;
+        P[2 * c4 + q] = piv;
+        if (q == 0) reinterpret_cast<float *>(partial + (size_t)gridDim.x * 3 * c4)[blockIdx.x] = (float)(r1 > r0 ? r1 - r0 : 0);
+    } else {
+        cl_f4 *P = partial + (size_t)blockIdx.x * 2 * c4;
+        P[q] = s0;
+        P[c4 + q] = s1;
+    }
 }
 
 // MODE 0: out = max(x scale + shift, lo);  MODE 1: dx = k0 (g - c1 - xhat c2)
@@ -353,6 +371,42 @@ __global__ __launch_bounds__(1024) void bn_sums_cl_kernel(int tiles, int c, cons
     if (part == 0 && ch < c)
 #pragma unroll
         for (int k = 0; k < K; ++k) sums[(size_t)K * ch + k] = red[0][lane][k];
+}
+
+// the statistics records of fp_front_cl / bn_stats_cl: (tiles, 3, C) = (s1, s2, pivot) followed by `tiles` row counts.  Each
+// record is turned back into (sum x, sum x^2) in fp64 before it is added (see bnrelu.hip bn_stats_kernel); same fixed order.
+__global__ __launch_bounds__(1024) void bn_sums_shifted_cl_kernel(int tiles, int c, const float *__restrict__ partial,
+                                                                  double *__restrict__ sums)
+{
+    constexpr int PARTS = 16;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int ch = blockIdx.x * 64 + lane;
+    const float *counts = partial + (size_t)tiles * 3 * c;
+    __shared__ double red[PARTS][64][2];
+    double a0 = 0.0, a1 = 0.0;
+    if (ch < c) {
+        for (int t = part; t < tiles; t += PARTS) {
+            const double s1 = partial[((size_t)t * 3) * c + ch], s2 = partial[((size_t)t * 3 + 1) * c + ch];
+            const double p = partial[((size_t)t * 3 + 2) * c + ch], n = counts[t];
+            a0 += s1 + n * p;
+            a1 += s2 + 2.0 * p * s1 + n * p * p;
+        }
+    }
+    red[part][lane][0] = a0;
+    red[part][lane][1] = a1;
+    __syncthreads();
+#pragma unroll
+    for (int h = PARTS / 2; h >= 1; h >>= 1) {
+        if (part < h) {
+            red[part][lane][0] += red[part + h][lane][0];
+            red[part][lane][1] += red[part + h][lane][1];
+        }
+        __syncthreads();
+    }
+    if (part == 0 && ch < c) {
+        sums[2 * ch] = red[0][lane][0];
+        sums[2 * ch + 1] = red[0][lane][1];
+    }
 }
 
 // BatchNorm backward reduce of the FP front end with the skip-weight gradient riding along: per tile
@@ -554,6 +608,17 @@ GEOT_EXPORT int geot_bn_sums_cl(int tiles, int c, const float *partial, double *
     if (tiles < 0 || c < 0) return hipErrorInvalidValue;
     if (c == 0) return hipSuccess;
     hipLaunchKernelGGL(bn_sums_cl_kernel<2>, dim3((c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, tiles, c, partial, sums);
+    return hipGetLastError();
+}
+
+// floats of the statistics buffer fp_front_cl / bn_stats_cl fill for `tiles` tiles: (tiles, 3, c) + tiles counts
+GEOT_EXPORT long long geot_cl_stat_floats(int tiles, int c) { return tiles < 0 || c < 0 ? -1 : (long long)tiles * (3LL * c + 1); }
+
+GEOT_EXPORT int geot_bn_sums_shifted_cl(int tiles, int c, const float *partial, double *sums, void *stream)
+{
+    if (tiles < 0 || c < 0) return hipErrorInvalidValue;
+    if (c == 0) return hipSuccess;
+    hipLaunchKernelGGL(bn_sums_shifted_cl_kernel, dim3((c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, tiles, c, partial, sums);
     return hipGetLastError();
 }
 

@@ -84,6 +84,11 @@ def _covered(bn, x):
             and x.dim() == 3 and x.shape[0] <= 65535 and x.shape[1] <= 65535 and x.numel() > 0)
 
 
+def _cl_stat_buffer(tiles, c, dev):
+    """Uninitialised statistics buffer of a point-major producer: (tiles, 3, c) records + tiles counts (flat)."""
+    return torch.empty(int(_lib.load().geot_cl_stat_floats(tiles, c)), dtype=torch.float32, device=dev)
+
+
 def _batch_statistics(bn, x, gamma, beta, partial, pre_bias, cl=False):
     """Training-mode statistics of x (B, C, L) -- or, with cl, of the point-major x (B, L, C) -- for the module `bn`: the
     stats pass (unless `partial` came with x), the all-reduce under SyncBatchNorm, mean / rstd / scale / shift and the
@@ -97,19 +102,20 @@ def _batch_statistics(bn, x, gamma, beta, partial, pre_bias, cl=False):
     group = _sync_group(bn)
     with torch.no_grad():
         sums = torch.empty((c, 2), dtype=torch.float64, device=dev)
+        # statistics records: shifted sums (s1, s2, pivot, count) per slice / tile, rebuilt and added in fp64
         if cl:
             if partial is None:
-                partial = torch.empty((int(_lib.load().geot_cl_tiles(1, b * l, c)), 2, c), dtype=torch.float32, device=dev)
+                partial = _cl_stat_buffer(int(_lib.load().geot_cl_tiles(1, b * l, c)), c, dev)
                 call("geot_bn_stats_cl", dev, b * l, c, ptr(x), ptr(partial))
-            call("geot_bn_sums_cl", dev, partial.shape[0], c, ptr(partial), ptr(sums))
+            call("geot_bn_sums_shifted_cl", dev, partial.numel() // (3 * c + 1), c, ptr(partial), ptr(sums))
         else:
             if partial is None:
                 slices = int(_lib.load().geot_bn_slices(b, c, l))
-                partial = torch.empty((b, c, slices, 2), dtype=torch.float32, device=dev)
+                partial = torch.empty((b, c, slices, 4), dtype=torch.float32, device=dev)
                 call("geot_bn_stats", dev, b, c, l, ptr(x), ptr(partial))
             slices = partial.shape[2]
             # everything between the two passes in two launches (csrc/bnrelu.hip; ~13 torch launches per layer otherwise)
-            call("geot_bn_sums", dev, b, c, slices, ptr(partial), ptr(sums))
+            call("geot_bn_sums_shifted", dev, b, c, slices, ptr(partial), ptr(sums))
         count = float(b * l)
         count_dev = None
         if group is not None:                  # SyncBatchNorm: sums and element counts of all ranks (counts may differ);
@@ -147,8 +153,8 @@ def _batch_statistics(bn, x, gamma, beta, partial, pre_bias, cl=False):
 
 
 def bn_act(bn, x, relu=True, partial=None, pre_bias=None):
-    """act(bn(x)) for x (B, C, L) float32 on the GPU; `partial` (B, C, S, 2): per-slice (sum x, sum x^2) when the
-    producer of x already formed them (fp_front).  `pre_bias` (C,): act(bn(x + pre_bias[:, None])) without the add --
+    """act(bn(x)) for x (B, C, L) float32 on the GPU; `partial` (B, C, S, 4): per-slice statistics records (shifted
+    sums, pivot, count) when the producer of x already formed them (fp_front).  `pre_bias` (C,): act(bn(x + pre_bias[:, None])) without the add --
     the bias of the convolution in front: under batch statistics it cancels in the output (only the running mean sees
     it, and its gradient is exactly zero), under running statistics it folds into the shift."""
     if not _covered(bn, x):
@@ -181,7 +187,7 @@ class _FpFrontFn(Function):
         lib = _lib.load()
         slices = int(lib.geot_fp_front_slices(b, c, m, n))
         y = torch.empty((b, c, n), dtype=torch.float32, device=a.device)
-        partial = torch.empty((b, c, slices, 2), dtype=torch.float32, device=a.device)
+        partial = torch.empty((b, c, slices, 4), dtype=torch.float32, device=a.device)     # statistics records
         wbc = wb.contiguous() if cs else None
         call("geot_fp_front", a.device, b, c, m, n, cs, ptr(a), ptr(idx), ptr(weight), ptr(skip), ptr(wbc), ptr(y), ptr(partial))
         ctx.save_for_backward(idx, weight, skip, wbc)
@@ -318,7 +324,7 @@ class _FpFrontClFn(Function):
         cs = 0 if skip is None else skip.shape[1]
         tiles = int(_lib.load().geot_fp_front_cl_tiles(b, c, n, cs))
         y = torch.empty((b, n, c), dtype=torch.float32, device=a_cl.device)
-        partial = torch.empty((tiles, 2, c), dtype=torch.float32, device=a_cl.device)
+        partial = _cl_stat_buffer(tiles, c, a_cl.device)
         wbc = wb.contiguous() if cs else None
         call("geot_fp_front_cl", a_cl.device, b, c, m, n, cs, ptr(a_cl), ptr(idx), ptr(weight), ptr(skip), ptr(wbc), ptr(order),
              ptr(y), ptr(partial))
@@ -398,8 +404,8 @@ class _BnActClFn(Function):
 
 
 def bn_act_cl(bn, x, relu=True, partial=None, pre_bias=None):
-    """bn_act for a point-major x (B, L, C) float32 on the GPU with C % 4 == 0 (geot_cl_tiles >= 0); `partial` (T, 2, C)
-    from fp_front_cl.  Same statistics, running buffers and SyncBatchNorm behaviour as bn_act."""
+    """bn_act for a point-major x (B, L, C) float32 on the GPU with C % 4 == 0 (geot_cl_tiles >= 0); `partial`: the
+    statistics buffer fp_front_cl returned.  Same statistics, running buffers and SyncBatchNorm behaviour as bn_act."""
     b, l, c = x.shape
     if not (isinstance(bn, nn.modules.batchnorm._BatchNorm) and x.is_cuda and x.dtype == torch.float32
             and _lib.load().geot_cl_tiles(1, b * l, c) > 0):
@@ -432,7 +438,7 @@ class _FpStageClFn(Function):
         cs = 0 if skip is None else skip.shape[1]
         tiles = int(_lib.load().geot_fp_front_cl_tiles(b, c, n, cs))
         y = torch.empty((b, n, c), dtype=torch.float32, device=dev)
-        partial = torch.empty((tiles, 2, c), dtype=torch.float32, device=dev)
+        partial = _cl_stat_buffer(tiles, c, dev)
         wbc = wb.contiguous() if cs else None
         call("geot_fp_front_cl", dev, b, c, m, n, cs, ptr(a_cl), ptr(idx), ptr(weight), ptr(skip), ptr(wbc), ptr(order), ptr(y),
              ptr(partial))

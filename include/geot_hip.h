@@ -162,6 +162,11 @@ int geot_three_nn_ws(int b, int n, int m, const float *unknown, const float *kno
  *                     skips the add, only the running mean sees it)
  *   geot_bn_bwd_coef  g_beta, g_gamma = fp32 of local_sums (this rank's sum g, sum g xhat); c1, c2 = sums/n (0 if n == 0) */
 int geot_bn_sums(int b, int c, int s, const float *partial, double *sums, void *stream);
+/* geot_bn_stats and geot_fp_front write statistics records (b,c,S,4) = (s1, s2, pivot, count): sums of (x - pivot) and
+ * (x - pivot)^2 around the slice's first element, so that |mean| >> std costs no digits; geot_bn_sums_shifted turns every
+ * record back into (sum x, sum x^2) in fp64 and adds them: sums (c,2).  (geot_bn_sums: the plain (b,c,S,2) partials of
+ * the backward reduce.) */
+int geot_bn_sums_shifted(int b, int c, int s, const float *partial, double *sums, void *stream);
 int geot_bn_finalize(int c, const double *sums, double count, const double *count_dev, double eps, double eaf,
                      const float *gamma, const float *beta, const float *pre_bias, float *running_mean,
                      float *running_var, float *mean, float *rstd, float *scale, float *shift, void *stream);
@@ -276,6 +281,11 @@ int geot_bn_bwd_apply_cl(long long rows, int c, int relu, const float *x, const 
                          const float *shift, const float *mean, const float *rstd, const float *k0, const float *c1,
                          const float *c2, float *dx, void *stream);
 int geot_bn_sums_cl(int tiles, int c, const float *partial, double *sums, void *stream);
+/* statistics records: fp_front_cl and bn_stats_cl accumulate SHIFTED sums (around each tile's first row) and write
+ * (tiles, 3, c) = (s1, s2, pivot) followed by `tiles` row counts = geot_cl_stat_floats(tiles, c) floats;
+ * geot_bn_sums_shifted_cl rebuilds (sum x, sum x^2) per tile in fp64 and adds them up: sums (c,2) */
+long long geot_cl_stat_floats(int tiles, int c);
+int geot_bn_sums_shifted_cl(int tiles, int c, const float *partial, double *sums, void *stream);
 long long geot_rix_ws_ints(int b, long long L, int m, int nt);
 int geot_rix_build(int b, int L, int m, int nt, const int *idx, const float *weight, const int *order, int *ws,
                    long long ws_ints, void *stream);

@@ -72,19 +72,31 @@ def test_fp_module_factored_and_composed_against_fp64(c_known, c_skip, widths):
     from geot_amd.openpoints.models.backbone.transformer import _fp_factored
     pos = _cloud(2, 5000, 3)
     known = pos[:, ::5].contiguous()
-    torch.manual_seed(1)
-    fp = PointnetFPModule(mlp=[c_known + c_skip] + widths).to(DEV).train()
-    kf = torch.randn(2, c_known, known.shape[1], device=DEV)
-    sk = torch.randn(2, c_skip, 5000, device=DEV) if c_skip else None
-    up = torch.randn(2, widths[-1], 5000, device=DEV)
-    # fp64 referee on the CPU: the reference's op chain with the GPU's (exact) neighbour ids
     d2, idx = pu._ext.three_nn(pos, known)
-    fp64 = copy.deepcopy(fp).double().cpu()
-    kf64 = kf.double().cpu().requires_grad_(True)
-    x64 = _interp64(kf64, idx.cpu(), _weights64(d2))
-    if sk is not None:
-        x64 = torch.cat([x64, sk.double().cpu()], 1)
-    y64 = fp64.mlp(x64.unsqueeze(-1)).squeeze(-1)
+    for seed in range(1, 60):
+        # a ReLU input within fp32 rounding of zero flips its mask between any two fp32 evaluations and moves a whole
+        # gradient element: the referee (fp64) looks for such kinks and the test takes the first seed without one
+        torch.manual_seed(seed)
+        fp = PointnetFPModule(mlp=[c_known + c_skip] + widths).to(DEV).train()
+        kf = torch.randn(2, c_known, known.shape[1], device=DEV)
+        sk = torch.randn(2, c_skip, 5000, device=DEV) if c_skip else None
+        up = torch.randn(2, widths[-1], 5000, device=DEV)
+        # fp64 referee on the CPU: the reference's op chain with the GPU's (exact) neighbour ids
+        fp64 = copy.deepcopy(fp).double().cpu()
+        kf64 = kf.double().cpu().requires_grad_(True)
+        x64 = _interp64(kf64, idx.cpu(), _weights64(d2))
+        if sk is not None:
+            x64 = torch.cat([x64, sk.double().cpu()], 1)
+        nearest = []
+        hooks = [mod.register_forward_hook(lambda _m, _i, out: nearest.append(float(out.detach().abs().min())))
+                 for mod in fp64.modules() if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm)]
+        y64 = fp64.mlp(x64.unsqueeze(-1)).squeeze(-1)
+        for h in hooks:
+            h.remove()
+        if min(nearest) > 1e-6:                  # fp32 evaluations of these values differ by ~2e-7
+            break
+    else:
+        pytest.skip("no kink-free seed")
     (y64 * up.double().cpu()).sum().backward()
     w64 = dict(fp64.named_parameters())
     errs = {}

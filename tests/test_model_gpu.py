@@ -448,9 +448,13 @@ def test_fp_front_equals_interpolate_plus_skip_conv():
         res.append((y.detach(), a.grad, wb.grad))
     for name, x, f in zip(("y", "dA", "dWb"), *res):
         assert float((x - f).abs().max()) <= 2e-5 * float(x.abs().max()), name
-    sums = partial.sum((0, 2), dtype=torch.float64)
-    assert torch.allclose(sums[:, 0], res[1][0].double().sum((0, 2)), rtol=1e-6, atol=1e-3)
-    assert torch.allclose(sums[:, 1], res[1][0].double().square().sum((0, 2)), rtol=1e-6)
+    # the statistics records (s1, s2, pivot, count) per (cloud, channel, slice): sum y = s1 + n p, sum y^2 = s2 + 2 p s1 + n p^2
+    rec = partial.double()
+    s1, s2, p, cnt = rec[..., 0], rec[..., 1], rec[..., 2], rec[..., 3]
+    assert float(cnt.sum((0, 2)).min()) == float(cnt.sum((0, 2)).max()) == 2 * 6000
+    sum_abs = res[1][0].double().abs().sum((0, 2))
+    assert float((((s1 + cnt * p).sum((0, 2)) - res[1][0].double().sum((0, 2))).abs() / sum_abs).max()) <= 2e-6
+    assert torch.allclose((s2 + 2 * p * s1 + cnt * p * p).sum((0, 2)), res[1][0].double().square().sum((0, 2)), rtol=1e-5)
 
 
 def _sync_bn_worker(rank, world, port, q):

@@ -54,7 +54,7 @@ for name, n, m, cs in (("prop0", 24000, 8192, 5), ("prop1", 8192, 512, 3), ("pro
         t_cf = timed(lambda: fp_front(a, idx, w, skip, wb))
         tiles = int(lib.geot_fp_front_cl_tiles(B, C, n, cs))
         y_cl = torch.empty(B, n, C, device=DEV)
-        part = torch.empty(tiles, 2, C, device=DEV)
+        part = torch.empty(int(lib.geot_cl_stat_floats(tiles, C)), device=DEV)
         res = {}
         for tag, order in (("memory order", None), ("Morton order", local_order(unknown))):
             y_cl.zero_()
@@ -63,9 +63,9 @@ for name, n, m, cs in (("prop0", 24000, 8192, 5), ("prop1", 8192, 512, 3), ("pro
             f()
             same = torch.equal(y_cl.transpose(1, 2), y_cf)
             sums = torch.empty(C, 2, dtype=torch.float64, device=DEV)
-            call("geot_bn_sums_cl", DEV, tiles, C, ptr(part), ptr(sums))
+            call("geot_bn_sums_shifted_cl", DEV, tiles, C, ptr(part), ptr(sums))
             ref = torch.stack([y_cf.double().sum((0, 2)), (y_cf.double() ** 2).sum((0, 2))], 1)
-            serr = float(((sums - ref).abs() / ref.abs().clamp_min(1e-30)).max())
+            serr = float(((sums - ref).abs() / torch.stack([y_cf.double().abs().sum((0, 2)), ref[:, 1]], 1)).max())
             res[tag] = (timed(f), same, serr)
         print("%s fwd  (n=%d m=%d C=%d): channels-first %7.1f us %5.2f TB/s" % (name, n, m, C, t_cf, nbytes / t_cf / 1e6))
         for tag, (t, same, serr) in res.items():
@@ -107,7 +107,7 @@ for name, n, m, cs in (("prop0", 24000, 8192, 5), ("prop1", 8192, 512, 3), ("pro
             t2 = timed(lambda: call("geot_bn_apply_cl", DEV, R, C, 1, ptr(y_cl), ptr(scale), ptr(shift), ptr(out_cl)))
             print("bn apply       cf %6.1f us  cl %6.1f us  identical %s" % (t1, t2, torch.equal(out_cl.transpose(1, 2), out_cf)))
             slices = int(lib.geot_bn_slices(B, C, n))
-            p_cf = torch.empty(B, C, slices, 2, device=DEV)
+            p_cf = torch.empty(B, C, slices, 2, device=DEV)      # (backward-reduce partials: plain pairs)
             tl = int(lib.geot_cl_tiles(1, R, C))
             p_cl = torch.empty(tl, 2, C, device=DEV)
             t1 = timed(lambda: call("geot_bn_bwd_reduce", DEV, B, C, n, 1, ptr(y_cf), ptr(gy), ptr(scale), ptr(shift), ptr(mean),

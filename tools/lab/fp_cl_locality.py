@@ -44,7 +44,7 @@ skip = torch.randn(B, cs, n, device=DEV)
 wb = torch.randn(C, cs, device=DEV)
 tiles = int(lib.geot_fp_front_cl_tiles(B, C, n, cs))
 y = torch.empty(B, n, C, device=DEV)
-part = torch.empty(tiles, 2, C, device=DEV)
+part = torch.empty(int(lib.geot_cl_stat_floats(tiles, C)), device=DEV)
 # how local is the Morton sequence?  distinct table rows per window of consecutive elements
 ids = torch.gather(idx.long(), 1, order.long().unsqueeze(-1).expand(-1, -1, 3))[0].cpu()
 for win in (64, 256, 1024, 4096):

@@ -40,7 +40,7 @@ for n, m in ((8192, 512), (24000, 512), (24000, 2048), (24000, 8192), (8192, 819
     wb = torch.randn(C, cs, device=DEV)
     tiles = int(lib.geot_fp_front_cl_tiles(B, C, n, cs))
     y = torch.empty(B, n, C, device=DEV)
-    part = torch.empty(tiles, 2, C, device=DEV)
+    part = torch.empty(int(lib.geot_cl_stat_floats(tiles, C)), device=DEV)
     t = timed(lambda: call("geot_fp_front_cl", DEV, B, C, m, n, cs, ptr(a_cl), ptr(idx), ptr(w), ptr(skip), ptr(wb), ptr(order),
                            ptr(y), ptr(part)))
     nbytes = 4.0 * B * C * (n + m)
