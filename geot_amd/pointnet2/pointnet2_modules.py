@@ -1,6 +1,7 @@
 """Set-abstraction / feature-propagation modules over the HIP ops -- the callers of the
 hot path that BASELINE configs[1] measures (pointnet2/pointnet2_modules.py:
-PointnetSAModuleVotes :273-380, PointnetSAModule(MSG) :75-158, PointnetFPModule :582-642).
+PointnetSAModuleVotes :273-380, PointnetSAModule(MSG) :75-158, PointnetSAModuleMSGVotes :500-579, PointnetFPModule :582-642,
+PointnetLFPModuleMSG :644-722).
 
 Same constructor arguments, forward signatures and return tuples as the reference.
 In eval mode, with max pooling and a plain conv->BN->ReLU stack, the SA module runs the
@@ -162,6 +163,58 @@ class PointnetSAModuleMSG(nn.Module):
             nf = mlp(grouper(xyz, new_xyz, features))
             outs.append(F.max_pool2d(nf, kernel_size=[1, nf.size(3)]).squeeze(-1))
         return new_xyz, torch.cat(outs, dim=1)
+
+
+class PointnetSAModuleMSGVotes(PointnetSAModuleMSG):
+    """Multi-scale grouping SA that takes / returns the sampled indices (pointnet2_modules.py:500-579): `inds` (B, npoint)
+    int32 selects the centres when given (furthest point sampling otherwise) and comes back as the third result, so a
+    caller can look up per-centre targets (votes).  Parameters / state_dict as PointnetSAModuleMSG."""
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
+        """-> (new_xyz (B,npoint,3), new_features (B, sum_k mlps[k][-1], npoint), inds (B,npoint))."""
+        xyz_flipped = xyz.transpose(1, 2).contiguous()
+        if inds is None:
+            inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+        new_xyz = pointnet2_utils.gather_operation(xyz_flipped, inds).transpose(1, 2).contiguous() \
+            if self.npoint is not None else None
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            nf = mlp(grouper(xyz, new_xyz, features))                              # (B, mlp[-1], npoint, nsample)
+            outs.append(F.max_pool2d(nf, kernel_size=[1, nf.size(3)]).squeeze(-1))
+        return new_xyz, torch.cat(outs, dim=1), inds
+
+
+class PointnetLFPModuleMSG(nn.Module):
+    """Learnable feature propagation (pointnet2_modules.py:644-722): for every scale k, the features of the N1 source
+    points are ball-grouped around the N2 target points (QueryAndGroup(radius_k, nsample_k)), run through mlps[k], max-pooled
+    over the group, concatenated with the targets' own features and passed through the ONE shared `post_mlp`; the
+    per-scale results are concatenated.  -> (B, n_scales * post_mlp[-1], N2)."""
+
+    def __init__(self, *, mlps: List[List[int]], radii: List[float], nsamples: List[int], post_mlp: List[int],
+                 bn: bool = True, use_xyz: bool = True, sample_uniformly: bool = False):
+        super().__init__()
+        assert len(mlps) == len(nsamples) == len(radii)
+        self.post_mlp = pt_utils.SharedMLP(list(post_mlp), bn=bn)
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz,
+                                                               sample_uniformly=sample_uniformly))
+            spec = list(spec)
+            if use_xyz:
+                spec[0] += 3
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
+
+    def forward(self, xyz2: torch.Tensor, xyz1: torch.Tensor, features2: torch.Tensor, features1: torch.Tensor):
+        """xyz2 (B,N2,3) targets, xyz1 (B,N1,3) sources, features2 (B,C2,N2) or None, features1 (B,C1,N1)."""
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            nf = mlp(grouper(xyz1, xyz2, features1))                               # (B, mlp[-1], N2, nsample)
+            nf = F.max_pool2d(nf, kernel_size=[1, nf.size(3)]).squeeze(-1)         # (B, mlp[-1], N2)
+            if features2 is not None:
+                nf = torch.cat([nf, features2], dim=1)
+            outs.append(self.post_mlp(nf.unsqueeze(-1)))
+        return torch.cat(outs, dim=1).squeeze(-1)
 
 
 class PointnetSAModule(PointnetSAModuleMSG):

@@ -162,3 +162,50 @@ def test_sa_module_factored_training_equals_composed(nsample, mlp_spec, c_feat, 
         assert err < 2e-3, (n, err)
     for n in a[3]:
         assert torch.allclose(a[3][n], b[3][n], rtol=1e-4, atol=1e-6), n
+
+
+@pytest.mark.gpu
+def test_msg_votes_and_learnable_fp_modules():
+    """PointnetSAModuleMSGVotes (pointnet2_modules.py:500-579) and PointnetLFPModuleMSG (:644-722): shapes, the index
+    contract, state_dict names, and the values against a composition written out with torch ops on the HIP ball query."""
+    from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleMSG, PointnetSAModuleMSGVotes, PointnetLFPModuleMSG
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    torch.manual_seed(2)
+    xyz = torch.from_numpy(make_batch(2, 1024, start_index=4)[0]).cuda()
+    feats = torch.randn(2, 6, 1024, device="cuda:0", requires_grad=True)
+    votes = PointnetSAModuleMSGVotes(npoint=64, radii=[0.1, 0.3], nsamples=[8, 16], mlps=[[6, 16], [6, 24]]).cuda().eval()
+    plain = PointnetSAModuleMSG(npoint=64, radii=[0.1, 0.3], nsamples=[8, 16], mlps=[[6, 16], [6, 24]]).cuda().eval()
+    assert list(votes.state_dict()) == list(plain.state_dict())
+    plain.load_state_dict(votes.state_dict())
+    new_xyz, nf, inds = votes(xyz, feats)
+    assert nf.shape == (2, 40, 64) and inds.shape == (2, 64) and inds.dtype == torch.int32
+    assert torch.equal(inds, pu.furthest_point_sample(xyz, 64))
+    assert torch.equal(new_xyz, torch.gather(xyz, 1, inds.long().unsqueeze(-1).expand(-1, -1, 3)))
+    px, pf = plain(xyz, feats)
+    assert torch.equal(px, new_xyz) and torch.equal(pf, nf)
+    # given indices are used as they are, and come back
+    mine = torch.stack([torch.randperm(1024, device="cuda:0")[:64] for _ in range(2)]).int()
+    x2, f2, i2 = votes(xyz, feats, mine)
+    assert torch.equal(i2, mine) and torch.equal(x2, torch.gather(xyz, 1, mine.long().unsqueeze(-1).expand(-1, -1, 3)))
+    # learnable feature propagation: 1024 sources -> 256 targets, two scales, one shared post_mlp
+    tgt = xyz[:, :256].contiguous()
+    f_tgt = torch.randn(2, 5, 256, device="cuda:0")
+    lfp = PointnetLFPModuleMSG(mlps=[[6, 16], [6, 16]], radii=[0.1, 0.25], nsamples=[8, 12], post_mlp=[16 + 5, 32]).cuda().train()
+    out = lfp(tgt, xyz, f_tgt, feats)
+    assert out.shape == (2, 64, 256)
+    out.sum().backward()
+    assert torch.isfinite(feats.grad).all() and float(feats.grad.abs().sum()) > 0
+    assert sorted({k.split(".")[0] for k in lfp.state_dict()}) == ["mlps", "post_mlp"]
+    lfp.eval()
+    with torch.no_grad():
+        got = lfp(tgt, xyz, f_tgt, feats)
+        want = []
+        for radius, ns, mlp in zip((0.1, 0.25), (8, 12), lfp.mlps):
+            idx = pu.ball_query(radius, ns, xyz, tgt).long()                                         # (2, 256, ns)
+            g_xyz = torch.gather(xyz.transpose(1, 2).unsqueeze(2).expand(-1, -1, 256, -1), 3, idx.unsqueeze(1).expand(-1, 3, -1, -1))
+            g_xyz = g_xyz - tgt.transpose(1, 2).unsqueeze(-1)
+            g_f = torch.gather(feats.unsqueeze(2).expand(-1, -1, 256, -1), 3, idx.unsqueeze(1).expand(-1, 6, -1, -1))
+            nf_k = mlp(torch.cat([g_xyz, g_f], 1)).max(-1)[0]
+            want.append(lfp.post_mlp(torch.cat([nf_k, f_tgt], 1).unsqueeze(-1)))
+        want = torch.cat(want, 1).squeeze(-1)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
