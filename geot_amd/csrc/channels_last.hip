@@ -325,52 +325,37 @@ __global__ __launch_bounds__(CL_MAX_THREADS) void bn_apply_cl_kernel(
     }
 }
 
-// (tiles, K, C) float -> (C, K) double, K <= CL_MAX_SUMS.  64 channels per workgroup (lanes = consecutive channels:
-// coalesced rows), the tiles dealt to its 16 waves; every wave sums its tiles in ascending order with 4 tiles in flight,
-// then the 16 wave sums are added in a fixed tree: the same result on every run.
+// (tiles, K, C) float -> (C, K) double, K <= CL_MAX_SUMS.  One workgroup per (64 channels, one of the K sums): lanes =
+// consecutive channels (coalesced rows), the tiles dealt to its 16 waves; every wave sums its tiles in ascending order
+// with 4 tiles in flight, then the 16 wave sums are added in a fixed tree: the same result on every run.
 constexpr int CL_MAX_SUMS = 2 + 2 * CL_MAX_SKIP;
-template <int K>
-__global__ __launch_bounds__(1024) void bn_sums_cl_kernel(int tiles, int c, const float *__restrict__ partial,
+__global__ __launch_bounds__(1024) void bn_sums_cl_kernel(int tiles, int c, int K, const float *__restrict__ partial,
                                                           double *__restrict__ sums)
 {
-    constexpr int PARTS = 16;
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    constexpr int PARTS = 16, U = 4;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, k = blockIdx.y;
     const int ch = blockIdx.x * 64 + lane;
-    __shared__ double red[PARTS][64][K];
-    double acc[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) acc[k] = 0.0;
+    __shared__ double red[PARTS][64];
+    double acc = 0.0;
     if (ch < c) {
-        constexpr int U = K <= 2 ? 4 : 2;
         int t = part;
         for (; t + (U - 1) * PARTS < tiles; t += U * PARTS) {
-            float v[U][K];
+            float v[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < U; ++u) v[u] = partial[((size_t)(t + u * PARTS) * K + k) * c + ch];
 #pragma unroll
-                for (int k = 0; k < K; ++k) v[u][k] = partial[((size_t)(t + u * PARTS) * K + k) * c + ch];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int k = 0; k < K; ++k) acc[k] += (double)v[u][k];
+            for (int u = 0; u < U; ++u) acc += (double)v[u];
         }
-        for (; t < tiles; t += PARTS)
-#pragma unroll
-            for (int k = 0; k < K; ++k) acc[k] += (double)partial[((size_t)t * K + k) * c + ch];
+        for (; t < tiles; t += PARTS) acc += (double)partial[((size_t)t * K + k) * c + ch];
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) red[part][lane][k] = acc[k];
+    red[part][lane] = acc;
     __syncthreads();
 #pragma unroll
     for (int h = PARTS / 2; h >= 1; h >>= 1) {
-        if (part < h)
-#pragma unroll
-            for (int k = 0; k < K; ++k) red[part][lane][k] += red[part + h][lane][k];
+        if (part < h) red[part][lane] += red[part + h][lane];
         __syncthreads();
     }
-    if (part == 0 && ch < c)
-#pragma unroll
-        for (int k = 0; k < K; ++k) sums[(size_t)K * ch + k] = red[0][lane][k];
+    if (part == 0 && ch < c) sums[(size_t)K * ch + k] = red[0][lane];
 }
 
 // the statistics records of fp_front_cl / bn_stats_cl: (tiles, 3, C) = (s1, s2, pivot) followed by `tiles` row counts.  Each
@@ -607,7 +592,7 @@ GEOT_EXPORT int geot_bn_sums_cl(int tiles, int c, const float *partial, double *
 {
     if (tiles < 0 || c < 0) return hipErrorInvalidValue;
     if (c == 0) return hipSuccess;
-    hipLaunchKernelGGL(bn_sums_cl_kernel<2>, dim3((c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, tiles, c, partial, sums);
+    hipLaunchKernelGGL(bn_sums_cl_kernel, dim3((c + 63) / 64, 2), dim3(1024), 0, (hipStream_t)stream, tiles, c, 2, partial, sums);
     return hipGetLastError();
 }
 
@@ -625,21 +610,9 @@ GEOT_EXPORT int geot_bn_sums_shifted_cl(int tiles, int c, const float *partial, 
 // partial (tiles, K, c) -> sums (c, K) fp64 for K = 2 + 2 cs (the reduce-with-skip pass below)
 GEOT_EXPORT int geot_bn_sums_k_cl(int tiles, int c, int k, const float *partial, double *sums, void *stream)
 {
-    if (tiles < 0 || c < 0 || k < 2 || k > CL_MAX_SUMS || (k & 1)) return hipErrorInvalidValue;
+    if (tiles < 0 || c < 0 || k < 1 || k > CL_MAX_SUMS) return hipErrorInvalidValue;
     if (c == 0) return hipSuccess;
-#define GEOT_SUMS(KV) hipLaunchKernelGGL(bn_sums_cl_kernel<KV>, dim3((c + 63) / 64), dim3(1024), 0, (hipStream_t)stream, tiles, c, partial, sums)
-    switch (k) {
-    case 2: GEOT_SUMS(2); break;
-    case 4: GEOT_SUMS(4); break;
-    case 6: GEOT_SUMS(6); break;
-    case 8: GEOT_SUMS(8); break;
-    case 10: GEOT_SUMS(10); break;
-    case 12: GEOT_SUMS(12); break;
-    case 14: GEOT_SUMS(14); break;
-    case 16: GEOT_SUMS(16); break;
-    default: GEOT_SUMS(18); break;
-    }
-#undef GEOT_SUMS
+    hipLaunchKernelGGL(bn_sums_cl_kernel, dim3((c + 63) / 64, k), dim3(1024), 0, (hipStream_t)stream, tiles, c, k, partial, sums);
     return hipGetLastError();
 }
 

@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_cl_kernel(int c4, int T,
 // Y = sum w (y - mean), W = sum w, A = -k0 rstd c2: three running sums per list, the constants applied once per target.
 // gy is never written or read (1.18 GB each way at 8 x 24000 x 1536) and the bn_bwd_apply pass disappears.
 #ifndef GEOT_GRB_LAB_U
-#define GEOT_GRB_LAB_U 3
+#define GEOT_GRB_LAB_U 4
 #endif
 constexpr int GRB_U = GEOT_GRB_LAB_U;    // pairs (2 row loads each) in flight per half of the software pipeline
 __global__ __launch_bounds__(1024) void gather_rows_csr_bn_cl_kernel(

@@ -1,9 +1,8 @@
 #!/bin/bash
-# lab: rows per group / stages of the forward's software pipeline
-for cfg in "2 2" "2 3" "1 4" "1 3" "4 2" "2 4"; do
-  set -- $cfg
-  GEOT_EXTRA_HIPCC_FLAGS="-DGEOT_CL_LAB_U=$1 -DGEOT_CL_LAB_STAGES=$2" python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
-  echo "== U $1 stages $2"
-  timeout -k 10 300 python tools/lab/fp_cl_scaling.py 2>&1 | grep -E "n=24000 m= 8192|n= 8192 m=  512"
+# lab: pairs in flight per pipeline half of the BatchNorm-fused gather (2 row loads per pair)
+for u in 2 3 4; do
+  GEOT_EXTRA_HIPCC_FLAGS="-DGEOT_GRB_LAB_U=$u" python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
+  echo "== GRB_U $u"
+  timeout -k 10 300 python tools/fp_cl_lab.py 2>&1 | grep "fused backward"
 done
 python -m geot_amd.build --force > /dev/null 2>&1
