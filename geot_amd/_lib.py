@@ -154,7 +154,7 @@ PLAIN = {
     "geot_rowdot_small_slices": ([_c_int] * 2, _c_int),
     "geot_colsum_ws_floats": ([_c_int] * 2, ctypes.c_longlong),
 }
-ABI_VERSION = 4     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
+ABI_VERSION = 5     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
 
 _lib = None
 

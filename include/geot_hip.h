@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEOT_ABI_VERSION 4
+#define GEOT_ABI_VERSION 5
 #define GEOT_NTM_MAX_C 32   /* largest class count of the geot_ntm_* entry points */
 
 /* ABI version / diagnostics. */
