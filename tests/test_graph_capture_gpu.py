@@ -212,3 +212,31 @@ def test_capture_lean_transformer_block_and_losses():
             dst.copy_(g)
         return (loss.detach(), feats.detach()) + tuple(grads)
     _check(fn, [x, pos], [torch.randn(2, 512, 384, device=DEV), torch.randn(2, 512, 384, device=DEV)])
+
+
+def test_capture_point_major_fp_stage():
+    """The point-major FP stage (csrc/channels_last.hip): Morton order + reverse index + fp_stage_cl forward and backward
+    (the BatchNorm backward folded into the row gather) in one capture, replayed on new coordinates and features."""
+    from geot_amd import fused_norm as fn
+    from geot_amd.pointnet2 import pointnet2_utils as pu
+    b, n, m, c, cs = 2, 3000, 700, 256, 5
+    pos, known = _cloud(b, n, 3), _cloud(b, n, 3)[:, :m].contiguous()
+    torch.manual_seed(0)
+    a = torch.randn(b, m, c, device=DEV)
+    skip = torch.randn(b, cs, n, device=DEV)
+    wb = torch.randn(c, cs, device=DEV)
+    up = torch.randn(b, n, c, device=DEV)
+    bn = torch.nn.BatchNorm1d(c).to(DEV).train()
+
+    def step():
+        d2, idx = pu._ext.three_nn(pos, known)
+        weight = pu._ext.fp_weights(d2)
+        rix = fn.ReverseIndex(idx, weight, m, fn.local_spatial_order(known))
+        a_req = a.detach().requires_grad_(True)
+        wb_req = wb.detach().requires_grad_(True)
+        z = fn.fp_stage_cl(bn, a_req, idx, weight, skip, wb_req, True, fn.local_spatial_order(pos), rix)
+        ga, gwb, ggamma = torch.autograd.grad((z * up).sum(), (a_req, wb_req, bn.weight))
+        return z.detach(), ga, gwb, ggamma
+
+    pos2 = _cloud(b, n, 40)
+    _check(step, [pos, known, a, skip], [pos2, pos2[:, :m].contiguous(), a.flip(1) * 0.5, skip.flip(2) + 0.1])
