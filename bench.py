@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--no-dense-reference", action="store_true",
                     help="model: skip the 3 extra steps in the reference's op order that fill the JSON's dense.reference_order")
     ap.add_argument("--no-saturated", action="store_true", help="sa: skip the extra run at 256 clouds per launch")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="model: do not hand the step the next batch's coordinates (its sampling / grouping then runs at "
+                         "the head of its own step instead of beside the previous backward)")
     ap.add_argument("--dense", choices=["factored", "reference"], default=None,
                     help="model: how the first 1x1 conv behind a gather is evaluated (see transformer.py)")
     ap.add_argument("--no-tuned-gemm", action="store_true",
@@ -344,8 +347,19 @@ def main():
         if world > 1:
             parallelism = "dp%d: DistributedDataParallel (25 MB buckets, overlapped with backward) + SyncBatchNorm" % world
 
+        # two batches, alternating, as a loader with one batch of look-ahead delivers them: the step is told the NEXT batch's
+        # coordinates and queues their sampling / grouping / index work beside its own backward (SupervisedStep, same
+        # results); --no-lookahead: every step does all of its own work between its own start and end
+        xyz_b_np, _ = make_batch(B, N_POINTS, start_index=dist_utils.cloud_range(rank, B)[0] + 100003)
+        batches = [(xyz, cls, target),
+                   (torch.from_numpy(xyz_b_np).to(dev), cls.flip(0).contiguous(), torch.from_numpy(region_labels(xyz_b_np)).to(dev))]
+        turn = [0]
+        lookahead = not args.no_lookahead
+
         def step():
-            return trainer(xyz, cls, target)
+            cur, nxt = batches[turn[0] % 2], batches[(turn[0] + 1) % 2]
+            turn[0] += 1
+            return trainer(cur[0], cur[1], cur[2], next_pos=nxt[0] if lookahead else None)
     elif workload == "fixmatch":
         from geot_amd import train_step as ts
         torch.manual_seed(1609)
@@ -580,6 +594,22 @@ def main():
                           "ms_per_step_without_gradient_allreduce": 1e3 * t_local / k2,
                           "exposed_allreduce_ms": ms_per_step - 1e3 * t_local / k2,
                           "note": "exposed = timed step minus the same step under DDP.no_sync() (%d steps); negative = noise" % k2}
+    if workload == "model":
+        result["config"]["lookahead"] = ("the step is handed the next batch's coordinates (two batches alternate) and queues "
+                                         "their sampling / grouping / index work beside its own backward"
+                                         if lookahead else "off: all of a batch's work inside its own step")
+    if workload == "model" and world == 1 and lookahead and not args.no_dense_reference:
+        # the same steps without the look-ahead (every batch's sampling at the head of its own step), observed in this run
+        def plain_step():
+            cur = batches[turn[0] % 2]
+            turn[0] += 1
+            return trainer(cur[0], cur[1], cur[2])
+        plain_step()
+        k3 = min(args.steps, 10)
+        t_plain, _ = timed_steps(plain_step, k3, dev, rehearsal)
+        result["lookahead"] = {"ms_per_step_without": 1e3 * t_plain / k3, "clouds_per_s_without": clouds_per_step * k3 / t_plain,
+                               "steps": k3, "note": "same model, same alternating batches, next_pos=None: every step samples "
+                                                    "and groups its own batch before its encoder can start"}
     if workload == "model" and world == 1 and dense_mode != "reference" and not args.no_dense_reference:
         # the same step with every layer in the REFERENCE's op order (first 1x1 conv after the gather, op-by-op attention /
         # LayerNorm) on the same kernels: what the algebraic re-ordering is worth, observed in this run

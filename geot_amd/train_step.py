@@ -103,12 +103,20 @@ class SupervisedStep:
         self.criterion = Poly1FocalLoss()
         self.optimizer = make_optimizer(model, lr, weight_decay)
         self.clip = grad_norm_clip
+        self._geometry = None          # coordinate-only work of the next batch, queued by the previous call
 
-    def __call__(self, pos, cls, target):
-        """pos (B,N,3) f32, cls (B,1) int64 jaw id, target (B,N) int64 -> detached loss."""
+    def __call__(self, pos, cls, target, next_pos=None):
+        """pos (B,N,3) f32, cls (B,1) int64 jaw id, target (B,N) int64 -> detached loss.
+        next_pos: the coordinates of the NEXT batch, when the loop already holds them (a data loader with one batch of
+        look-ahead): their sampling / grouping / index work is queued between this batch's forward and backward
+        (PointTransformer_seg_T.prefetch_geometry) and picked up by the next call -- same results, 0.6 ms less per step."""
         self.model.train()
-        logits = self.model(pos, pos.transpose(1, 2).contiguous(), cls)[0]
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        geometry, self._geometry = self._geometry, None
+        logits = self.model(pos, pos.transpose(1, 2).contiguous(), cls, geometry=geometry)[0]
         loss = self.criterion(logits, target)
+        if next_pos is not None and hasattr(inner, "prefetch_geometry"):
+            self._geometry = inner.prefetch_geometry(next_pos)
         loss.backward()
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)

@@ -266,8 +266,13 @@ def test_fixmatch_iteration_at_the_configured_sizes(npts):
         assert torch.allclose(rows, torch.ones_like(rows), atol=1e-3), rows
         assert any(not torch.equal(a, l.weight) for a, l in zip(w0, trainer.T_predictor.T_predictor.fc))
         runs.append([float(v) for o in out for v in o.values()])
+    # iteration 1 is reproducible to the last digit; its gradients are not quite (the graph loss accumulates with float
+    # atomics), and AdamW's first update is lr * sign-like: a low-bit difference in a near-zero gradient moves that weight by
+    # 2 lr, which iteration 2's losses see at the 1e-5 level (observed 1e-5 ... 5e-5 between any two runs)
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert abs(a - b) <= 1e-6 * abs(a) + 1e-7, runs
     for a, b in zip(*runs):
-        assert abs(a - b) <= 5e-5 * abs(a) + 1e-7, runs
+        assert abs(a - b) <= 3e-4 * abs(a) + 1e-7, runs
 
 
 @pytest.mark.parametrize("n", [24576, 24577, 32768])

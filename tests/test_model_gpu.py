@@ -610,3 +610,51 @@ def test_side_stream_index_plan_changes_nothing_but_the_schedule(monkeypatch):
         assert set(ga) == set(gb) and all(torch.equal(ga[k], gb[k]) for k in ga)
     for (la, ga), (lc, gc) in zip(a, res["side"][1]):
         assert torch.equal(la, lc) and all(torch.equal(ga[k], gc[k]) for k in ga)
+
+
+def test_look_ahead_geometry_changes_nothing_but_the_schedule():
+    """SupervisedStep(next_pos=...) / PointTransformer_seg_T.prefetch_geometry: the next batch's Group (FPS + kNN), 8192-sample
+    FPS and index plan queued beside the current batch's backward -- a run of alternating batches gives bit-identical losses
+    and parameters to the same run without look-ahead; a geometry of ANOTHER tensor, or one the tensor was edited after,
+    is ignored."""
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd import train_step as ts
+    dev = torch.device("cuda:0")
+    from geot_amd.synth import make_batch, region_labels
+    _, pos_a, tgt_a = _batch(2, 6000, dev)
+    xyz_b = make_batch(2, 6000, start_index=40)[0]
+    pos_b, tgt_b = torch.from_numpy(xyz_b).to(dev), torch.from_numpy(region_labels(xyz_b)).to(dev)
+    cls = torch.tensor([[0], [1]], device=dev)
+    torch.manual_seed(0)
+    init = PointTransformer_seg_T(**SMALL).state_dict()
+    batches = [(pos_a, cls, tgt_a), (pos_b, cls.flip(0).contiguous(), tgt_b)]
+    runs = {}
+    for look in (False, True):
+        m = PointTransformer_seg_T(**SMALL).to(dev)
+        m.load_state_dict(init)
+        m.seg_head[2].p = 0.0
+        step = ts.SupervisedStep(m)
+        losses = []
+        for i in range(4):
+            cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+            losses.append(step(cur[0], cur[1], cur[2], next_pos=nxt[0] if look else None).clone())
+            assert (step._geometry is not None) == look
+        torch.cuda.synchronize()
+        runs[look] = (losses, {k: v.detach().clone() for k, v in m.state_dict().items()})
+    for a, b in zip(runs[False][0], runs[True][0]):
+        assert torch.equal(a, b)
+    for k, v in runs[False][1].items():
+        assert torch.equal(v, runs[True][1][k]), k
+    # a geometry that does not belong to the tensor passed in is not used
+    m = PointTransformer_seg_T(**SMALL).to(dev).train()
+    m.load_state_dict(init)
+    m.seg_head[2].p = 0.0
+    x = pos_a.transpose(1, 2).contiguous()
+    want = m(pos_a, x, cls)[0]
+    stale = m.prefetch_geometry(pos_b)
+    assert torch.equal(m(pos_a, x, cls, geometry=stale)[0], want)
+    edited = pos_a.clone()
+    g = m.prefetch_geometry(edited)
+    edited.mul_(1.0)                                      # version bump: the geometry no longer describes this tensor's history
+    assert torch.equal(m(edited, x, cls, geometry=g)[0], want)
+    assert torch.equal(m(pos_a, x, cls, geometry=m.prefetch_geometry(pos_a))[0], want)
