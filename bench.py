@@ -483,6 +483,18 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     fps_ms = fps_timer.mean_ms()
+    fps_alone_ms = None
+    if workload == "model" and fps_rounds:
+        # the same launch with the chip to itself: inside the step the kernel shares its CUs with the GEMMs of the stream it
+        # runs beside (the previous batch's backward under look-ahead, the encoder otherwise) and its loop waits for issue
+        # slots -- the in-step duration above is what the roofline uses, this one says how much of it is contention
+        alone = EventTimer()
+        solo = alone.wrap(pops.furthestsampling_uniform)
+        torch.cuda.synchronize()
+        for _ in range(3):
+            solo(xyz.reshape(-1, 3), B, N_POINTS, fps_rounds + 1)
+            torch.cuda.synchronize()
+        fps_alone_ms = alone.mean_ms()
     fps_flop = fps_clouds * N_POINTS * fps_rounds * FPS_FLOP_PER_UPDATE
     fps_tf = fps_flop / (fps_ms * 1e-3) / 1e12 if fps_rounds else float("nan")
     tag = {"model": "bench_model", "sa": "bench_sa"}.get(workload, workload)
@@ -490,10 +502,11 @@ def main():
     fps_roofline = {
         "kernel": "fps_pruned_kernel", "bound": "valu", "achieved": fps_tf, "peak": FP32_VECTOR_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": fps_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
-        "avg_launch_ms": fps_ms, "cus_used": fps_clouds,
+        "avg_launch_ms": fps_ms, "alone_launch_ms": fps_alone_ms, "cus_used": fps_clouds,
         "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic flop = clouds*N*(m-1) updates "
                 "* 10 (what the reference executes); the pruned kernel skips most of them exactly; one workgroup "
-                "(one CU of 256) per cloud"}
+                "(one CU of 256) per cloud; avg_launch_ms is the launch as it ran inside the step (side stream, sharing its CUs "
+                "with the main stream's GEMMs), alone_launch_ms the same launch with the chip to itself"}
     result = {
         "metric": "point-clouds/sec (24k pts, 17 classes) fwd+bwd" if workload in ("model", "fixmatch") else
                   "point-clouds/sec (24k pts, 17 classes)",
