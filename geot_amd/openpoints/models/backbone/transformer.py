@@ -518,8 +518,8 @@ class PointTransformer_seg_T(nn.Module):
         """Queue everything forward() derives from the COORDINATES of a batch -- Group (512-sample FPS, kNN, the
         neighbourhoods), the 8192-sample FPS and the index plan -- on the side stream, for a batch that will be passed
         to forward(pts, ..., geometry=<the result>) later: a training loop calls this with batch k + 1 between the
-        forward and the backward of batch k, so that the sampling of the next batch (8 + 8 CUs for 0.55 + 4.6 ms) runs
-        beside the GEMM-bound backward instead of at the head of the next step.  Same kernels on the same inputs: the
+        forward and the backward of batch k, so that ~6.5 ms of few-workgroup kernels run beside the GEMM-bound backward
+        instead of at the head of the next step and beside its (shorter) encoder.  GEOT_LOOKAHEAD=group queues Group only.  Same kernels on the same inputs: the
         results are those forward() would compute itself.  None when the model cannot use it (CPU, overlap off)."""
         if not (pts.is_cuda and self.overlap and self.dense == "factored"):
             return None
@@ -531,8 +531,14 @@ class PointTransformer_seg_T(nn.Module):
             group = self.group_divider(pts)
             grouped = torch.cuda.Event()
             grouped.record(side)
-            pointops.fps_indices(pts, max(self.downsample_targets))
-            plan = self._index_plan(pts, group[1])
+            plan = None
+            if os.environ.get("GEOT_LOOKAHEAD", "all") == "all":
+                # also the 8192-sample FPS and the index plan.  Beside the next batch's encoder + 12 blocks (~5 ms of main-stream
+                # work) those ~6 ms of side-stream work ARE the critical path: the decoder waits for them (measured: queueing
+                # only Group gains nothing, 33.94 vs 33.97 ms; queueing everything 33.64).  Beside the backward's GEMMs the
+                # FPS launch itself takes 5.6 instead of 4.7 ms, but nothing waits for it
+                pointops.fps_indices(pts, max(self.downsample_targets))
+                plan = self._index_plan(pts, group[1])
         return {"pts": pts, "version": pts._version, "group": group, "grouped": grouped, "plan": plan,
                 "training": self.training, "fp_layout": self.fp_layout}
 
@@ -549,6 +555,12 @@ class PointTransformer_seg_T(nn.Module):
             main.wait_event(geometry["grouped"])
             neighborhood, center, idx = geometry["group"]
             plan = geometry["plan"]
+            if plan is None:                  # the long FPS and the index plan beside this batch's encoder, as without look-ahead
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    pointops.fps_indices(pts, top)
+                    if os.environ.get("GEOT_INDEX_PLAN", "side") == "side":
+                        plan = self._index_plan(pts, center)
         else:
             # the long FPS (largest target; the shorter ones are prefixes, pointops.fps_indices) beside the encoder
             if side is not None:
