@@ -390,8 +390,22 @@ def main():
         if world > 1:
             parallelism = "dp%d: DDP(student) + DDP(T_predictor) + SyncBatchNorm + all-gather of the class anchors" % world
 
+        # a second pair of batches: the iterations alternate, and each is told the next one's batches (FixMatchNTMStep look-ahead)
+        xyz_l2_np, _ = make_batch(bl, N_POINTS, start_index=dist_utils.cloud_range(rank, bl)[0] + 100003)
+        xyz_u2_np, _ = make_batch(bu, N_POINTS, start_index=110_003 + dist_utils.cloud_range(rank, bu)[0])
+        xyz_l2, xyz_u2 = torch.from_numpy(xyz_l2_np).to(dev), torch.from_numpy(xyz_u2_np).to(dev)
+        strong2 = (xyz_u2 * torch.from_numpy(rng.uniform(0.8, 1.2, size=(bu, 1, 3)).astype(np.float32)).to(dev)).contiguous()
+        data2 = {"pos": xyz_l2, "x": xyz_l2.transpose(1, 2).contiguous(), "cls": data["cls"], "y": torch.from_numpy(region_labels(xyz_l2_np)).to(dev)}
+        data_u2 = {"pos_w": xyz_u2, "x_w": xyz_u2.transpose(1, 2).contiguous(), "cls_w": data_u["cls_w"], "pos_s": strong2,
+                   "x_s": strong2.transpose(1, 2).contiguous(), "cls_s": data_u["cls_s"], "raw_pos": xyz_u2}
+        batches = [(data, data_u), (data2, data_u2)]
+        turn = [0]
+        lookahead = not args.no_lookahead
+
         def step():
-            return trainer(data, data_u)["loss"]
+            cur, nxt = batches[turn[0] % 2], batches[(turn[0] + 1) % 2]
+            turn[0] += 1
+            return trainer(cur[0], cur[1], next_batches=nxt if lookahead else None)["loss"]
     elif workload == "sa":
         from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
         import geot_amd.pointnet2.pointnet2_modules as mods
@@ -607,16 +621,16 @@ def main():
                           "ms_per_step_without_gradient_allreduce": 1e3 * t_local / k2,
                           "exposed_allreduce_ms": ms_per_step - 1e3 * t_local / k2,
                           "note": "exposed = timed step minus the same step under DDP.no_sync() (%d steps); negative = noise" % k2}
-    if workload == "model":
+    if workload in ("model", "fixmatch"):
         result["config"]["lookahead"] = ("the step is handed the next batch's coordinates (two batches alternate) and queues "
                                          "their sampling / grouping / index work beside its own backward"
                                          if lookahead else "off: all of a batch's work inside its own step")
-    if workload == "model" and world == 1 and lookahead and not args.no_dense_reference:
+    if workload in ("model", "fixmatch") and world == 1 and lookahead and not args.no_dense_reference:
         # the same steps without the look-ahead (every batch's sampling at the head of its own step), observed in this run
         def plain_step():
             cur = batches[turn[0] % 2]
             turn[0] += 1
-            return trainer(cur[0], cur[1], cur[2])
+            return trainer(cur[0], cur[1], cur[2]) if workload == "model" else trainer(cur[0], cur[1])["loss"]
         plain_step()
         k3 = min(args.steps, 10)
         t_plain, _ = timed_steps(plain_step, k3, dev, rehearsal)

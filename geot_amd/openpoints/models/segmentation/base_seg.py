@@ -27,7 +27,27 @@ class WholePartSeg(nn.Module):
         super().__init__()
         self.segmentor = build_segmentor(segmentor_args)
 
-    def forward(self, p0, f0=None, cls0=None, u0=None, if_teacher=False, fixmatch=False):
+    @staticmethod
+    def batch_positions(p0, u0=None, if_teacher=False, fixmatch=False):
+        """The (B', N, 3) coordinates forward() hands to the segmentor for these arguments (labelled + strong (+ weak) views
+        concatenated, or the teacher's weak view)."""
+        if if_teacher:
+            return p0["pos_w"].detach()
+        if hasattr(p0, "keys"):
+            if u0 is None:
+                return p0["pos"]
+            views = [p0["pos"], u0["pos_s"]] + ([u0["pos_w"]] if fixmatch else [])
+            return torch.cat(views, 0)
+        return p0
+
+    def prefetch_geometry(self, p0, u0=None, if_teacher=False, fixmatch=False):
+        """Queue the coordinate-only work of the batch a LATER forward(p0, ..., geometry=<result>) will see
+        (PointTransformer_seg_T.prefetch_geometry); None when the segmentor has no such thing."""
+        if not hasattr(self.segmentor, "prefetch_geometry"):
+            return None
+        return self.segmentor.prefetch_geometry(self.batch_positions(p0, u0, if_teacher, fixmatch))
+
+    def forward(self, p0, f0=None, cls0=None, u0=None, if_teacher=False, fixmatch=False, geometry=None):
         if if_teacher:
             p0, f0, cls0 = p0["pos_w"].detach(), p0["x_w"].detach(), p0["cls_w"].detach()
         elif hasattr(p0, "keys"):
@@ -40,6 +60,17 @@ class WholePartSeg(nn.Module):
                 p0, f0, cls0 = p0["pos"], p0["x"], p0["cls"]
         elif f0 is None:
             f0 = p0.transpose(1, 2).contiguous()
+        if geometry is not None:
+            # the geometry was computed on a tensor of the same coordinates (batch_positions of the same arguments): take that
+            # tensor for the positions, so that the segmentor recognises it; a mismatch in shape means it is not ours
+            g = geometry["pts"]
+            if g.shape == p0.shape and g.device == p0.device:
+                p0 = g
+            else:
+                geometry = None
         T = u0["T"] if (u0 is not None and "T" in u0.keys()) else None
-        f, p, s, _ = self.segmentor(p0, f0, cls0, T)
+        if geometry is not None:
+            f, p, s, _ = self.segmentor(p0, f0, cls0, T, geometry=geometry)
+        else:
+            f, p, s, _ = self.segmentor(p0, f0, cls0, T)
         return f, p, s

@@ -143,13 +143,22 @@ class FixMatchNTMStep:
         self.cm = cm if cm is not None else torch.full((c, c), 1.0 / c, device=dev)    # cal_mean_feature's output
         self.group = group
         self._side = None
+        self._geometry = (None, None)      # coordinate-only work of the next student / teacher batch (look-ahead)
+        self._geometry_src = None
         self._teacher_stream = None
         self.overlap_teacher = True    # the frozen teacher's forward on its own stream beside the student's (same results)
 
-    def __call__(self, data, data_u):
+    def __call__(self, data, data_u, next_batches=None):
         """data: labelled batch {pos (B_l,N,3), x (B_l,3,N), cls (B_l,1), y (B_l,N)}; data_u: unlabelled batch
-        {pos_w, x_w, cls_w, pos_s, x_s, cls_s, raw_pos (B_u,N,3)} -> dict of detached losses."""
+        {pos_w, x_w, cls_w, pos_s, x_s, cls_s, raw_pos (B_u,N,3)} -> dict of detached losses.
+        next_batches = (data', data_u') of the NEXT iteration when the loop already holds them: the coordinate-only work of
+        the next student and teacher batches is queued behind this iteration's student forward (SupervisedStep's look-ahead;
+        the caller must then pass exactly those dicts next time -- the positions are matched by content, not trusted)."""
         cfg = self.cfg
+        geom_s, geom_t = self._geometry
+        self._geometry = (None, None)
+        if geom_s is not None and not _same_positions_impl(self._geometry_src, data, data_u):
+            geom_s = geom_t = None       # not the batches the look-ahead was given: do the work in line
         bl, bu = data["pos"].shape[0], data_u["pos_w"].shape[0]
         n = data["pos"].shape[1]
         # the kNN graph of the 3-D loss needs raw_pos only: build it beside the teacher / student forwards
@@ -177,14 +186,21 @@ class FixMatchNTMStep:
             t_stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), (torch.cuda.stream(t_stream) if t_stream is not None else contextlib.nullcontext()):
             self.model_t.eval()
-            pred_u = F.softmax(self.model_t(data_u, if_teacher=True)[0], dim=1)
+            pred_u = F.softmax(self.model_t(data_u, if_teacher=True, geometry=geom_t)[0], dim=1)
             logits_u_aug, label_u_aug = torch.max(pred_u, dim=1)
         # 2. student on labelled + strong + weak (train.py:478-492)
         self.model.train()
         self.T_predictor.train()
         data_u = dict(data_u, T=self.ema_t)
-        pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True)
+        pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
         pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
+        if next_batches is not None:
+            nd, nu = next_batches
+            inner = self.model.module if hasattr(self.model, "module") else self.model
+            self.model_t.eval()
+            self._geometry = (inner.prefetch_geometry(nd, nu, fixmatch=True), self.model_t.prefetch_geometry(nu, if_teacher=True))
+            src = (nd["pos"], nu["pos_s"], nu["pos_w"])
+            self._geometry_src = src + (tuple(t._version for t in src),)
         if t_stream is not None:
             _join(dev, t_stream, pred_u, logits_u_aug, label_u_aug)
         # 3. class-level transition matrix, prior, EMA (train.py:502-545, 556-557)
@@ -213,6 +229,11 @@ class FixMatchNTMStep:
         self.T_optimizer.step()
         self.T_optimizer.zero_grad(set_to_none=True)
         return {"loss": loss.detach(), "sup": sup_loss.detach(), "unsup": unsup_loss.detach(), "threed": loss_3d.detach()}
+
+
+def _same_positions_impl(src, data, data_u):
+    return src is not None and src[0] is data["pos"] and src[1] is data_u["pos_s"] and src[2] is data_u["pos_w"] \
+        and all(t._version == v for t, v in zip(src, src[3]))
 
 
 def build_fixmatch(device, seg_cfg=None, cfg=None, use_ddp=True, group=None):

@@ -658,3 +658,59 @@ def test_look_ahead_geometry_changes_nothing_but_the_schedule():
     edited.mul_(1.0)                                      # version bump: the geometry no longer describes this tensor's history
     assert torch.equal(m(edited, x, cls, geometry=g)[0], want)
     assert torch.equal(m(pos_a, x, cls, geometry=m.prefetch_geometry(pos_a))[0], want)
+
+
+def test_fixmatch_look_ahead_changes_nothing_but_the_schedule():
+    """FixMatchNTMStep(next_batches=...): the next iteration's student batch (labelled + strong + weak views, concatenated)
+    and teacher batch (weak view) have their sampling / grouping / index plan queued behind this iteration's student
+    forward.  WholePartSeg with and without the prefetched geometry: bit-identical logits (student in training mode,
+    teacher in eval mode); three alternating iterations: the first identical, the later ones within the run-to-run
+    spread of the step (float atomics in the graph loss -> AdamW, see tests/test_fullsize_gpu.py); batches other than the
+    announced ones are computed in line."""
+    from geot_amd import train_step as ts
+    from geot_amd.synth import make_batch, region_labels
+    dev = torch.device("cuda:0")
+    cfg = dict(ts.NTM_CFG, threed_k=8)
+
+    def batch(seed):
+        xl, xu = make_batch(2, 4096, start_index=seed)[0], make_batch(2, 4096, start_index=seed + 50)[0]
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+        lab, unl, strong = T(xl), T(xu), T(xu * np.float32(1.04))
+        z = torch.zeros(2, 1, dtype=torch.long, device=dev)
+        return ({"pos": lab, "x": lab.transpose(1, 2).contiguous(), "cls": z, "y": T(region_labels(xl))},
+                {"pos_w": unl, "x_w": unl.transpose(1, 2).contiguous(), "cls_w": z, "pos_s": strong,
+                 "x_s": strong.transpose(1, 2).contiguous(), "cls_s": z, "raw_pos": unl})
+    batches = [batch(3), batch(400)]
+    runs = {}
+    for look in (False, True):
+        torch.manual_seed(5)
+        step = ts.build_fixmatch(dev, seg_cfg=SMALL, cfg=cfg, use_ddp=False)
+        step.model.segmentor.seg_head[2].p = 0.0
+        out = []
+        for i in range(3):
+            cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+            out.append({k: float(v) for k, v in step(cur[0], cur[1], next_batches=nxt if look else None).items()})
+            assert (step._geometry[0] is not None) == look and (step._geometry[1] is not None) == look
+        runs[look] = out
+        if look:
+            # forward with / without the queued geometry: the same logits, bit for bit
+            d, u = batches[1]
+            g_s, g_t = step._geometry
+            with torch.no_grad():
+                step.model.train()
+                a = step.model(d, u0=dict(u, T=step.ema_t), fixmatch=True, geometry=g_s)[0]
+                b = step.model(d, u0=dict(u, T=step.ema_t), fixmatch=True)[0]
+                step.model_t.eval()
+                ta = step.model_t(u, if_teacher=True, geometry=g_t)[0]
+                tb = step.model_t(u, if_teacher=True)[0]
+            assert torch.equal(ta, tb)
+            assert torch.equal(a, b)
+            # an iteration on batches that were NOT announced ignores the geometry
+            other = batch(900)
+            loss = step(other[0], other[1])
+            assert all(bool(torch.isfinite(v)) for v in loss.values())
+    for k in runs[False][0]:
+        assert abs(runs[False][0][k] - runs[True][0][k]) <= 1e-6 * abs(runs[False][0][k]) + 1e-7, (k, runs)
+    for i in (1, 2):
+        for k in runs[False][i]:
+            assert abs(runs[False][i][k] - runs[True][i][k]) <= 3e-4 * abs(runs[False][i][k]) + 1e-6, (i, k, runs)

@@ -1,9 +1,8 @@
 #!/bin/bash
-# lab: A/B on one box, alternating runs: what the look-ahead queues (GEOT_LOOKAHEAD=group|all) and none (--no-lookahead)
+# lab: A/B on one box, alternating runs, fixmatch workload: look-ahead on / off
 for rep in 1 2 3; do
-  for mode in group all none; do
-    flag=""; [ $mode = none ] && flag="--no-lookahead"
-    GEOT_LOOKAHEAD=$mode python bench.py $flag --steps 40 --warmup 5 --no-cpu-baseline --no-dense-reference --no-saturated 2>/dev/null | tail -1 > /tmp/ab.json
-    python -c "import json; r=json.load(open('/tmp/ab.json')); print('$mode', round(r['value'],2), round(r['ms_per_step'],3), 'fps in-step / alone ms', round(r['roofline']['avg_launch_ms'],3), round(r['roofline']['alone_launch_ms'],3))"
+  for flag in "" "--no-lookahead"; do
+    python bench.py --workload fixmatch $flag --steps 40 --warmup 5 --no-cpu-baseline --no-dense-reference 2>/tmp/ab.err | tail -1 > /tmp/ab.json
+    python -c "import json; r=json.load(open('/tmp/ab.json')); print('lookahead' if '$flag' == '' else 'plain    ', round(r['value'],2), round(r['ms_per_step'],3), round(r.get('host_issue_ms_per_step'),2))" || tail -5 /tmp/ab.err
   done
 done
