@@ -3,7 +3,7 @@
 The hot path of this package is hand-written HIP; the dense layers of ``PointTransformer_seg_T`` are library GEMMs,
 half of the step's kernel time.  PyTorch's TunableOp times every rocBLAS / hipBLASLt solution for a GEMM shape once and
 remembers the fastest; ``tunableop_gfx950.csv`` holds that choice for the shapes of BASELINE configs[2] / [4] (8 and
-6 + 2 clouds of 24 000 points), recorded on MI355X with the ROCm 7.2 image (the file's ``Validator`` rows pin PyTorch,
+6 + 2 clouds of 24 000 points, in both layouts of the FP stages, and the same batches at the authors' 16 000 points), recorded on MI355X with the ROCm 7.2 image (the file's ``Validator`` rows pin PyTorch,
 HIP, rocBLAS, hipBLASLt and ``gfx950``: on any other stack TunableOp ignores the file and the default solutions run).
 Same fp32 arithmetic, different tiling: 45.0 -> 41.0 ms per configs[2] step.
 
