@@ -500,7 +500,8 @@ static int fp_front_cl_tiles(long long rows, int c, int cs)
 }
 GEOT_EXPORT int geot_fp_front_cl_tiles(int b, int c, int n, int cs)
 {
-    if (b < 1 || cs < 0 || cs > CL_MAX_SKIP || !cl_dims_ok(n, c) || (long long)b * n > 0x7fffffffLL) return -1;
+    // (rows up to 2^30: the row deal of fp_front_cl_kernel steps past the end of its range by up to a stage of granules)
+    if (b < 1 || cs < 0 || cs > CL_MAX_SKIP || !cl_dims_ok(n, c) || (long long)b * n > 0x3fffffffLL) return -1;
     return fp_front_cl_tiles((long long)b * n, c, cs);
 }
 
