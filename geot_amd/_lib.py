@@ -125,6 +125,8 @@ PROTOTYPES.update({
     "geot_segment_max_grad": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],
     "geot_edgeconv_gn_max": [_c_int] * 6 + [_c_float, _c_float] + [_P] * 11 + [ctypes.c_longlong, _c_void_p],
     "geot_edgeconv_gn_max_grad": [_c_int] * 6 + [_c_float] + [_P] * 15 + [ctypes.c_longlong, _c_void_p],
+    "geot_edgeconv_gn_max_grad_rix": [_c_int] * 6 + [_c_float] + [_P] * 15 + [ctypes.c_longlong, _c_void_p],
+    "geot_edgeconv_rix_build": [_c_int] * 4 + [_P, _P, ctypes.c_longlong, _c_void_p],
 })
 # entry points that do not follow the "(..., stream) -> hipError_t" shape
 PLAIN = {
@@ -148,6 +150,7 @@ PLAIN = {
     "geot_cl_stat_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_rix_ws_ints": ([_c_int, ctypes.c_longlong, _c_int, _c_int], ctypes.c_longlong),
     "geot_edgeconv_ws_bytes": ([_c_int] * 5, ctypes.c_longlong),
+    "geot_edgeconv_rix_ints": ([_c_int] * 4, ctypes.c_longlong),
     "geot_poly1_focal_ws_doubles": ([_c_int] * 3, ctypes.c_longlong),
     "geot_res_ln_supported": ([_c_int], _c_int),
     "geot_res_ln_ws_floats": ([_c_int] * 2, ctypes.c_longlong),

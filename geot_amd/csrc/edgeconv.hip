@@ -470,36 +470,78 @@ GEOT_EXPORT int geot_edgeconv_gn_max(int b, int c, int nq, int nk, int k, int gr
     return hipGetLastError();
 }
 
-GEOT_EXPORT int geot_edgeconv_gn_max_grad(int b, int c, int nq, int nk, int k, int groups, float slope, const float *P,
-                                          const float *Q, const int *idx, const float *gamma, const float *beta,
-                                          const float *ysel, const float *ysum, const unsigned char *jsel,
-                                          const float *stats, const float *grad_out, float *grad_p, float *grad_q,
-                                          float *grad_gamma, float *grad_beta, void *workspace, long long ws_bytes,
-                                          void *stream)
+// The reverse index of idx (pairs (i, j) grouped by (batch, target), ascending pair id inside a list) depends on the kNN
+// graph alone: a caller that has the graph early (the model's index plan: side stream / look-ahead) builds it there with
+// geot_edgeconv_rix_build and hands it to geot_edgeconv_gn_max_grad_rix; geot_edgeconv_gn_max_grad builds it in its
+// workspace on the gradient's own stream (7 small launches per layer on the critical path of the backward).
+struct EcRix {
+    long long t, pairs, off, bsum, rank, rev, tmp, ints;
+};
+static inline EcRix ec_rix_layout(int b, int nq, int nk, int k)
+{
+    EcRix r;
+    r.t = (long long)b * nk;
+    r.pairs = (long long)b * nq * k;
+    r.off = 0;
+    r.bsum = r.t + 1;
+    r.rank = r.bsum + scan_blocks(r.t);
+    r.rev = r.rank + r.pairs;
+    r.tmp = r.rev + r.pairs;
+    r.ints = r.tmp + r.pairs + 8;
+    return r;
+}
+static hipError_t ec_rix_build(int b, int nq, int nk, int k, const int *idx, int *ws, hipStream_t s)
+{
+    const EcRix r = ec_rix_layout(b, nq, nk, k);
+    int *off = ws + r.off, *rank = ws + r.rank, *rev = ws + r.rev;
+    hipError_t e = zero_words(off, r.t + 1, s);
+    if (e != hipSuccess) return e;
+    const int pb = (int)((r.pairs + 255) / 256);
+    hipLaunchKernelGGL(edge_rix_count_kernel, dim3(pb), dim3(256), 0, s, r.pairs, (long long)nq * k, nk, idx, off, rank);
+    exclusive_scan_i32((int)r.t, off, ws + r.bsum, nullptr, s);
+    if (rix_reproducible()) {   // fill pair ids in arrival order, then place them in ascending order: fixed summation order
+        int *tmp = ws + r.tmp;
+        hipLaunchKernelGGL(edge_rix_fill_kernel, dim3(pb), dim3(256), 0, s, r.pairs, (long long)nq * k, nk, idx, off, rank, tmp);
+        hipLaunchKernelGGL(edge_rix_place_kernel, dim3(pb), dim3(256), 0, s, r.pairs, (long long)nq * k, nk, idx, off, rank, tmp, rev);
+    } else {
+        hipLaunchKernelGGL(edge_rix_fill_kernel, dim3(pb), dim3(256), 0, s, r.pairs, (long long)nq * k, nk, idx, off, rank, rev);
+    }
+    return hipGetLastError();
+}
+
+GEOT_EXPORT long long geot_edgeconv_rix_ints(int b, int nq, int nk, int k)
+{
+    if (b < 1 || nq < 1 || nk < 1 || k < 1) return 0;
+    return ec_rix_layout(b, nq, nk, k).ints;
+}
+
+GEOT_EXPORT int geot_edgeconv_rix_build(int b, int nq, int nk, int k, const int *idx, int *rix, long long rix_ints, void *stream)
+{
+    if (b < 1 || nq < 1 || nk < 1 || k < 1 || !idx || !rix || rix_ints < ec_rix_layout(b, nq, nk, k).ints ||
+        (long long)b * nq * k > 0x7ffffff0LL || (long long)b * nk > 0x7ffffff0LL)
+        return hipErrorInvalidValue;
+    return ec_rix_build(b, nq, nk, k, idx, rix, (hipStream_t)stream);
+}
+
+static int ec_grad(int b, int c, int nq, int nk, int k, int groups, float slope, const float *P, const float *Q, const int *idx,
+                   const float *gamma, const float *beta, const float *ysel, const float *ysum, const unsigned char *jsel,
+                   const float *stats, const float *grad_out, float *grad_p, float *grad_q, float *grad_gamma, float *grad_beta,
+                   void *workspace, long long ws_bytes, const int *rix, hipStream_t s)
 {
     if (!ec_ok(b, c, nq, nk, k, groups) || ws_bytes < geot_edgeconv_ws_bytes(b, c, nq, nk, k)) return hipErrorInvalidValue;
-    hipStream_t s = (hipStream_t)stream;
     float *bpart = (float *)workspace;
     float *coef = bpart + (size_t)b * c * 32 * 2 - (size_t)b * groups * 2 - 8; // tail of the partials area (slices <= 16 used)
     int slices = ec_slices(b, c, 1, nq);
     if (slices > 16) slices = 16;
-    int *off = (int *)((char *)workspace + (size_t)b * c * 32 * 2 * sizeof(float));
-    const long long t = (long long)b * nk, pairs = (long long)b * nq * k;
-    int *bsum = off + t + 1;
-    int *rank = bsum + scan_blocks(t);
-    int *rev = rank + pairs;
-    hipError_t e = zero_words(off, t + 1, s);
-    if (e != hipSuccess) return e;
-    const int pb = (int)((pairs + 255) / 256);
-    hipLaunchKernelGGL(edge_rix_count_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank);
-    exclusive_scan_i32((int)t, off, bsum, nullptr, s);
-    if (rix_reproducible()) {   // fill pair ids in arrival order, then place them in ascending order: fixed summation order
-        int *tmp = rev + pairs;
-        hipLaunchKernelGGL(edge_rix_fill_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank, tmp);
-        hipLaunchKernelGGL(edge_rix_place_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank, tmp, rev);
-    } else {
-        hipLaunchKernelGGL(edge_rix_fill_kernel, dim3(pb), dim3(256), 0, s, pairs, (long long)nq * k, nk, idx, off, rank, rev);
+    const EcRix r = ec_rix_layout(b, nq, nk, k);
+    hipError_t e;
+    if (!rix) {                 // no index given: build it in the workspace, on this stream
+        int *own = (int *)((char *)workspace + (size_t)b * c * 32 * 2 * sizeof(float));
+        e = ec_rix_build(b, nq, nk, k, idx, own, s);
+        if (e != hipSuccess) return e;
+        rix = own;
     }
+    const int *off = rix + r.off, *rev = rix + r.rev;
 
     hipLaunchKernelGGL(edge_bwd_reduce_kernel, dim3(slices, c, b), dim3(256), 0, s, c, nq, groups, slope, ysel, gamma, beta,
                        stats, grad_out, bpart);
@@ -528,4 +570,28 @@ GEOT_EXPORT int geot_edgeconv_gn_max_grad(int b, int c, int nq, int nk, int k, i
     }
 #undef GEOT_EC_BWD
     return hipGetLastError();
+}
+
+GEOT_EXPORT int geot_edgeconv_gn_max_grad(int b, int c, int nq, int nk, int k, int groups, float slope, const float *P,
+                                          const float *Q, const int *idx, const float *gamma, const float *beta,
+                                          const float *ysel, const float *ysum, const unsigned char *jsel,
+                                          const float *stats, const float *grad_out, float *grad_p, float *grad_q,
+                                          float *grad_gamma, float *grad_beta, void *workspace, long long ws_bytes,
+                                          void *stream)
+{
+    return ec_grad(b, c, nq, nk, k, groups, slope, P, Q, idx, gamma, beta, ysel, ysum, jsel, stats, grad_out, grad_p, grad_q,
+                   grad_gamma, grad_beta, workspace, ws_bytes, nullptr, (hipStream_t)stream);
+}
+
+// as above with the reverse index of idx built beforehand (geot_edgeconv_rix_build, same b, nq, nk, k, idx)
+GEOT_EXPORT int geot_edgeconv_gn_max_grad_rix(int b, int c, int nq, int nk, int k, int groups, float slope, const float *P,
+                                              const float *Q, const int *rix, const float *gamma, const float *beta,
+                                              const float *ysel, const float *ysum, const unsigned char *jsel,
+                                              const float *stats, const float *grad_out, float *grad_p, float *grad_q,
+                                              float *grad_gamma, float *grad_beta, void *workspace, long long ws_bytes,
+                                              void *stream)
+{
+    if (!rix) return hipErrorInvalidValue;
+    return ec_grad(b, c, nq, nk, k, groups, slope, P, Q, nullptr, gamma, beta, ysel, ysum, jsel, stats, grad_out, grad_p, grad_q,
+                   grad_gamma, grad_beta, workspace, ws_bytes, rix, (hipStream_t)stream);
 }

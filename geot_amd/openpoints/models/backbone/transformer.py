@@ -34,7 +34,7 @@ from ....pointnet2 import pointnet2_utils as pt_utils
 from ....pointnet2.pytorch_utils import PointwiseConv1d, PointwiseConv2d, pointwise, batch_norm_nd, shared_mlp_nd
 from ....knn_cuda import KNN, knn_sorted
 from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused,  # noqa: F401
-                              edgeconv_tail, edgeconv_tail_eligible)
+                              edgeconv_tail, edgeconv_tail_eligible, edgeconv_reverse_index)
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
 from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
 from ....fused_norm import (fp_front_cl, fp_front_cl_eligible, bn_act_cl, fp_stage_cl, pointwise_to_cl, pointwise_from_cl,
@@ -308,6 +308,10 @@ class DGCNN_Propagation(nn.Module):
         return graph_feature(x_q, x_k, _knn_idx(coor_q, coor_k, self.k))
 
     def _edge(self, layer, coor_q, x_q, coor_k, x_k, idx=None):
+        """idx: the kNN ids (B,Nq,k), or the pair (ids, reverse index of the ids) when the caller built both ahead."""
+        rix = None
+        if isinstance(idx, (tuple, list)):
+            idx, rix = idx
         conv, norm, act = layer[0], layer[1], layer[2]
         if self.dense != "factored":
             y = conv(self.get_graph_feature(coor_q, x_q, coor_k, x_k))
@@ -321,7 +325,7 @@ class DGCNN_Propagation(nn.Module):
             q = pointwise(w_q - w_d, x_q)                                # (B, Cout, Nq)
             if (self.fused_tail and p.is_cuda and isinstance(norm, nn.GroupNorm) and norm.affine and isinstance(act, nn.LeakyReLU)
                     and edgeconv_tail_eligible(p.shape[0], p.shape[1], q.shape[2], p.shape[2], self.k, norm.num_groups)):
-                return edgeconv_tail(p, q, idx, norm, act.negative_slope)   # gather + GN + LeakyReLU + max, fused
+                return edgeconv_tail(p, q, idx, norm, act.negative_slope, rix)   # gather + GN + LeakyReLU + max, fused
             y = pt_utils.grouping_operation(p.contiguous(), idx) + q.unsqueeze(-1)
         return act(norm(y)).max(dim=-1, keepdim=False)[0]
 
@@ -504,10 +508,18 @@ class PointTransformer_seg_T(nn.Module):
             rix = ReverseIndex(idx, weight, known.shape[1], local_spatial_order(known) if big else None) if self.training else None
             return idx, weight, local_spatial_order(unknown) if big else None, rix
         k2, k1 = self.dgcnn_pro_2.k, self.dgcnn_pro_1.k
+
+        def graph(coor_q, coor_k, k):
+            # the kNN ids of an EdgeConv layer and, in training, the reverse index its fused gradient walks (7 small launches
+            # per layer that would otherwise sit on the backward's critical path)
+            idx = _knn_idx(coor_q, coor_k, k)
+            if not (self.training and self.dgcnn_pro_1.fused_tail):
+                return idx
+            return idx, edgeconv_reverse_index(idx, coor_k.shape[2])
         return {"center_pts": center_pts, "center_pts_trans": trans, "center_trans": center_trans,
                 "fp2": nn3(center_pts[1], center), "fp1": nn3(center_pts[0], center), "fp0": nn3(pts, center_pts[0]),
-                "dg2": (_knn_idx(trans[1], center_trans, k2), _knn_idx(trans[1], trans[1], k2)),
-                "dg1": (_knn_idx(trans[0], trans[1], k1), _knn_idx(trans[0], trans[0], k1))}
+                "dg2": (graph(trans[1], center_trans, k2), graph(trans[1], trans[1], k2)),
+                "dg1": (graph(trans[0], trans[1], k1), graph(trans[0], trans[0], k1))}
 
     def forward(self, pts, x=None, cls_label=None, T=None, geometry=None):
         with pointops.fps_prefix_scope():       # the three pointops.fps targets are prefixes of one FPS run

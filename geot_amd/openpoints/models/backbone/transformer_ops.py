@@ -81,7 +81,7 @@ class _EdgeConvTailFn(torch.autograd.Function):
     """max_j LeakyReLU(GroupNorm(P[:, idx] + Q[..., None])) without the (B,C,Nq,k) tensor (csrc/edgeconv.hip)."""
 
     @staticmethod
-    def forward(ctx, p, q, idx, gamma, beta, groups, eps, slope):
+    def forward(ctx, p, q, idx, gamma, beta, groups, eps, slope, rix=None):
         p, q = f32(p.contiguous(), "P", 3), f32(q.contiguous(), "Q", 3)
         idx = i32(idx.contiguous(), "idx", 3)
         gamma, beta = f32(gamma.contiguous(), "weight", 1), f32(beta.contiguous(), "bias", 1)
@@ -102,6 +102,7 @@ class _EdgeConvTailFn(torch.autograd.Function):
              ptr(gamma), ptr(beta), ptr(out), ptr(ysel), ptr(ysum), ptr(jsel), ptr(stats), ptr(ws), nbytes)
         ctx.save_for_backward(p, q, idx, gamma, beta, ysel, ysum, jsel, stats)
         ctx.consts = (int(groups), float(slope), nbytes)
+        ctx.rix = rix                  # the reverse index of idx built ahead (edgeconv_reverse_index), or None
         return out
 
     @staticmethod
@@ -114,16 +115,33 @@ class _EdgeConvTailFn(torch.autograd.Function):
         gp, gq = torch.empty_like(p), torch.empty_like(q)
         gg, gb = torch.empty_like(gamma), torch.empty_like(beta)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=p.device)
-        call("geot_edgeconv_gn_max_grad", p.device, b, c, nq, nk, k, groups, slope, ptr(p), ptr(q), ptr(idx), ptr(gamma),
-             ptr(beta), ptr(ysel), ptr(ysum), ptr(jsel), ptr(stats), ptr(g), ptr(gp), ptr(gq), ptr(gg), ptr(gb), ptr(ws),
-             nbytes)
-        return gp, gq, None, gg, gb, None, None, None
+        if ctx.rix is not None:
+            call("geot_edgeconv_gn_max_grad_rix", p.device, b, c, nq, nk, k, groups, slope, ptr(p), ptr(q), ptr(ctx.rix), ptr(gamma),
+                 ptr(beta), ptr(ysel), ptr(ysum), ptr(jsel), ptr(stats), ptr(g), ptr(gp), ptr(gq), ptr(gg), ptr(gb), ptr(ws),
+                 nbytes)
+        else:
+            call("geot_edgeconv_gn_max_grad", p.device, b, c, nq, nk, k, groups, slope, ptr(p), ptr(q), ptr(idx), ptr(gamma),
+                 ptr(beta), ptr(ysel), ptr(ysum), ptr(jsel), ptr(stats), ptr(g), ptr(gp), ptr(gq), ptr(gg), ptr(gb), ptr(ws),
+                 nbytes)
+        return gp, gq, None, gg, gb, None, None, None, None
 
 
-def edgeconv_tail(p, q, idx, norm, slope):
+def edgeconv_reverse_index(idx, nk):
+    """idx (B,Nq,k) int32 neighbours among nk sources -> the reverse index the fused tail's gradient walks
+    (geot_edgeconv_rix_build): depends on the graph alone, so the model builds it with its index plan."""
+    idx = i32(idx.contiguous(), "idx", 3)
+    b, nq, k = idx.shape
+    ints = int(_lib.load().geot_edgeconv_rix_ints(b, nq, int(nk), k))
+    rix = torch.empty(ints, dtype=torch.int32, device=idx.device)
+    call("geot_edgeconv_rix_build", idx.device, b, nq, int(nk), k, ptr(idx), ptr(rix), ints)
+    return rix
+
+
+def edgeconv_tail(p, q, idx, norm, slope, rix=None):
     """p (B,C,Nk) = W_d x_k, q (B,C,Nq) = (W_q - W_d) x_q, idx (B,Nq,k) int32, norm = the layer's nn.GroupNorm ->
-    (B,C,Nq) = max_j LeakyReLU(norm(p[:, idx] + q[..., None])), one fused forward / backward."""
-    return _EdgeConvTailFn.apply(p, q, idx, norm.weight, norm.bias, norm.num_groups, norm.eps, slope)
+    (B,C,Nq) = max_j LeakyReLU(norm(p[:, idx] + q[..., None])), one fused forward / backward.  rix: the reverse index of
+    idx when it was built ahead (edgeconv_reverse_index)."""
+    return _EdgeConvTailFn.apply(p, q, idx, norm.weight, norm.bias, norm.num_groups, norm.eps, slope, rix)
 
 
 def edgeconv_tail_eligible(b, c, nq, nk, k, groups):

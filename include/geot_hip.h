@@ -325,6 +325,17 @@ int geot_edgeconv_gn_max_grad(int b, int c, int nq, int nk, int k, int groups, f
                               const float *ysel, const float *ysum, const unsigned char *jsel, const float *stats,
                               const float *grad_out, float *grad_p, float *grad_q, float *grad_gamma,
                               float *grad_beta, void *workspace, long long ws_bytes, void *stream);
+/* The gradient's reverse index of idx (pairs grouped by target, ascending pair id) depends on the kNN graph alone:
+ * geot_edgeconv_rix_build writes it into `rix` (geot_edgeconv_rix_ints ints) wherever the caller has the graph early;
+ * geot_edgeconv_gn_max_grad_rix = geot_edgeconv_gn_max_grad with that index instead of idx (7 launches fewer on the
+ * gradient's stream). */
+long long geot_edgeconv_rix_ints(int b, int nq, int nk, int k);
+int geot_edgeconv_rix_build(int b, int nq, int nk, int k, const int *idx, int *rix, long long rix_ints, void *stream);
+int geot_edgeconv_gn_max_grad_rix(int b, int c, int nq, int nk, int k, int groups, float slope, const float *P,
+                                  const float *Q, const int *rix, const float *gamma, const float *beta,
+                                  const float *ysel, const float *ysum, const unsigned char *jsel, const float *stats,
+                                  const float *grad_out, float *grad_p, float *grad_q, float *grad_gamma,
+                                  float *grad_beta, void *workspace, long long ws_bytes, void *stream);
 
 /* EdgeConv graph feature = DGCNN_Propagation.get_graph_feature
  * (openpoints/models/backbone/transformer.py:343-364: transpose + fancy-index gather + permute +

@@ -302,3 +302,30 @@ def test_model_step_in_both_fp_layouts():
             assert err <= 5e-3, (k, err)                     # fp32 through ~30 layers with max-pools (see test_fp64_referee)
     for k in b0:
         assert float((b0[k].float() - b1[k].float()).abs().max()) <= 1e-5 * max(1.0, float(b0[k].float().abs().max())), k
+
+
+def test_edgeconv_gradient_with_the_reverse_index_built_ahead():
+    """transformer_ops.edgeconv_reverse_index + edgeconv_tail(rix=...): the reverse index of the kNN graph built once, ahead
+    (the model's index plan), gives the same gradients bit for bit as the one the gradient call builds for itself."""
+    from geot_amd.openpoints.models.backbone.transformer_ops import edgeconv_tail, edgeconv_reverse_index
+    from geot_amd.knn_cuda import knn_sorted
+    b, c, nq, nk, k = 2, 384, 2048, 512, 4
+    pos = _cloud(b, nq, 6)
+    src = pos[:, :nk].contiguous()
+    _, idx = knn_sorted(pos, src, k)                       # (query, reference) -> (b, nq, k) ids among the nk sources
+    idx = idx.int().contiguous()
+    assert idx.shape == (b, nq, k) and int(idx.max()) < nk
+    torch.manual_seed(0)
+    norm = torch.nn.GroupNorm(4, c).to(DEV)
+    up = torch.randn(b, c, nq, device=DEV)
+    res = []
+    for ahead in (False, True):
+        p = torch.randn(b, c, nk, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)).requires_grad_(True)
+        q = torch.randn(b, c, nq, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)).requires_grad_(True)
+        norm.zero_grad(set_to_none=True)
+        rix = edgeconv_reverse_index(idx, nk) if ahead else None
+        out = edgeconv_tail(p, q, idx, norm, 0.2, rix)
+        (out * up).sum().backward()
+        res.append((out.detach(), p.grad.clone(), q.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()))
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
