@@ -114,6 +114,7 @@ PROTOTYPES.update({
     "geot_rix_build": [_c_int] * 4 + [_P] * 4 + [ctypes.c_longlong, _c_void_p],
     "geot_gather_rows_csr_cl": [_c_int] * 5 + [_P] * 4 + [_c_void_p],
     "geot_bn_sums_k_cl": [_c_int] * 3 + [_P] * 2 + [_c_void_p],
+    "geot_fp_skip_wgrad_cl": [_c_int, _c_int] + [_P] * 6 + [_c_void_p],
     "geot_bn_bwd_reduce_skip_cl": [_c_int] * 5 + [_P] * 8 + [_c_void_p],
     "geot_gather_rows_csr_bn_cl": [_c_int] * 6 + [_P] * 11 + [_c_void_p],
     "geot_segment_max": [ctypes.c_longlong, _c_int, _P, _P, _P, _c_void_p],

@@ -452,6 +452,20 @@ __global__ __launch_bounds__(CL_MAX_THREADS) void bn_reduce_skip_cl_kernel(
     }
 }
 
+// grad_wb[c, j] = scale_c (S1[c, j] - c1_c S2[j] - c2_c S3[c, j]) from the sums of bn_reduce_skip_cl_kernel (sums_k (C, 2 + 2 CS)
+// fp64: [2 + j] = S1, [2 + CS + j] = S3), the means c1 / c2 of geot_bn_bwd_coef and S2[j] = sum over all points of skip_j
+__global__ __launch_bounds__(256) void fp_skip_wgrad_cl_kernel(int c, int cs, const double *__restrict__ sums_k,
+                                                               const float *__restrict__ scale, const float *__restrict__ c1,
+                                                               const float *__restrict__ c2, const double *__restrict__ s2,
+                                                               float *__restrict__ gwb)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= c * cs) return;
+    const int ch = x / cs, j = x - ch * cs, K = 2 + 2 * cs;
+    const double v = sums_k[(size_t)ch * K + 2 + j] - (double)c1[ch] * s2[j] - (double)c2[ch] * sums_k[(size_t)ch * K + 2 + cs + j];
+    gwb[x] = (float)((double)scale[ch] * v);
+}
+
 } // namespace geot
 
 using namespace geot;
@@ -643,5 +657,16 @@ GEOT_EXPORT int geot_bn_bwd_reduce_skip_cl(int b, int n, int c, int cs, int relu
     default: GEOT_RS(8); break;
     }
 #undef GEOT_RS
+    return hipGetLastError();
+}
+
+// grad of the skip weights wb (c, cs) of fp_front_cl behind a BatchNorm, from the reduce-with-skip sums (see the kernel)
+GEOT_EXPORT int geot_fp_skip_wgrad_cl(int c, int cs, const double *sums_k, const float *scale, const float *c1, const float *c2,
+                                      const double *s2, float *gwb, void *stream)
+{
+    if (c < 0 || cs < 0 || cs > CL_MAX_SKIP) return hipErrorInvalidValue;
+    if (c == 0 || cs == 0) return hipSuccess;
+    hipLaunchKernelGGL(fp_skip_wgrad_cl_kernel, dim3((c * cs + 255) / 256), dim3(256), 0, (hipStream_t)stream, c, cs, sums_k, scale,
+                       c1, c2, s2, gwb);
     return hipGetLastError();
 }

@@ -456,6 +456,7 @@ class _FpStageClFn(Function):
         call("geot_bn_apply_cl", dev, b * n, c, int(relu), ptr(y), ptr(scale), ptr(shift), ptr(z))
         ctx.save_for_backward(y, idx, weight, skip, wbc, scale, shift, mean, rstd)
         ctx.cfg = (bool(relu), count, group, m, order, rix)
+        ctx.skip_sums = skip.sum((0, 2), dtype=torch.float64) if cs else None     # S2 of the skip-weight gradient (input data only)
         return z
 
     @staticmethod
@@ -492,10 +493,8 @@ class _FpStageClFn(Function):
                  ptr(rstd), ptr(coef[2]), ptr(coef[3]), ptr(rix.ws), ptr(rix.order), ptr(ga))
         if cs and ctx.needs_input_grad[4]:
             # grad_wb[c, j] = sum_e gy[e, c] skip_j[e] = scale_c (sum g skip_j - c1_c sum skip_j - c2_c sum xhat skip_j)
-            s1, s3 = sums_k[:, 2:2 + cs], sums_k[:, 2 + cs:]
-            s2 = skip.sum((0, 2), dtype=torch.float64)
-            gwb = (scale.double().unsqueeze(1) * (s1 - coef[2].double().unsqueeze(1) * s2.unsqueeze(0)
-                                                   - coef[3].double().unsqueeze(1) * s3)).float()
+            gwb = torch.empty((c, cs), dtype=torch.float32, device=dev)
+            call("geot_fp_skip_wgrad_cl", dev, c, cs, ptr(sums_k), ptr(scale), ptr(coef[2]), ptr(coef[3]), ptr(ctx.skip_sums), ptr(gwb))
         if cs and ctx.needs_input_grad[3]:                                   # (never in the model: the skip tensor is input data)
             gy = torch.empty_like(y)
             call("geot_bn_bwd_apply_cl", dev, b * n, c, int(relu), ptr(y), ptr(dz), ptr(scale), ptr(shift), ptr(mean), ptr(rstd),

@@ -300,6 +300,10 @@ int geot_bn_sums_k_cl(int tiles, int c, int k, const float *partial, double *sum
 int geot_bn_bwd_reduce_skip_cl(int b, int n, int c, int cs, int relu, const float *x, const float *dz, const float *scale,
                                const float *shift, const float *mean, const float *rstd, const float *skip, float *partial,
                                void *stream);
+/* grad_wb (c, cs) = scale_c (S1 - c1_c S2 - c2_c S3) from sums_k (c, 2 + 2 cs) of the pass above, c1 / c2 of
+ * geot_bn_bwd_coef and s2 (cs) fp64 = the sum of every skip channel over all points */
+int geot_fp_skip_wgrad_cl(int c, int cs, const double *sums_k, const float *scale, const float *c1, const float *c2,
+                          const double *s2, float *gwb, void *stream);
 int geot_gather_rows_csr_bn_cl(int b, int c, int L, int m, int nt, int relu, const float *y_cl, const float *dz_cl,
                                const float *scale, const float *shift, const float *mean, const float *rstd, const float *c1,
                                const float *c2, const int *ws, const int *order, float *out_cl, void *stream);
