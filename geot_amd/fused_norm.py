@@ -456,7 +456,8 @@ class _FpStageClFn(Function):
         call("geot_bn_apply_cl", dev, b * n, c, int(relu), ptr(y), ptr(scale), ptr(shift), ptr(z))
         ctx.save_for_backward(y, idx, weight, skip, wbc, scale, shift, mean, rstd)
         ctx.cfg = (bool(relu), count, group, m, order, rix)
-        ctx.skip_sums = skip.sum((0, 2), dtype=torch.float64) if cs else None     # S2 of the skip-weight gradient (input data only)
+        # S2 of the skip-weight gradient (input data only); not under no_grad / for frozen weights
+        ctx.skip_sums = skip.sum((0, 2), dtype=torch.float64) if (cs and ctx.needs_input_grad[4]) else None
         return z
 
     @staticmethod
