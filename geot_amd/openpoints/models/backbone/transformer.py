@@ -427,6 +427,7 @@ class PointTransformer_seg_T(nn.Module):
         self.fp_layout = os.environ.get("GEOT_FP_LAYOUT", "cl")
         self.overlap = overlap
         self._side = {}
+        self.at_blocks_backward = None    # one-shot callback of the training step (set before forward, see _forward)
 
         self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
         self.encoder_dims = encoder_dims
@@ -590,6 +591,17 @@ class PointTransformer_seg_T(nn.Module):
         group_input_tokens = self.reduce_dim(self.encoder(neighborhood))
         pos = self.pos_embed(center)
         inter_feats = self.blocks(group_input_tokens, pos)
+        if self.at_blocks_backward is not None and inter_feats[-1].requires_grad:
+            # look-ahead, timed: the training step's callback (it queues the next batch's coordinate-only work,
+            # prefetch_geometry) runs when the backward REACHES the transformer blocks -- the gradient of their last output
+            # exists, the decoder's backward is done.  Beside the decoder's wide GEMMs the 8192-sample FPS takes 5.6 ms and
+            # slows them; beside the blocks' small GEMMs it takes its 4.7 ms (33.27 vs 33.61 ms per step)
+            cb, self.at_blocks_backward = self.at_blocks_backward, None
+
+            def run_callback(grad, cb=cb):
+                cb()
+                return grad
+            inter_feats[-1].register_hook(run_callback)
         inter_feats = [self.norm(t).transpose(-1, -2).contiguous() for t in inter_feats]
         cls_label_one_hot = F.one_hot(cls_label, 2).transpose(1, 2).float().repeat(1, 1, N)
 

@@ -14,6 +14,7 @@ does (SyncBatchNorm + DistributedDataParallel) -- and also wraps T_predictor, wh
 unsynchronised (last row: an intentional divergence).
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -97,6 +98,16 @@ def make_optimizer(model, lr=1e-3, weight_decay=1e-4):
     return torch.optim.AdamW(groups, lr=lr, weight_decay=0.0 if weight_decay else weight_decay, fused=fused)
 
 
+def _lookahead_at_blocks(segmentor, default):
+    """Where a step queues its look-ahead: inside the backward, when it reaches the transformer blocks ("blocks"; the model
+    must offer the hook), or right behind the forward ("forward").  GEOT_LOOKAHEAD_AT overrides the step's default --
+    measured (profiles/r03_ab_lookahead_at*.txt): the supervised step 33.27 ms at "blocks" against 33.61 at "forward" (behind
+    the forward the 8192-sample FPS shares the chip with the decoder's widest GEMMs and takes 5.5 instead of 4.8 ms); the
+    FixMatch iteration 32.1 ms at "forward" against 32.7 at "blocks" (behind its student forward come the NTM block and the
+    losses: a stretch of small kernels that leaves the FPS launches room)."""
+    return os.environ.get("GEOT_LOOKAHEAD_AT", default) == "blocks" and hasattr(segmentor, "at_blocks_backward")
+
+
 class SupervisedStep:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, grad_norm_clip=None):
         self.model = model
@@ -113,11 +124,20 @@ class SupervisedStep:
         self.model.train()
         inner = self.model.module if hasattr(self.model, "module") else self.model
         geometry, self._geometry = self._geometry, None
+        queue = None
+        if next_pos is not None and hasattr(inner, "prefetch_geometry"):
+            def queue():
+                self._geometry = inner.prefetch_geometry(next_pos)
+        at_blocks = _lookahead_at_blocks(inner, "blocks")
+        if queue is not None and at_blocks:
+            inner.at_blocks_backward = queue          # runs inside the backward, when it reaches the transformer blocks
         logits = self.model(pos, pos.transpose(1, 2).contiguous(), cls, geometry=geometry)[0]
         loss = self.criterion(logits, target)
-        if next_pos is not None and hasattr(inner, "prefetch_geometry"):
-            self._geometry = inner.prefetch_geometry(next_pos)
+        if queue is not None and not at_blocks:
+            queue()                                   # (GEOT_LOOKAHEAD_AT=forward: right behind the forward)
         loss.backward()
+        if at_blocks:
+            inner.at_blocks_backward = None
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
         self.optimizer.step()
@@ -192,15 +212,23 @@ class FixMatchNTMStep:
         self.model.train()
         self.T_predictor.train()
         data_u = dict(data_u, T=self.ema_t)
-        pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
-        pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        queue = None
         if next_batches is not None:
             nd, nu = next_batches
-            inner = self.model.module if hasattr(self.model, "module") else self.model
-            self.model_t.eval()
-            self._geometry = (inner.prefetch_geometry(nd, nu, fixmatch=True), self.model_t.prefetch_geometry(nu, if_teacher=True))
-            src = (nd["pos"], nu["pos_s"], nu["pos_w"])
-            self._geometry_src = src + (tuple(t._version for t in src),)
+
+            def queue():
+                self.model_t.eval()
+                self._geometry = (inner.prefetch_geometry(nd, nu, fixmatch=True), self.model_t.prefetch_geometry(nu, if_teacher=True))
+                src = (nd["pos"], nu["pos_s"], nu["pos_w"])
+                self._geometry_src = src + (tuple(t._version for t in src),)
+        at_blocks = _lookahead_at_blocks(inner.segmentor, "forward")
+        if queue is not None and at_blocks:
+            inner.segmentor.at_blocks_backward = queue      # runs when the student's backward reaches the transformer blocks
+        pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
+        pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
+        if queue is not None and not at_blocks:
+            queue()
         if t_stream is not None:
             _join(dev, t_stream, pred_u, logits_u_aug, label_u_aug)
         # 3. class-level transition matrix, prior, EMA (train.py:502-545, 556-557)
@@ -222,6 +250,8 @@ class FixMatchNTMStep:
         unsup_loss = unsup_loss * (cfg["unsupervised_loss_weight"] * (bu * n) / thresh_mask.sum())
         loss = sup_loss + unsup_loss + loss_3d
         loss.backward()
+        if at_blocks:
+            inner.segmentor.at_blocks_backward = None
         if cfg["grad_norm_clip"] is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["grad_norm_clip"])
         self.optimizer.step()
