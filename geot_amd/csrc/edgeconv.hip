@@ -317,7 +317,20 @@ __global__ __launch_bounds__(256) void edge_rix_place_kernel(long long total, lo
 // ---- backward 4: d/dP[b,c,n] = sum over the pairs (i,j) with idx[b,i,j] == n of dy_ij ---------------------------
 //   = rstd ( sum_pairs ( a_i [j == jsel_i] + u_i ) - cnt_n (s1 + s2 rstd (P_n - mean)) ),
 //     a_i = gamma dz_i,  u_i = - s2 rstd Q_i        (y_ij = P_n + Q_i)
-// rows a, u (floats) and jsel (bytes) of CH channels live in LDS, computed while they are staged.
+// The rows (a, u) (one float2 per query) and jsel (bytes) of CH channels live in LDS, computed while they are staged.
+// Both phases are written for loads in flight, because one 147-KB workgroup owns the CU and nothing else hides its latency:
+// the staging loop issues EC_SU x 4 row loads before its first LDS store, and the walk takes EC_TG targets per thread at a
+// time -- their list bounds, then the first EC_E pair ids of each list UNCONDITIONALLY (index clamped into the list, value
+// masked), then all LDS reads of the group; only lists longer than EC_E (k = 4: the mean length is 4) run the dependent
+// loop for their tail.  The sum over a list keeps its ascending order, so the result is the one of the plain walk.
+#ifndef GEOT_EC_LAB_TG
+#define GEOT_EC_LAB_TG 4
+#endif
+#ifndef GEOT_EC_LAB_E
+#define GEOT_EC_LAB_E 4
+#endif
+constexpr int EC_TG = GEOT_EC_LAB_TG, EC_E = GEOT_EC_LAB_E, EC_SU = 4;
+
 template <bool K4, int CH>
 __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
     int c, int nq, int nk, int k, int groups, float slope, const float *__restrict__ P, const float *__restrict__ Q,
@@ -326,9 +339,9 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
     const float *__restrict__ grad_out, const int *__restrict__ off, const int *__restrict__ rev,
     float *__restrict__ grad_p)
 {
-    extern __shared__ float ec_rows[]; // [CH][nq] a | [CH][nq] u | [CH][nq] jsel bytes
-    float *A = ec_rows, *U = ec_rows + (size_t)CH * nq;
-    uint8_t *J = reinterpret_cast<uint8_t *>(U + (size_t)CH * nq);
+    extern __shared__ float ec_rows[]; // [CH][nq] (a, u) | [CH][nq] jsel bytes
+    float2 *AU = reinterpret_cast<float2 *>(ec_rows);
+    uint8_t *J = reinterpret_cast<uint8_t *>(AU + (size_t)CH * nq);
     const int bi = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, c - c0);
     float mean[CH], rstd[CH], s1[CH], s2[CH];
 #pragma unroll
@@ -342,42 +355,96 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
 #pragma unroll
     for (int l = 0; l < CH; ++l) {
         if (l < nch) {
-            const float gm = gamma[c0 + l], bt = beta[c0 + l];
+            const float gm = gamma[c0 + l], bt = beta[c0 + l], us = -s2[l] * rstd[l];
             const size_t base = ((size_t)bi * c + c0 + l) * nq;
-            for (int i = threadIdx.x; i < nq; i += EC_THREADS) {
-                const float yh = (ysel[base + i] - mean[l]) * rstd[l];
-                const float z = fmaf(gm, yh, bt);
-                A[(size_t)l * nq + i] = gm * grad_out[base + i] * (z > 0.f ? 1.f : slope);
-                U[(size_t)l * nq + i] = -s2[l] * rstd[l] * Q[base + i];
-                J[(size_t)l * nq + i] = jsel[base + i];
+            for (int i0 = threadIdx.x; i0 < nq; i0 += EC_SU * EC_THREADS) {
+                float ys[EC_SU], go[EC_SU], qq[EC_SU];
+                uint8_t jj[EC_SU];
+#pragma unroll
+                for (int u = 0; u < EC_SU; ++u) {
+                    const int i = min(i0 + u * EC_THREADS, nq - 1);
+                    ys[u] = ysel[base + i];
+                    go[u] = grad_out[base + i];
+                    qq[u] = Q[base + i];
+                    jj[u] = jsel[base + i];
+                }
+#pragma unroll
+                for (int u = 0; u < EC_SU; ++u) {
+                    const int i = i0 + u * EC_THREADS;
+                    if (i < nq) {
+                        const float yh = (ys[u] - mean[l]) * rstd[l];
+                        const float z = fmaf(gm, yh, bt);
+                        AU[(size_t)l * nq + i] = make_float2(gm * go[u] * (z > 0.f ? 1.f : slope), us * qq[u]);
+                        J[(size_t)l * nq + i] = jj[u];
+                    }
+                }
             }
         }
     }
     __syncthreads();
     const int per = (nk + gridDim.x - 1) / gridDim.x;
     const int n0 = blockIdx.x * per, n1 = min(nk, n0 + per);
-    for (int n = n0 + threadIdx.x; n < n1; n += EC_THREADS) {
-        const int a0 = off[(size_t)bi * nk + n], a1 = off[(size_t)bi * nk + n + 1];
-        float acc[CH];
+    const int *offb = off + (size_t)bi * nk;
+    for (int nb = n0 + threadIdx.x; nb < n1; nb += EC_TG * EC_THREADS) {
+        int a0[EC_TG], a1[EC_TG], pid[EC_TG][EC_E];
+        float pv[EC_TG][CH];
 #pragma unroll
-        for (int l = 0; l < CH; ++l) acc[l] = 0.f;
-        for (int e = a0; e < a1; ++e) {
-            const int p = rev[e];
-            const int i = K4 ? (p >> 2) : (p / k), j = K4 ? (p & 3) : (p - i * k);
+        for (int t = 0; t < EC_TG; ++t) {
+            const int n = nb + t * EC_THREADS;
+            const bool live = n < n1;
+            const int nn = live ? n : n1 - 1;
+            a0[t] = offb[nn];
+            a1[t] = live ? offb[nn + 1] : a0[t];          // a dead slot is an empty list
 #pragma unroll
-            for (int l = 0; l < CH; ++l) {
-                if (l < nch) {
-                    const float a = J[(size_t)l * nq + i] == (uint8_t)j ? A[(size_t)l * nq + i] : 0.f;
-                    acc[l] += a + U[(size_t)l * nq + i];
+            for (int l = 0; l < CH; ++l) pv[t][l] = l < nch ? P[((size_t)bi * c + c0 + l) * nk + nn] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < EC_TG; ++t) {
+#pragma unroll
+            for (int e = 0; e < EC_E; ++e) pid[t][e] = rev[max(min(a0[t] + e, a1[t] - 1), 0)];
+        }
+        float acc[EC_TG][CH];
+#pragma unroll
+        for (int t = 0; t < EC_TG; ++t) {
+#pragma unroll
+            for (int l = 0; l < CH; ++l) acc[t][l] = 0.f;
+#pragma unroll
+            for (int e = 0; e < EC_E; ++e) {
+                const int p = pid[t][e];
+                const int i = K4 ? (p >> 2) : (p / k), j = K4 ? (p & 3) : (p - i * k);
+                const bool in = a0[t] + e < a1[t];
+#pragma unroll
+                for (int l = 0; l < CH; ++l) {
+                    if (l < nch) {
+                        const float2 au = AU[(size_t)l * nq + i];
+                        const float v = (J[(size_t)l * nq + i] == (uint8_t)j ? au.x : 0.f) + au.y;
+                        acc[t][l] = in ? acc[t][l] + v : acc[t][l];
+                    }
                 }
             }
         }
-        const float cnt = (float)(a1 - a0);
 #pragma unroll
-        for (int l = 0; l < CH; ++l) {
-            if (l < nch) {
-                const size_t o = ((size_t)bi * c + c0 + l) * nk + n;
-                grad_p[o] = rstd[l] * (acc[l] - cnt * (s1[l] + s2[l] * rstd[l] * (P[o] - mean[l])));
+        for (int t = 0; t < EC_TG; ++t) {
+            for (int e = a0[t] + EC_E; e < a1[t]; ++e) {          // the tail of a long list
+                const int p = rev[e];
+                const int i = K4 ? (p >> 2) : (p / k), j = K4 ? (p & 3) : (p - i * k);
+#pragma unroll
+                for (int l = 0; l < CH; ++l) {
+                    if (l < nch) {
+                        const float2 au = AU[(size_t)l * nq + i];
+                        acc[t][l] += (J[(size_t)l * nq + i] == (uint8_t)j ? au.x : 0.f) + au.y;
+                    }
+                }
+            }
+            const int n = nb + t * EC_THREADS;
+            if (n < n1) {
+                const float cnt = (float)(a1[t] - a0[t]);
+#pragma unroll
+                for (int l = 0; l < CH; ++l) {
+                    if (l < nch)
+                        grad_p[((size_t)bi * c + c0 + l) * nk + n] =
+                            rstd[l] * (acc[t][l] - cnt * (s1[l] + s2[l] * rstd[l] * (pv[t][l] - mean[l])));
+                }
             }
         }
     }
@@ -389,9 +456,13 @@ static int ec_fwd_ch(int nk)
     const int fit = EC_LDS_BYTES / ((int)sizeof(float) * nk);
     return fit >= 8 ? 8 : (fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0)));
 }
+#ifndef GEOT_EC_LAB_CH
+#define GEOT_EC_LAB_CH 4
+#endif
 static int ec_bwd_ch(int nq)
 {
-    const int fit = EC_LDS_BYTES / (9 * nq);
+    int fit = EC_LDS_BYTES / (9 * nq);
+    if (fit > GEOT_EC_LAB_CH) fit = GEOT_EC_LAB_CH;
     return fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0));
 }
 static int ec_slices(int b, int c, int ch, int n)
