@@ -318,11 +318,21 @@ __global__ __launch_bounds__(256) void edge_rix_place_kernel(long long total, lo
 //   = rstd ( sum_pairs ( a_i [j == jsel_i] + u_i ) - cnt_n (s1 + s2 rstd (P_n - mean)) ),
 //     a_i = gamma dz_i,  u_i = - s2 rstd Q_i        (y_ij = P_n + Q_i)
 // The rows (a, u) (one float2 per query) and jsel (bytes) of CH channels live in LDS, computed while they are staged.
+// (Interleaving the channels -- [query][channel], one ds_read_b128 + one u16 per pair for two channels -- measured slower:
+// the strided staging stores cost more than the wider reads save, and CH = 4 spills.  Knock-outs at 8 clouds, c = 512,
+// Nq = 8192, Nk = 4096: of the gradient call's 393 us the walk is 105 -- 55 its pair-id loads, 50 its LDS reads -- the staging
+// 100; first-8 instead of first-4 pair ids, 2 or 8 slots per group, conflict-free addresses for masked reads: all within
+// noise.  profiles/r03_edge_sweep.txt.)
 // Both phases are written for loads in flight, because one 147-KB workgroup owns the CU and nothing else hides its latency:
-// the staging loop issues EC_SU x 4 row loads before its first LDS store, and the walk takes EC_TG targets per thread at a
-// time -- their list bounds, then the first EC_E pair ids of each list UNCONDITIONALLY (index clamped into the list, value
-// masked), then all LDS reads of the group; only lists longer than EC_E (k = 4: the mean length is 4) run the dependent
-// loop for their tail.  The sum over a list keeps its ascending order, so the result is the one of the plain walk.
+// * the staging loop issues EC_SU x 4 row loads before its first LDS store;
+// * the walk gives every target 2^lg adjacent lanes (host: from the mean list length Nq k / Nk, so that a lane's share is
+//   a few times EC_E pairs at most -- 512 sources under 4096 queries x 4 make lists of 32), takes EC_TG (target, lane) slots per thread at
+//   a time, and loads for all of them the list bounds, then the first EC_E pair ids of each share UNCONDITIONALLY (index
+//   clamped into the list, value masked), then does all LDS reads of the group; only a share longer than EC_E runs the
+//   dependent loop for its tail.  The first group's bounds and pair ids are requested BEFORE the staging loop, so two of
+//   the walk's three dependent round trips overlap the row loads.
+// A target's sum has a fixed order (its lanes' shares ascending, then an xor butterfly over the lanes): reproducible; with
+// lg = 0 it is the ascending order of the plain walk.
 #ifndef GEOT_EC_LAB_TG
 #define GEOT_EC_LAB_TG 4
 #endif
@@ -333,7 +343,7 @@ constexpr int EC_TG = GEOT_EC_LAB_TG, EC_E = GEOT_EC_LAB_E, EC_SU = 4;
 
 template <bool K4, int CH>
 __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
-    int c, int nq, int nk, int k, int groups, float slope, const float *__restrict__ P, const float *__restrict__ Q,
+    int c, int nq, int nk, int k, int groups, int lg, float slope, const float *__restrict__ P, const float *__restrict__ Q,
     const float *__restrict__ ysel, const uint8_t *__restrict__ jsel, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ stats, const float *__restrict__ coef,
     const float *__restrict__ grad_out, const int *__restrict__ off, const int *__restrict__ rev,
@@ -343,6 +353,39 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
     float2 *AU = reinterpret_cast<float2 *>(ec_rows);
     uint8_t *J = reinterpret_cast<uint8_t *>(AU + (size_t)CH * nq);
     const int bi = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, c - c0);
+    const int per = (nk + gridDim.x - 1) / gridDim.x;
+    const int n0 = blockIdx.x * per, n1 = min(nk, n0 + per);
+    const int *offb = off + (size_t)bi * nk;
+    const int step = 1 << lg, slot_end = n1 << lg;
+    int slot = (n0 << lg) + threadIdx.x;          // (target, lane) slots: target = slot >> lg, lane of the target = slot & (step - 1)
+
+    int a0[EC_TG], a1[EC_TG], pid[EC_TG][EC_E];
+    float pv[EC_TG][CH], cnt[EC_TG];
+    auto request = [&](int first) {
+#pragma unroll
+        for (int t = 0; t < EC_TG; ++t) {
+            const int sl = first + t * EC_THREADS;
+            const bool live = sl < slot_end;
+            const int n = live ? sl >> lg : max(n1 - 1, 0);
+            const int o0 = offb[n], o1 = offb[n + 1];
+            a0[t] = o0 + (sl & (step - 1));
+            a1[t] = live ? o1 : a0[t];              // a dead slot is an empty share
+            cnt[t] = (float)(o1 - o0);
+#pragma unroll
+            for (int l = 0; l < CH; ++l) pv[t][l] = l < nch ? P[((size_t)bi * c + c0 + l) * nk + n] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < EC_TG; ++t) {
+#pragma unroll
+#ifdef GEOT_EC_LAB_NOREV
+            for (int e = 0; e < EC_E; ++e) pid[t][e] = (a0[t] + (e << lg)) & 8191;
+#else
+            for (int e = 0; e < EC_E; ++e) pid[t][e] = rev[max(min(a0[t] + (e << lg), a1[t] - 1), 0)];
+#endif
+        }
+    };
+    if (n1 > n0) request(slot);
+
     float mean[CH], rstd[CH], s1[CH], s2[CH];
 #pragma unroll
     for (int l = 0; l < CH; ++l) {
@@ -357,7 +400,11 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
         if (l < nch) {
             const float gm = gamma[c0 + l], bt = beta[c0 + l], us = -s2[l] * rstd[l];
             const size_t base = ((size_t)bi * c + c0 + l) * nq;
+#ifdef GEOT_EC_LAB_NOSTAGE
+            for (int i0 = threadIdx.x; i0 < min(nq, 1024); i0 += EC_SU * EC_THREADS) {
+#else
             for (int i0 = threadIdx.x; i0 < nq; i0 += EC_SU * EC_THREADS) {
+#endif
                 float ys[EC_SU], go[EC_SU], qq[EC_SU];
                 uint8_t jj[EC_SU];
 #pragma unroll
@@ -382,28 +429,13 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
         }
     }
     __syncthreads();
-    const int per = (nk + gridDim.x - 1) / gridDim.x;
-    const int n0 = blockIdx.x * per, n1 = min(nk, n0 + per);
-    const int *offb = off + (size_t)bi * nk;
-    for (int nb = n0 + threadIdx.x; nb < n1; nb += EC_TG * EC_THREADS) {
-        int a0[EC_TG], a1[EC_TG], pid[EC_TG][EC_E];
-        float pv[EC_TG][CH];
-#pragma unroll
-        for (int t = 0; t < EC_TG; ++t) {
-            const int n = nb + t * EC_THREADS;
-            const bool live = n < n1;
-            const int nn = live ? n : n1 - 1;
-            a0[t] = offb[nn];
-            a1[t] = live ? offb[nn + 1] : a0[t];          // a dead slot is an empty list
-#pragma unroll
-            for (int l = 0; l < CH; ++l) pv[t][l] = l < nch ? P[((size_t)bi * c + c0 + l) * nk + nn] : 0.f;
-        }
-#pragma unroll
-        for (int t = 0; t < EC_TG; ++t) {
-#pragma unroll
-            for (int e = 0; e < EC_E; ++e) pid[t][e] = rev[max(min(a0[t] + e, a1[t] - 1), 0)];
-        }
+    if (n1 <= n0) return;
+    while (true) {
         float acc[EC_TG][CH];
+#ifdef GEOT_EC_LAB_NOWALK
+#pragma unroll
+        for (int t = 0; t < EC_TG; ++t) { a1[t] = a0[t]; }
+#endif
 #pragma unroll
         for (int t = 0; t < EC_TG; ++t) {
 #pragma unroll
@@ -411,13 +443,17 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
 #pragma unroll
             for (int e = 0; e < EC_E; ++e) {
                 const int p = pid[t][e];
+                const bool in = a0[t] + (e << lg) < a1[t];
                 const int i = K4 ? (p >> 2) : (p / k), j = K4 ? (p & 3) : (p - i * k);
-                const bool in = a0[t] + e < a1[t];
 #pragma unroll
                 for (int l = 0; l < CH; ++l) {
                     if (l < nch) {
+#ifdef GEOT_EC_LAB_NOLDSREAD
+                        const float v = __int_as_float(i + j + l);
+#else
                         const float2 au = AU[(size_t)l * nq + i];
                         const float v = (J[(size_t)l * nq + i] == (uint8_t)j ? au.x : 0.f) + au.y;
+#endif
                         acc[t][l] = in ? acc[t][l] + v : acc[t][l];
                     }
                 }
@@ -425,28 +461,44 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
         }
 #pragma unroll
         for (int t = 0; t < EC_TG; ++t) {
-            for (int e = a0[t] + EC_E; e < a1[t]; ++e) {          // the tail of a long list
+            for (int e = a0[t] + (EC_E << lg); e < a1[t]; e += step) {          // the tail of a long share
+#ifdef GEOT_EC_LAB_NOREV
+                const int p = e & 8191;
+#else
                 const int p = rev[e];
+#endif
                 const int i = K4 ? (p >> 2) : (p / k), j = K4 ? (p & 3) : (p - i * k);
 #pragma unroll
                 for (int l = 0; l < CH; ++l) {
                     if (l < nch) {
+#ifdef GEOT_EC_LAB_NOLDSREAD
+                        acc[t][l] += __int_as_float(i + j + l);
+#else
                         const float2 au = AU[(size_t)l * nq + i];
                         acc[t][l] += (J[(size_t)l * nq + i] == (uint8_t)j ? au.x : 0.f) + au.y;
+#endif
                     }
                 }
             }
-            const int n = nb + t * EC_THREADS;
-            if (n < n1) {
-                const float cnt = (float)(a1[t] - a0[t]);
+            // the lanes of one target are adjacent and all of them are here (same target, same liveness)
+            for (int d = 1; d < step; d <<= 1) {
+#pragma unroll
+                for (int l = 0; l < CH; ++l) acc[t][l] += __shfl_xor(acc[t][l], d);
+            }
+            const int sl = slot + t * EC_THREADS;
+            if (sl < slot_end && (sl & (step - 1)) == 0) {
+                const int n = sl >> lg;
 #pragma unroll
                 for (int l = 0; l < CH; ++l) {
                     if (l < nch)
                         grad_p[((size_t)bi * c + c0 + l) * nk + n] =
-                            rstd[l] * (acc[t][l] - cnt * (s1[l] + s2[l] * rstd[l] * (pv[t][l] - mean[l])));
+                            rstd[l] * (acc[t][l] - cnt[t] * (s1[l] + s2[l] * rstd[l] * (pv[t][l] - mean[l])));
                 }
             }
         }
+        slot += EC_TG * EC_THREADS;
+        if (slot >= slot_end) break;
+        request(slot);
     }
 }
 
@@ -464,6 +516,18 @@ static int ec_bwd_ch(int nq)
     int fit = EC_LDS_BYTES / (9 * nq);
     if (fit > GEOT_EC_LAB_CH) fit = GEOT_EC_LAB_CH;
     return fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0));
+}
+// lanes per target in the dP walk (log2): a lane's share of the mean list is about EC_E pairs
+static int ec_lanes_log2(int nq, int nk, int k)
+{
+#ifdef GEOT_EC_LAB_LG
+    return GEOT_EC_LAB_LG;
+#else
+    const long long mean_len = ((long long)nq * k + nk - 1) / nk;
+    int lg = 0;
+    while (lg < 3 && (long long)(3 * EC_E) << lg < mean_len) ++lg;      // measured: a mean of 8 is best left to one lane
+    return lg;
+#endif
 }
 static int ec_slices(int b, int c, int ch, int n)
 {
@@ -627,11 +691,12 @@ static int ec_grad(int b, int c, int nq, int nk, int k, int groups, float slope,
     const size_t lds = (size_t)ch * nq * 9;
     const dim3 grid(pslices, (c + ch - 1) / ch, b);
     const bool k4 = k == 4;
+    const int lg = ec_lanes_log2(nq, nk, k);
 #define GEOT_EC_BWD(KV, CHV)                                                                                       \
     {                                                                                                              \
         e = ec_allow_lds(edge_bwd_p_kernel<KV, CHV>, lds);                                                         \
         if (e != hipSuccess) return e;                                                                             \
-        hipLaunchKernelGGL((edge_bwd_p_kernel<KV, CHV>), grid, dim3(EC_THREADS), lds, s, c, nq, nk, k, groups, slope, \
+        hipLaunchKernelGGL((edge_bwd_p_kernel<KV, CHV>), grid, dim3(EC_THREADS), lds, s, c, nq, nk, k, groups, lg, slope, \
                            P, Q, ysel, jsel, gamma, beta, stats, coef, grad_out, off, rev, grad_p);                \
     }
     if (k4) {

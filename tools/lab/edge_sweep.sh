@@ -2,16 +2,15 @@
 # lab: the dP kernel of the EdgeConv gradient -- the round-2 kernel against the pipelined walk, group sizes and channels per workgroup
 set -o pipefail
 run() { timeout -k 10 300 python tools/lab/edge_time.py 2>&1 | grep -v amdgpu.ids; }
-if [ -f tools/_lab/edgeconv_old.hip ]; then
+if [ -f tools/_lab/edgeconv_old.hip ] && [ -z "$SKIP_OLD" ]; then
   cp geot_amd/csrc/edgeconv.hip /tmp/edgeconv_new.hip
   cp tools/_lab/edgeconv_old.hip geot_amd/csrc/edgeconv.hip
   python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
   echo "== round-2 kernel"; run
   cp /tmp/edgeconv_new.hip geot_amd/csrc/edgeconv.hip
 fi
-for v in "4 4 4" "2 4 4" "8 4 4" "4 3 4" "4 6 4" "4 4 2" "4 4 1"; do
-  set -- $v
-  GEOT_EXTRA_HIPCC_FLAGS="-DGEOT_EC_LAB_TG=$1 -DGEOT_EC_LAB_E=$2 -DGEOT_EC_LAB_CH=$3" python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
-  echo "== TG $1 E $2 CH<= $3"; run
+for v in "" "-DGEOT_EC_LAB_LG=0" "-DGEOT_EC_LAB_TG=8" "-DGEOT_EC_LAB_E=8 -DGEOT_EC_LAB_TG=2" "-DGEOT_EC_LAB_NOWALK" "-DGEOT_EC_LAB_NOSTAGE" "-DGEOT_EC_LAB_NOLDSREAD" "-DGEOT_EC_LAB_NOREV"; do
+  GEOT_EXTRA_HIPCC_FLAGS="$v" python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
+  echo "== flags: ${v:-default (TG 4, E 4, lanes per target from the mean list length)}"; run
 done
 python -m geot_amd.build --force > /dev/null 2>&1
