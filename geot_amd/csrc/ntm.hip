@@ -159,15 +159,50 @@ struct SigMfma {
     static_assert(KP % 2 == 0, "K must be even for the 32x32x2 MFMA");
 };
 
-template <int C, bool BACKWARD>
-__global__ __launch_bounds__(256, BACKWARD ? 2 : 4) void sig_t_mean_mfma_kernel(
+// The backward keeps the NEXT tile's incoming gradients in flight in registers through the whole tile (loads unconditional,
+// indices clamped into the buffer, issued behind this tile's input loads so that the MFMAs wait with a counted vmcnt): with
+// the copy at the top of the tile a block had one 37-KB tile in flight and waited for it.  183 -> 154 us at 8 clouds
+// (1.5 TB/s).  What bounds it now is not HBM: per tile a wave issues 75 MFMAs of 64 cycles (the second GEMM uses 18 of its
+// 32 rows), ~600 VALU instructions of row arithmetic in three passes (544 rows on 256 threads) and three barriers, at two
+// waves per SIMD (229 registers, 77 KB of LDS per block).  512-thread blocks -- two column tiles per wave at most, the row
+// phase in two passes -- measured SLOWER: 222 us at one block per CU (244 registers), 445 us held to 128 registers for two
+// blocks per CU (181 spilled).  profiles/r03_sig_sweep.txt.
+#ifndef GEOT_SIG_LAB_BWD_THREADS
+#define GEOT_SIG_LAB_BWD_THREADS 256
+#endif
+constexpr int SIG_BWD_THREADS = GEOT_SIG_LAB_BWD_THREADS;
+#ifndef GEOT_SIG_LAB_BWD_WPS
+#define GEOT_SIG_LAB_BWD_WPS 2
+#endif
+constexpr int SIG_BWD_WPS = GEOT_SIG_LAB_BWD_WPS;
+
+// GV float4 per thread of the gradient tile that starts at float4 index base4: loads unconditional, index clamped to the
+// last whole float4 of the buffer (a clamped value is never used)
+typedef float ntm_f32x4 __attribute__((ext_vector_type(4)));   // (HIP's float4 struct in an array stays in scratch memory)
+template <int GV, int NT>
+__device__ __forceinline__ void sig_fetch_tile(ntm_f32x4 (&pre)[GV], const float *__restrict__ grad_out, long long base4, long long last4,
+                                               int tid)
+{
+    const ntm_f32x4 *src4 = reinterpret_cast<const ntm_f32x4 *>(grad_out);
+#pragma unroll
+    for (int v = 0; v < GV; ++v) {
+        long long e = base4 + tid + v * NT;
+        e = e < last4 ? e : last4;
+        pre[v] = src4[e];
+    }
+}
+
+template <int C, bool BACKWARD, int NT>
+__global__ __launch_bounds__(NT, BACKWARD ? SIG_BWD_WPS : 4) void sig_t_mean_mfma_kernel(   // second figure: waves per SIMD
     int total_pts, int n, const float *__restrict__ p, const float *__restrict__ W,
     const float *__restrict__ cm, const float *__restrict__ grad_out, float *__restrict__ out,
     float *__restrict__ partial)
 {
     using S = SigMfma<C>;
     constexpr int CC = S::CC, KP = S::KP, NCT = S::NCT, ATS = S::AT_STRIDE;
-    constexpr int MYCT = (NCT + 3) / 4; // column tiles per wave (3, 3, 2, 2)
+    constexpr int NW = NT / 64;
+    constexpr int MYCT = (NCT + NW - 1) / NW; // column tiles per wave (4 waves: 3, 3, 2, 2; 8 waves: 2, 2, 1 ...)
+    constexpr int GV = (SM_PTS * CC / 4 + NT - 1) / NT; // float4 of a full gradient tile per thread
     extern __shared__ float ntm_lds[];
     float *tile = ntm_lds;            // [SM_PTS][CC]  (contiguous = the global layout of the block)
     float *At = tile + SM_PTS * CC;   // [SM_PTS][ATS] (+ slack: the padded columns of the last row read past `tile`); BACKWARD only
@@ -179,8 +214,8 @@ __global__ __launch_bounds__(256, BACKWARD ? 2 : 4) void sig_t_mean_mfma_kernel(
     float bw[KP / 2][MYCT];
 #pragma unroll
     for (int t = 0; t < MYCT; ++t) {
-        const int col = (wave + 4 * t) * 32 + r;
-        const bool live = wave + 4 * t < NCT && col < CC;
+        const int col = (wave + NW * t) * 32 + r;
+        const bool live = wave + NW * t < NCT && col < CC;
 #pragma unroll
         for (int ks = 0; ks < KP / 2; ++ks) {
             const int k = 2 * ks + h;
@@ -196,36 +231,71 @@ __global__ __launch_bounds__(256, BACKWARD ? 2 : 4) void sig_t_mean_mfma_kernel(
         }
     }
     if (BACKWARD) {
-        for (int e = tid; e < SM_PTS * ATS + 64; e += 256) At[e] = 0.f;
+        for (int e = tid; e < SM_PTS * ATS + 64; e += NT) At[e] = 0.f;
     }
     ntm_f32x16 gacc[MYCT];
 #pragma unroll
     for (int t = 0; t < MYCT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) gacc[t][e] = 0.f;
+
+    // BACKWARD: the gradient tile of the block's next full tile, in registers (a partial last tile is copied directly)
+    ntm_f32x4 pre[GV];
+    const long long g_last4 = BACKWARD ? ((long long)total_pts * CC) / 4 - 1 : 0;   // last whole float4 of grad_out (>= 0: CC >= 4)
+    auto fetch = [&](long long i0) { sig_fetch_tile<GV, NT>(pre, grad_out, i0 * CC / 4, g_last4, tid); };   // i0 % 32 == 0: whole float4s
+    bool have_pre = false;
+    if (BACKWARD) {
+        const long long first = (long long)blockIdx.x * SM_PTS;
+        have_pre = first + SM_PTS <= total_pts;
+#ifdef GEOT_SIG_LAB_NOPREFETCH
+        have_pre = false;
+#endif
+        fetch(have_pre ? first : 0);
+    }
     __syncthreads();
 
     for (int i0 = blockIdx.x * SM_PTS; i0 < total_pts; i0 += gridDim.x * SM_PTS) {
         const int cnt = min(SM_PTS, total_pts - i0);
         if (BACKWARD) {
-            // (17 scalar loads per (point, row) thread straight from global touched 32 cache lines per instruction)
-            const float *src = grad_out + (size_t)i0 * CC; // 16-byte aligned: i0 is a multiple of 32
-            const int total = cnt * CC, vec = total >> 2;
-            for (int e = tid; e < vec; e += 256)
-                reinterpret_cast<float4 *>(gtile)[e] = reinterpret_cast<const float4 *>(src)[e];
-            for (int e = (vec << 2) + tid; e < total; e += 256) gtile[e] = src[e];
+            if (have_pre) {
+#pragma unroll
+                for (int v = 0; v < GV; ++v) {
+                    const int e = tid + v * NT;
+                    if (e < SM_PTS * CC / 4) reinterpret_cast<ntm_f32x4 *>(gtile)[e] = pre[v];
+                }
+            } else {
+                // (17 scalar loads per (point, row) thread straight from global touched 32 cache lines per instruction)
+                const float *src = grad_out + (size_t)i0 * CC; // 16-byte aligned: i0 is a multiple of 32
+                const int total = cnt * CC, vec = total >> 2;
+                for (int e = tid; e < vec; e += NT)
+                    reinterpret_cast<float4 *>(gtile)[e] = reinterpret_cast<const float4 *>(src)[e];
+                for (int e = (vec << 2) + tid; e < total; e += NT) gtile[e] = src[e];
+            }
         }
-        // A fragment: lane (r = point, h) holds A[r][2*ks + h]
+        // A fragment: lane (r = point, h) holds A[r][2*ks + h]  (loads unconditional: index clamped, value selected)
         float a[KP / 2];
         {
-            const int i = i0 + r;
             const bool ok = r < cnt;
-            const int b = ok ? i / n : 0, ni = ok ? i - b * n : 0;
+            const int i = min(i0 + r, total_pts - 1);
+            const int b = i / n, ni = i - b * n;
 #pragma unroll
             for (int ks = 0; ks < KP / 2; ++ks) {
                 const int k = 2 * ks + h;
-                a[ks] = !ok ? 0.f : (k < C ? p[((size_t)b * C + k) * n + ni] : 1.f);
-                if (BACKWARD && wave == 0) At[r * ATS + k] = a[ks];
+                const float v = p[((size_t)b * C + min(k, C - 1)) * n + ni];
+                a[ks] = !ok ? 0.f : (k < C ? v : 1.f);
+            }
+        }
+        if (BACKWARD) {
+            const long long next = (long long)i0 + (long long)gridDim.x * SM_PTS;
+            have_pre = next + SM_PTS <= total_pts;
+#ifdef GEOT_SIG_LAB_NOPREFETCH
+            have_pre = false;
+#else
+            fetch(have_pre ? next : 0);                   // stays in flight until the top of the next tile
+#endif
+            if (wave == 0) {
+#pragma unroll
+                for (int ks = 0; ks < KP / 2; ++ks) At[r * ATS + 2 * ks + h] = a[ks];
             }
         }
         ntm_f32x16 acc[MYCT];
@@ -238,22 +308,22 @@ __global__ __launch_bounds__(256, BACKWARD ? 2 : 4) void sig_t_mean_mfma_kernel(
         for (int ks = 0; ks < KP / 2; ++ks) {
 #pragma unroll
             for (int t = 0; t < MYCT; ++t) {
-                const int ct = wave + 4 * t;
+                const int ct = wave + NW * t;
                 if (ct < NCT) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks], bw[ks][t], acc[t], 0, 0, 0);
             }
         }
         // D layout of the 32x32 tile: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * h
 #pragma unroll
         for (int t = 0; t < MYCT; ++t) {
-            const int col = (wave + 4 * t) * 32 + r;
-            if (wave + 4 * t < NCT && col < CC) {
+            const int col = (wave + NW * t) * 32 + r;
+            if (wave + NW * t < NCT && col < CC) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) tile[((e & 3) + 8 * (e >> 2) + 4 * h) * CC + col] = acc[t][e];
             }
         }
         __syncthreads();
         // (point, row) threads: clamp + L1-normalise (forward) or d raw (backward), in place
-        for (int rr = tid; rr < SM_PTS * C; rr += 256) {
+        for (int rr = tid; rr < SM_PTS * C; rr += NT) {
             const int pt = rr & (SM_PTS - 1), kk = rr >> 5;
             float *row = tile + pt * CC + kk * C;
             float raw[C], s = 0.f;
@@ -291,18 +361,18 @@ __global__ __launch_bounds__(256, BACKWARD ? 2 : 4) void sig_t_mean_mfma_kernel(
         if (!BACKWARD) {
             float *dst = out + (size_t)i0 * CC; // 16-byte aligned: i0 is a multiple of 32
             const int total = cnt * CC, vec = total >> 2;
-            for (int e = tid; e < vec; e += 256)
+            for (int e = tid; e < vec; e += NT)
                 reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(tile)[e];
-            for (int e = (vec << 2) + tid; e < total; e += 256) dst[e] = tile[e];
+            for (int e = (vec << 2) + tid; e < total; e += NT) dst[e] = tile[e];
         } else {
             // G[k][col] += sum_pt A[pt][k] * draw[pt][col]:  M = k (rows r < 18 used), K = point
-#pragma unroll
+#pragma unroll 4
             for (int ks = 0; ks < SM_PTS / 2; ++ks) {
                 const int pt = 2 * ks + h;
                 const float av = r < KP ? At[pt * ATS + r] : 0.f;
 #pragma unroll
                 for (int t = 0; t < MYCT; ++t) {
-                    const int ct = wave + 4 * t;
+                    const int ct = wave + NW * t;
                     if (ct < NCT) {
                         const float bv = tile[pt * CC + ct * 32 + r]; // cols >= 289: junk, discarded below
                         gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, gacc[t], 0, 0, 0);
@@ -316,8 +386,8 @@ __global__ __launch_bounds__(256, BACKWARD ? 2 : 4) void sig_t_mean_mfma_kernel(
         float *P = partial + (size_t)blockIdx.x * KP * CC;
 #pragma unroll
         for (int t = 0; t < MYCT; ++t) {
-            const int col = (wave + 4 * t) * 32 + r;
-            if (wave + 4 * t < NCT && col < CC) {
+            const int col = (wave + NW * t) * 32 + r;
+            if (wave + NW * t < NCT && col < CC) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int k = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -1098,9 +1168,9 @@ GEOT_EXPORT int geot_ntm_sig_t_mean(int b, int n, int c, const float *p, const f
     if (c != GEOT_NTM_C) return gen_sig_t_mean(false, b, n, c, p, W, cm, nullptr, ins_T, (hipStream_t)stream);
     constexpr int C = GEOT_NTM_C;
     size_t lds = (size_t)SigMfma<C>::LDS_FLOATS_FWD * sizeof(float);
-    hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, false>, lds);
+    hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, false, 256>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, false>), dim3(sig_mfma_blocks((long long)b * n, SIG_FWD_PER_CU)), dim3(256), lds,
+    hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, false, 256>), dim3(sig_mfma_blocks((long long)b * n, SIG_FWD_PER_CU)), dim3(256), lds,
                        (hipStream_t)stream, b * n, n, p, W, cm, nullptr, ins_T, nullptr);
     return hipGetLastError();
 }
@@ -1119,11 +1189,11 @@ GEOT_EXPORT int geot_ntm_sig_t_mean_grad_w(int b, int n, int c, const float *p, 
     if ((long long)b * n == 0) return hipSuccess;
     constexpr int C = GEOT_NTM_C;
     size_t lds = (size_t)SigMfma<C>::LDS_FLOATS_BWD * sizeof(float);
-    hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, true>, lds);
+    hipError_t e = set_lds(sig_t_mean_mfma_kernel<C, true, SIG_BWD_THREADS>, lds);
     if (e != hipSuccess) return e;
     const int nblk = sig_mfma_blocks((long long)b * n, SIG_BWD_PER_CU);
-    hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, true>), dim3(nblk), dim3(256), lds, (hipStream_t)stream, b * n, n,
-                       p, W, cm, grad_ins_T, nullptr, workspace);
+    hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, true, SIG_BWD_THREADS>), dim3(nblk), dim3(SIG_BWD_THREADS), lds, (hipStream_t)stream,
+                       b * n, n, p, W, cm, grad_ins_T, nullptr, workspace);
     hipLaunchKernelGGL((sig_t_mean_wgrad_reduce_kernel<C>), dim3(((C + 1) * C * C + 255) / 256, (nblk + 31) / 32), dim3(256), 0,
                        (hipStream_t)stream, nblk, workspace, cm, grad_W);
     return hipGetLastError();
