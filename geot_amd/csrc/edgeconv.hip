@@ -29,15 +29,17 @@ constexpr int EC_LDS_BYTES = 150 * 1024; // of the CU's 160 KB
 __device__ __forceinline__ void ec_load_row(float *__restrict__ dst, const float *__restrict__ src, int count)
 {
     const int tid = threadIdx.x;
-    if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0) {
+    if (((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0 && count >= 4) {
         const int vec = count >> 2;
         const float4 *s4 = reinterpret_cast<const float4 *>(src);
         float4 *d4 = reinterpret_cast<float4 *>(dst);
-        for (int e = tid; e < vec; e += 2 * EC_THREADS) {
-            const float4 a = s4[e];
-            const float4 b = e + EC_THREADS < vec ? s4[e + EC_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f);
-            d4[e] = a;
-            if (e + EC_THREADS < vec) d4[e + EC_THREADS] = b;
+        for (int e = tid; e < vec; e += 4 * EC_THREADS) {      // four loads in flight, unconditional (index clamped)
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = s4[min(e + u * EC_THREADS, vec - 1)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e + u * EC_THREADS < vec) d4[e + u * EC_THREADS] = v[u];
         }
         for (int e = (vec << 2) + tid; e < count; e += EC_THREADS) dst[e] = src[e];
     } else {
@@ -73,6 +75,62 @@ __global__ __launch_bounds__(EC_THREADS) void edge_fwd_kernel(
     float s[CH], ss[CH];
 #pragma unroll
     for (int l = 0; l < CH; ++l) s[l] = ss[l] = 0.f;
+    if (K4 && nch == CH) {
+        // The configured case, written for loads in flight: the indices and the CH values of Q of the NEXT query are requested
+        // (unconditionally, index clamped) before this query's 3 CH stores are issued, so the wait at the top of the loop is a
+        // counted vmcnt that leaves the stores in flight.  (The plain loop below loads Q[o] per channel behind the previous
+        // channel's stores: every load waited for those stores to be acknowledged -- 2.8 TB/s.)
+        const size_t qb = ((size_t)bi * c + c0) * nq;
+        const int4 *idx4 = reinterpret_cast<const int4 *>(idx) + (size_t)bi * nq;
+        int i = i0 + threadIdx.x;
+        if (i < i1) {
+            int4 n4 = idx4[i];
+            float qv[CH];
+#pragma unroll
+            for (int l = 0; l < CH; ++l) qv[l] = Q[qb + (size_t)l * nq + i];
+            // the first query's loads land before the loop: a pending load at the loop's entry would merge with the back edge's
+            // pending stores into waits that drain the stores every iteration
+            __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+            for (; i < i1; i += EC_THREADS) {
+                const int in = min(i + EC_THREADS, i1 - 1);
+                const int4 n4n = idx4[in];
+                float qn[CH];
+#pragma unroll
+                for (int l = 0; l < CH; ++l) qn[l] = Q[qb + (size_t)l * nq + in];
+                float pv[CH][4];
+#pragma unroll
+                for (int l = 0; l < CH; ++l) {
+                    const float *R = ec_rows + l * nk;
+                    pv[l][0] = R[n4.x];
+                    pv[l][1] = R[n4.y];
+                    pv[l][2] = R[n4.z];
+                    pv[l][3] = R[n4.w];
+                }
+#pragma unroll
+                for (int l = 0; l < CH; ++l) {
+                    float best = 0.f, sum = 0.f;
+                    int bj = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float y = pv[l][j] + qv[l];
+                        sum += y;
+                        ss[l] = fmaf(y, y, ss[l]);
+                        const bool take = j == 0 || (want_max[l] ? y > best : y < best); // first extremum wins
+                        best = take ? y : best;
+                        bj = take ? j : bj;
+                    }
+                    s[l] += sum;
+                    const size_t o = qb + (size_t)l * nq + i;
+                    ysel[o] = best;
+                    ysum[o] = sum;
+                    jsel[o] = (uint8_t)bj;
+                }
+                n4 = n4n;
+#pragma unroll
+                for (int l = 0; l < CH; ++l) qv[l] = qn[l];
+            }
+        }
+    } else
     for (int i = i0 + threadIdx.x; i < i1; i += EC_THREADS) {
         const size_t row = (size_t)bi * nq + i;
         if (K4) {
@@ -503,9 +561,13 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
+#ifndef GEOT_EC_LAB_FCH
+#define GEOT_EC_LAB_FCH 8
+#endif
 static int ec_fwd_ch(int nk)
 {
-    const int fit = EC_LDS_BYTES / ((int)sizeof(float) * nk);
+    int fit = EC_LDS_BYTES / ((int)sizeof(float) * nk);
+    if (fit > GEOT_EC_LAB_FCH) fit = GEOT_EC_LAB_FCH;
     return fit >= 8 ? 8 : (fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0)));
 }
 #ifndef GEOT_EC_LAB_CH
