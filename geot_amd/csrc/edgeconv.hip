@@ -236,6 +236,20 @@ __global__ __launch_bounds__(256) void edge_out_kernel(int c, int nq, int groups
     const float mean = stats[2 * (bi * groups + g)], rstd = stats[2 * (bi * groups + g) + 1];
     const float a = gamma[cc] * rstd, b2 = beta[cc] - mean * a;
     const size_t base = ((size_t)bi * c + cc) * nq;
+    if ((nq & 3) == 0 && ((((uintptr_t)ysel) | ((uintptr_t)out)) & 15) == 0) {       // 16-byte vectors
+        const float4 *src = reinterpret_cast<const float4 *>(ysel + base);
+        float4 *dst = reinterpret_cast<float4 *>(out + base);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (nq >> 2); i += gridDim.x * 256) {
+            const float4 y = src[i];
+            float4 z = make_float4(fmaf(y.x, a, b2), fmaf(y.y, a, b2), fmaf(y.z, a, b2), fmaf(y.w, a, b2));
+            z.x = z.x > 0.f ? z.x : slope * z.x;
+            z.y = z.y > 0.f ? z.y : slope * z.y;
+            z.z = z.z > 0.f ? z.z : slope * z.z;
+            z.w = z.w > 0.f ? z.w : slope * z.w;
+            dst[i] = z;
+        }
+        return;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
         const float z = fmaf(ysel[base + i], a, b2);
         out[base + i] = z > 0.f ? z : slope * z;
@@ -561,12 +575,16 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
 }
 
 // ---- host side --------------------------------------------------------------------------------------------------
+// channels per forward workgroup: rows of P within 64 KB of LDS so that two workgroups share a CU (one's staging under the
+// other's streaming) and at most 4 (measured at 8 clouds, Nk = 512 / 4096 / 8192: 8 channels = 131 KB, one workgroup per
+// CU, 492 us per step; <= 4: 466; <= 2: 448 -- profiles/r03_edge_sweep.txt); longer rows take what the CU's LDS holds
 #ifndef GEOT_EC_LAB_FCH
-#define GEOT_EC_LAB_FCH 8
+#define GEOT_EC_LAB_FCH 4
 #endif
 static int ec_fwd_ch(int nk)
 {
-    int fit = EC_LDS_BYTES / ((int)sizeof(float) * nk);
+    int fit = 64 * 1024 / ((int)sizeof(float) * nk);
+    if (fit < 1) fit = EC_LDS_BYTES / ((int)sizeof(float) * nk);
     if (fit > GEOT_EC_LAB_FCH) fit = GEOT_EC_LAB_FCH;
     return fit >= 8 ? 8 : (fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0)));
 }
@@ -661,7 +679,7 @@ GEOT_EXPORT int geot_edgeconv_gn_max(int b, int c, int nq, int nk, int k, int gr
     if (e != hipSuccess) return e;
     const double count = (double)(c / groups) * nq * k;
     hipLaunchKernelGGL(edge_stats_kernel, dim3(b * groups), dim3(256), 0, s, c, groups, slices, count, eps, partial, stats);
-    int gx = (nq + 1023) / 1024;
+    int gx = (nq + 2047) / 2048;
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(edge_out_kernel, dim3(gx, c, b), dim3(256), 0, s, c, nq, groups, slope, ysel, gamma, beta, stats, out);
     return hipGetLastError();
