@@ -487,7 +487,7 @@ def main():
         unpatch += gemm_timer.hook(model.propogation_0.mlp.layer1.conv)
         import geot_amd.openpoints.models.backbone.transformer as tr_mod
         orig_from_cl = tr_mod.pointwise_from_cl
-        gemm_timer.only = lambda w, z: tuple(w.shape) == (384, 1536) and z.shape[1] == N_POINTS
+        gemm_timer.only = lambda w, z, **kw: tuple(w.shape) == (384, 1536) and z.shape[1] == N_POINTS
         tr_mod.pointwise_from_cl = gemm_timer.wrap(orig_from_cl)
     if workload == "sa" and not args.graph:
         import geot_amd.sa_fused as sa_fused_mod
