@@ -166,7 +166,8 @@ class FixMatchNTMStep:
         self._geometry = (None, None)      # coordinate-only work of the next student / teacher batch (look-ahead)
         self._geometry_src = None
         self._teacher_stream = None
-        self.overlap_teacher = True    # the frozen teacher's forward on its own stream beside the student's (same results)
+        # the frozen teacher's forward on its own stream beside the student's (same results; GEOT_TEACHER_STREAM=0: in line)
+        self.overlap_teacher = os.environ.get("GEOT_TEACHER_STREAM", "1") != "0"
 
     def __call__(self, data, data_u, next_batches=None):
         """data: labelled batch {pos (B_l,N,3), x (B_l,3,N), cls (B_l,1), y (B_l,N)}; data_u: unlabelled batch
