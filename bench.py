@@ -181,7 +181,17 @@ def pmc_traffic(kernel, tag):
         prof = json.load(f)
     for name, rec in prof.get("kernels", {}).items():
         if kernel in name:
-            return rec.get("traffic_bytes"), {"file": os.path.relpath(files[-1], ROOT), "commit": prof.get("commit")}
+            source = {"file": os.path.relpath(files[-1], ROOT), "commit": prof.get("commit")}
+            # the kernel's source file as profiled against the one this run was built from (None: the profile predates the field)
+            import hashlib
+            base = re.split(r"[<(]", kernel)[0].split("::")[-1].strip()
+            unchanged = None
+            for fn, sha in prof.get("csrc_sha16", {}).items():
+                path = os.path.join(ROOT, "geot_amd", "csrc", fn)
+                if fn.endswith(".hip") and os.path.exists(path) and base and base in open(path).read():
+                    unchanged = hashlib.sha256(open(path, "rb").read()).hexdigest()[:16] == sha
+            source["kernel_source_unchanged"] = unchanged
+            return rec.get("traffic_bytes"), source
     return None, None
 
 

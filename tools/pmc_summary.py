@@ -44,7 +44,14 @@ def main():
         except OSError:
             commit = None
         commit = os.environ.get("GEOT_COMMIT", commit)
-        json.dump({"command": cmd, "commit": commit, "unit": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes); traffic_bytes = "
+        # sha256 (16 hex digits) of every kernel source at the time of the profile: bench.py compares them with the tree it
+        # runs from, so a figure whose kernel has changed since is flagged instead of silently quoted
+        import glob
+        import hashlib
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        src = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()[:16]
+               for f in sorted(glob.glob(os.path.join(root, "geot_amd", "csrc", "*.h*")))}
+        json.dump({"command": cmd, "commit": commit, "csrc_sha16": src, "unit": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate passes); traffic_bytes = "
                    "(2 x FETCH_SIZE + WRITE_SIZE) KB: FETCH doubled per the gfx950 rule in MI355X_MICROARCH.md (HBM section)",
                    "kernels": kernels}, open(out, "w"), indent=1)
     elif sys.argv[1] == "sq":
