@@ -129,7 +129,8 @@ while done < CASES:
     # reproducible bit for bit; geot_common.h)
     longest = int(torch.bincount((idx.long() + torch.arange(b, device=DEV).view(b, 1, 1) * m).reshape(-1), minlength=b * m).max())
     same = torch.equal(z2, res["fused"][0]) and (longest > 4096 or torch.equal(a_r.grad, res["fused"][1]))
-    tol = 3e-5 if mode in ("hub", "one") else 2e-5          # a hub sums thousands of terms in fp32
+    # a list of N pairs is summed in fp32 in list order: error grows like sqrt(N) eps x (sum |terms| / |result|)
+    tol = 1e-4 if longest > 2000 else (5e-5 if longest > 256 else 2e-5)
     bad = {k: v for k, v in errs.items() if v > (1e-5 if k.endswith(" z") else tol)}
     for k, v in errs.items():
         key = k.split(" ", 1)[1]
