@@ -1231,6 +1231,95 @@ __global__ __launch_bounds__(256) void invert_order_kernel(long long total, int 
     rank_of[bi * m + order[x]] = (int)(x - bi * m);
 }
 
+// ---- which pairs a workgroup of the row gathers walks ---------------------------------------------------------------------
+// A source row is one of the three neighbours of THREE targets, and those targets are neighbours in the Morton order the
+// lists are stored in.  With one contiguous share of the pair stream per workgroup (round 3, first form) the three uses of
+// a row were three trips to memory: the uses sit tens of pairs apart, a CU's share of its XCD's 4-MB L2 is ~128 KB (ten
+// pairs of 6-KB rows), and neighbouring shares ran on other XCDs -- rocprofv3 FETCH_SIZE 3.0x the algorithmic bytes.  So
+// the targets are dealt like the rows of the forward (channels_last.hip): XCD x (blocks x, x + 8, ...) takes the x-th
+// eighth of the target sequence, and inside it workgroup w of the XCD's nwg takes targets w, w + nwg, w + 2 nwg, ...: at
+// any moment the XCD's workgroups walk ONE band of nwg consecutive lists, whose pair ids ascend the same way, so the
+// second and third use of a row arrive while the first is in flight or still in that XCD's L2.  A list stays whole and
+// keeps its order: results are bit-identical to the contiguous form.  List lengths vary (0 ... 30), but a workgroup's
+// share is every nwg-th list of thousands: the sums differ by a few per cent.
+// GR_SB target slots at a time: lengths -> LDS, one-wave scan, then chunks of GR_CAP pairs are staged by binary search.
+#ifdef GEOT_GR_LAB_SHARES
+constexpr bool GR_DEAL = false;     // lab: contiguous shares of the pair stream (the first form)
+#else
+constexpr bool GR_DEAL = true;
+#endif
+constexpr int GR_SB = 512;
+#ifndef GEOT_GR_LAB_GT
+#define GEOT_GR_LAB_GT 2
+#endif
+constexpr int GR_GT = GEOT_GR_LAB_GT;   // consecutive targets a workgroup takes at a time
+struct GrDeal {
+    int tb, te, nwg, w, nloc;       // the XCD's target range, workgroups sharing it, this one's rank, its target slots
+    __device__ __forceinline__ int target(int u) const { return tb + ((u / GR_GT) * nwg + w) * GR_GT + u % GR_GT; }
+};
+__device__ __forceinline__ GrDeal gr_deal(int T)
+{
+    const int nx = (gridDim.x % 8 == 0) ? 8 : 1;
+    const int x = blockIdx.x % nx;
+    GrDeal d;
+    d.w = blockIdx.x / nx;
+    d.nwg = gridDim.x / nx;
+    d.tb = (int)((long long)T * x / nx);
+    d.te = (int)((long long)T * (x + 1) / nx);
+    const int granules = (d.te - d.tb + GR_GT - 1) / GR_GT;
+    d.nloc = granules > d.w ? (granules - d.w + d.nwg - 1) / d.nwg * GR_GT : 0;     // (slots past the range's end are empty lists)
+    return d;
+}
+// lengths and first pair of the slots [ub, ub + nb) of this workgroup; s_pre[u] = pairs in front of slot u (s_pre[nb] = all)
+__device__ __forceinline__ void gr_scan_slots(const GrDeal &d, int ub, int nb, const int *__restrict__ off, int *s_pre, int *s_off)
+{
+    __syncthreads();                // the previous block's staging has read s_pre / s_off
+    for (int u = threadIdx.x; u < nb; u += blockDim.x) {
+        const int k = d.target(ub + u);
+        const int a = k < d.te ? off[k] : 0;
+        s_off[u] = a;
+        s_pre[u + 1] = k < d.te ? off[k + 1] - a : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int carry = 0;
+        for (int piece = 0; piece < nb; piece += 64) {
+            const int i = piece + lane;
+            int v = i < nb ? s_pre[i + 1] : 0;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int o = __shfl_up(v, sh);
+                if (lane >= sh) v += o;
+            }
+            if (i < nb) s_pre[i + 1] = v + carry;
+            carry += __shfl(v, 63);
+        }
+        if (lane == 0) s_pre[0] = 0;
+    }
+    __syncthreads();
+}
+// pairs [base, base + cnt) of the block's concatenated lists -> source row, weight, output row | last-of-list flag
+__device__ __forceinline__ void gr_stage_pairs(const GrDeal &d, int ub, int nb, int base, int cnt, const int *s_pre, const int *s_off,
+                                               const int *__restrict__ rev, const float *__restrict__ revw,
+                                               const int *__restrict__ order, int m, int *s_src, float *s_w, unsigned *s_tgt)
+{
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const int v = base + i;
+        int lo = 0, hi = nb;        // s_pre[lo] <= v < s_pre[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= v) lo = mid;
+            else hi = mid;
+        }
+        const int pair = s_off[lo] + (v - s_pre[lo]);
+        const int k = d.target(ub + lo);
+        s_src[i] = rev[pair];
+        s_w[i] = revw[pair];
+        s_tgt[i] = (unsigned)(order ? (k / m) * m + order[k] : k) | (v + 1 == s_pre[lo + 1] ? GR_LAST : 0u);
+    }
+}
+
 __global__ __launch_bounds__(1024) void gather_rows_csr_cl_kernel(int c4, int T, int P, const cl_f4 *__restrict__ g,
                                                                   const int *__restrict__ off, const int *__restrict__ rev,
                                                                   const float *__restrict__ revw,
@@ -1261,18 +1350,27 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_cl_kernel(int c4, int T,
             __syncthreads();
         }
     }
-    // this workgroup's share of the pair stream: the lists that START in [s0, s1)
+    __shared__ int s_pre[GR_SB + 1], s_off[GR_SB];
+    // contiguous form (lab): the lists that START in this workgroup's share [s0, s1) of the pair stream
     auto snap = [&](long long s) -> int {
         if (s <= 0) return 0;
         if (s >= P) return P;
         const int k = (int)(rtgt[s] & ~GR_LAST);
         return off[k] == (int)s ? (int)s : off[k + 1];
     };
-    const int p0 = snap((long long)P * blockIdx.x / gridDim.x), p1 = snap((long long)P * (blockIdx.x + 1) / gridDim.x);
+    const GrDeal deal = gr_deal(T);
+    const int p0 = GR_DEAL ? 0 : snap((long long)P * blockIdx.x / gridDim.x);
+    const int p1 = GR_DEAL ? 0 : snap((long long)P * (blockIdx.x + 1) / gridDim.x);
     cl_f4 acc = zero;
-    for (int base = p0; base < p1; base += GR_CAP) {
-        const int cnt = min(GR_CAP, p1 - base);
+    for (int ub = 0; ub < (GR_DEAL ? deal.nloc : 1); ub += GR_SB) {
+    const int nb = min(GR_SB, deal.nloc - ub);
+    if (GR_DEAL) gr_scan_slots(deal, ub, nb, off, s_pre, s_off);
+    const int first = GR_DEAL ? 0 : p0, end = GR_DEAL ? s_pre[nb] : p1;
+    for (int base = first; base < end; base += GR_CAP) {
+        const int cnt = min(GR_CAP, end - base);
         __syncthreads();
+        if (GR_DEAL) gr_stage_pairs(deal, ub, nb, base, cnt, s_pre, s_off, rev, revw, order, m, s_src, s_w, s_tgt);
+        else
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
             const unsigned t = rtgt[base + i];
             const int k = (int)(t & ~GR_LAST);
@@ -1313,6 +1411,7 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_cl_kernel(int c4, int T,
             load(i + 2 * GR_U, va);
             walk(i + GR_U, vb);
         }
+    }
     }
 }
 
@@ -1357,18 +1456,27 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_bn_cl_kernel(
             __syncthreads();
         }
     }
+    __shared__ int s_pre[GR_SB + 1], s_off[GR_SB];
     auto snap = [&](long long s) -> int {
         if (s <= 0) return 0;
         if (s >= P) return P;
         const int k = (int)(rtgt[s] & ~GR_LAST);
         return off[k] == (int)s ? (int)s : off[k + 1];
     };
-    const int p0 = snap((long long)P * blockIdx.x / gridDim.x), p1 = snap((long long)P * (blockIdx.x + 1) / gridDim.x);
+    const GrDeal deal = gr_deal(T);
+    const int p0 = GR_DEAL ? 0 : snap((long long)P * blockIdx.x / gridDim.x);
+    const int p1 = GR_DEAL ? 0 : snap((long long)P * (blockIdx.x + 1) / gridDim.x);
     cl_f4 G = zero, Y = zero;
     float W = 0.f;
-    for (int base = p0; base < p1; base += GR_CAP) {
-        const int cnt = min(GR_CAP, p1 - base);
+    for (int ub = 0; ub < (GR_DEAL ? deal.nloc : 1); ub += GR_SB) {
+    const int nb = min(GR_SB, deal.nloc - ub);
+    if (GR_DEAL) gr_scan_slots(deal, ub, nb, off, s_pre, s_off);
+    const int first = GR_DEAL ? 0 : p0, end = GR_DEAL ? s_pre[nb] : p1;
+    for (int base = first; base < end; base += GR_CAP) {
+        const int cnt = min(GR_CAP, end - base);
         __syncthreads();
+        if (GR_DEAL) gr_stage_pairs(deal, ub, nb, base, cnt, s_pre, s_off, rev, revw, order, m, s_src, s_w, s_tgt);
+        else
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
             const unsigned t = rtgt[base + i];
             const int k = (int)(t & ~GR_LAST);
@@ -1418,6 +1526,7 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_bn_cl_kernel(
             load(i + 2 * GRB_U, ya, ga);
             walk(i + GRB_U, yb, gb);
         }
+    }
     }
 }
 
