@@ -98,6 +98,13 @@ def make_optimizer(model, lr=1e-3, weight_decay=1e-4):
     return torch.optim.AdamW(groups, lr=lr, weight_decay=0.0 if weight_decay else weight_decay, fused=fused)
 
 
+def _mode(module, training):
+    """module.train(training) when the root is not in that mode already: train.py sets the modes once per epoch
+    (train_one_epoch: model.train(), model_t.eval()); walking ~180 modules three times per iteration cost 2 ms of host time."""
+    if module.training != training:
+        module.train(training)
+
+
 def _lookahead_at_blocks(segmentor, default):
     """Where a step queues its look-ahead: inside the backward, when it reaches the transformer blocks ("blocks"; the model
     must offer the hook), or right behind the forward ("forward").  GEOT_LOOKAHEAD_AT overrides the step's default --
@@ -121,7 +128,7 @@ class SupervisedStep:
         next_pos: the coordinates of the NEXT batch, when the loop already holds them (a data loader with one batch of
         look-ahead): their sampling / grouping / index work is queued between this batch's forward and backward
         (PointTransformer_seg_T.prefetch_geometry) and picked up by the next call -- same results, 0.6 ms less per step."""
-        self.model.train()
+        _mode(self.model, True)
         inner = self.model.module if hasattr(self.model, "module") else self.model
         geometry, self._geometry = self._geometry, None
         queue = None
@@ -206,12 +213,12 @@ class FixMatchNTMStep:
             t_stream = self._teacher_stream
             t_stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.no_grad(), (torch.cuda.stream(t_stream) if t_stream is not None else contextlib.nullcontext()):
-            self.model_t.eval()
+            _mode(self.model_t, False)
             pred_u = F.softmax(self.model_t(data_u, if_teacher=True, geometry=geom_t)[0], dim=1)
             logits_u_aug, label_u_aug = torch.max(pred_u, dim=1)
         # 2. student on labelled + strong + weak (train.py:478-492)
-        self.model.train()
-        self.T_predictor.train()
+        _mode(self.model, True)
+        _mode(self.T_predictor, True)
         data_u = dict(data_u, T=self.ema_t)
         inner = self.model.module if hasattr(self.model, "module") else self.model
         queue = None
@@ -219,7 +226,7 @@ class FixMatchNTMStep:
             nd, nu = next_batches
 
             def queue():
-                self.model_t.eval()
+                _mode(self.model_t, False)
                 self._geometry = (inner.prefetch_geometry(nd, nu, fixmatch=True), self.model_t.prefetch_geometry(nu, if_teacher=True))
                 src = (nd["pos"], nu["pos_s"], nu["pos_w"])
                 self._geometry_src = src + (tuple(t._version for t in src),)
