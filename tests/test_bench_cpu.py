@@ -84,8 +84,22 @@ def test_pmc_traffic_lookup_reports_its_source(tmp_path, monkeypatch):
             {"commit": "abc%d" % v, "kernels": {"geot::fps_pruned_kernel<768, 32, false, 8>": {"traffic_bytes": traffic}}}))
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     t, src = bench.pmc_traffic("fps_pruned_kernel<768, 32, false", "bench_model")
-    assert t == 222 and src == {"file": os.path.join("profiles", "r02_bench_model_v2_pmc_traffic.json"), "commit": "abc2"}
+    assert t == 222 and src == {"file": os.path.join("profiles", "r02_bench_model_v2_pmc_traffic.json"), "commit": "abc2",
+                                "kernel_source_unchanged": None}          # (a profile from before the source hashes)
     assert bench.pmc_traffic("no_such_kernel", "bench_model") == (None, None)
+    # a profile that recorded the hash of the kernel's source: unchanged / changed since
+    import hashlib
+    csrc = tmp_path / "geot_amd" / "csrc"
+    csrc.mkdir(parents=True)
+    (csrc / "fps.hip").write_text("__global__ void fps_pruned_kernel() {}\n")
+    sha = hashlib.sha256((csrc / "fps.hip").read_bytes()).hexdigest()[:16]
+    (prof / "r02_bench_model_v3_pmc_traffic.json").write_text(json.dumps(
+        {"commit": "abc3", "csrc_sha16": {"fps.hip": sha, "geot_common.h": "0" * 16},
+         "kernels": {"geot::fps_pruned_kernel<768, 32, false, 8>": {"traffic_bytes": 333}}}))
+    t, src = bench.pmc_traffic("fps_pruned_kernel<768, 32, false", "bench_model")
+    assert t == 333 and src["kernel_source_unchanged"] is True
+    (csrc / "fps.hip").write_text("__global__ void fps_pruned_kernel() { /* edited */ }\n")
+    assert bench.pmc_traffic("fps_pruned_kernel<768, 32, false", "bench_model")[1]["kernel_source_unchanged"] is False
 
 
 def test_recorded_gemm_selection_is_a_wellformed_tunableop_file():
