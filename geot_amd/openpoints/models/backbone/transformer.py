@@ -506,7 +506,10 @@ class PointTransformer_seg_T(nn.Module):
             # (prop1 / prop2: 80 us in memory order, 85 in Morton order), and the orders are not free: they run beside the
             # transformer blocks
             big = known.shape[1] > 2048
-            rix = ReverseIndex(idx, weight, known.shape[1], local_spatial_order(known) if big else None) if self.training else None
+            # the gradient's targets (= the known points) in Morton order for every stage: its workgroups are dealt consecutive
+            # lists inside an XCD (gather_group.hip gr_deal), which only pays when consecutive lists share source rows
+            tgt_order = big or os.environ.get("GEOT_FP_RIX_ORDER", "all") == "all"
+            rix = ReverseIndex(idx, weight, known.shape[1], local_spatial_order(known) if tgt_order else None) if self.training else None
             return idx, weight, local_spatial_order(unknown) if big else None, rix
         k2, k1 = self.dgcnn_pro_2.k, self.dgcnn_pro_1.k
 
