@@ -476,12 +476,27 @@ __global__ __launch_bounds__(KG_WAVES * 64) void knn_grid_kernel(
     }
 }
 
+// The records of a cell sit in arrival order (kg_count_kernel ranks them with an atomic), which changes from launch to
+// launch; a processing ORDER has to be the same every time -- per-tile BatchNorm sums are taken in that order, and their
+// rounding reaches every weight -- so inside a cell the points go by ascending index: rank = members with a smaller index
+// (cells hold a handful of points; a cell of more than RIX_SORT_MAX -- thousands of duplicates -- keeps its arrival order).
 __global__ __launch_bounds__(256) void kg_order_kernel(int nr, const uint32_t *__restrict__ ws, size_t per_cloud,
-                                                       size_t off_rec, int *__restrict__ order)
+                                                       size_t off_tmp, size_t off_rec, int *__restrict__ order)
 {
-    const float4 *rec = reinterpret_cast<const float4 *>(ws + (size_t)blockIdx.y * per_cloud + off_rec);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nr; i += gridDim.x * 256)
-        order[(size_t)blockIdx.y * nr + i] = blockIdx.y * nr + __float_as_int(rec[i].w);
+    const uint32_t *W = ws + (size_t)blockIdx.y * per_cloud;
+    const uint32_t *start = W + KG_HDR, *tmp = W + off_tmp;
+    const float4 *rec = reinterpret_cast<const float4 *>(W + off_rec);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nr; i += gridDim.x * 256) {
+        const int me = __float_as_int(rec[i].w);
+        const uint32_t cell = tmp[2 * me];
+        const int a = (int)start[cell], z = (int)start[cell + 1];
+        int pos = i;
+        if (z - a <= RIX_SORT_MAX) {
+            pos = a;
+            for (int j = a; j < z; ++j) pos += __float_as_int(rec[j].w) < me ? 1 : 0;
+        }
+        order[(size_t)blockIdx.y * nr + pos] = blockIdx.y * nr + me;
+    }
 }
 
 // ---- ball query over the grid -------------------------------------------------------------------
@@ -683,7 +698,8 @@ GEOT_EXPORT int geot_three_nn_ws(int b, int n, int m, const float *unknown, cons
 
 // order (b*n) int32 <- the global point ids b*n + i sorted by (cloud, Morton cell of a 32^3 grid over the
 // cloud's bounding box): a processing order in which consecutive points are spatial neighbours, so that
-// kernels which gather per-point rows of a kNN graph find them in L2.  Arbitrary within a cell.
+// kernels which gather per-point rows of a kNN graph find them in L2.  Ascending index within a cell: the same order on
+// every call (cells of more than RIX_SORT_MAX points excepted).
 GEOT_EXPORT int geot_spatial_order(int b, int n, const float *xyz, int *order, void *workspace, long long ws_bytes,
                                    void *stream)
 {
@@ -702,7 +718,7 @@ GEOT_EXPORT int geot_spatial_order(int b, int n, const float *xyz, int *order, v
     hipLaunchKernelGGL(kg_scan_kernel, dim3(b), dim3(1024), 0, s, ws, L.per_cloud_words);
     hipLaunchKernelGGL(kg_scatter_kernel, dim3(pb, b), dim3(256), 0, s, n, xyz, ws, L.per_cloud_words, L.off_tmp,
                        L.off_rec);
-    hipLaunchKernelGGL(kg_order_kernel, dim3(pb, b), dim3(256), 0, s, n, ws, L.per_cloud_words, L.off_rec, order);
+    hipLaunchKernelGGL(kg_order_kernel, dim3(pb, b), dim3(256), 0, s, n, ws, L.per_cloud_words, L.off_tmp, L.off_rec, order);
     return hipGetLastError();
 }
 

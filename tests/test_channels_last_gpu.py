@@ -329,3 +329,56 @@ def test_edgeconv_gradient_with_the_reverse_index_built_ahead():
         res.append((out.detach(), p.grad.clone(), q.grad.clone(), norm.weight.grad.clone(), norm.bias.grad.clone()))
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+def test_spatial_order_is_the_same_on_every_call():
+    """The Morton processing order decides in which order a tile sums its rows (BatchNorm statistics of the point-major FP
+    stage), so it must not depend on the arrival order of the counting sort's atomics: inside a grid cell the points go by
+    ascending index.  Clouds with many points per cell (duplicates, a cluster) make ties certain."""
+    from geot_amd import fused_norm as fn
+    from geot_amd.synth import make_batch
+    xyz = make_batch(3, 6000, start_index=3, dup_frac=0.3)[0]
+    xyz[1, 1000:3000] = xyz[1, 17] + 1e-4 * np.random.default_rng(0).standard_normal((2000, 3)).astype(np.float32)   # a cluster
+    pos = torch.from_numpy(xyz).to(DEV)
+    orders = [fn.local_spatial_order(pos).cpu().numpy() for _ in range(4)]
+    for o in orders[1:]:
+        assert np.array_equal(o, orders[0])
+    for bi in range(3):
+        assert np.array_equal(np.sort(orders[0][bi]), np.arange(6000))
+    # equal points share a cell: they appear in ascending index
+    o = orders[0][0]
+    first = {}
+    rank = np.empty(6000, np.int64)
+    rank[o] = np.arange(6000)
+    keys = [tuple(p) for p in xyz[0]]
+    for i, k in enumerate(keys):
+        if k in first:
+            assert rank[first[k]] < rank[i]
+        else:
+            first[k] = i
+
+
+def test_training_steps_are_bit_reproducible():
+    """Two trainers built from the same seed, run independently (their own Morton orders, reverse indices, look-ahead): the
+    same losses and the same parameters, bit for bit, after three steps -- no float atomics and no arrival-order dependence
+    on the supervised path."""
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd.train_step import SupervisedStep
+    from geot_amd.synth import make_batch, region_labels
+    cfg = dict(trans_dim=384, depth=3, num_heads=4, group_size=32, num_group=128, encoder_dims=256, nclasses=17,
+               drop_path_rate=0.1, downsample_targets=[4096, 2048, 1024], extract_layers=[1, 2, 3])
+    xyz, xyz2 = make_batch(2, 12000, start_index=5)[0], make_batch(2, 12000, start_index=9)[0]
+    batches = [(torch.from_numpy(x).to(DEV), torch.from_numpy(region_labels(x)).to(DEV)) for x in (xyz, xyz2)]
+    cls = torch.zeros(2, 1, dtype=torch.long, device=DEV)
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(4)
+        model = PointTransformer_seg_T(**cfg).to(DEV)
+        step = SupervisedStep(model, lr=1e-3)
+        losses = []
+        for it in range(3):
+            cur, nxt = batches[it % 2], batches[(it + 1) % 2]
+            losses.append(step(cur[0].clone(), cls, cur[1], next_pos=None if it == 2 else nxt[0]).clone())
+        runs.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
+    assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
