@@ -400,23 +400,34 @@ __global__ __launch_bounds__(NT, BACKWARD ? SIG_BWD_WPS : 4) void sig_t_mean_mfm
 
 // grad_W[kk][o][j] += sum_blk partial[blk][j][col];  grad_W[kk][o][C+j] += cm[kk][j] * sum_blk partial[blk][C][col]
 template <int C>
-__global__ __launch_bounds__(256) void sig_t_mean_wgrad_reduce_kernel(int nblk, const float *__restrict__ partial,
+__global__ __launch_bounds__(1024) void sig_t_mean_wgrad_reduce_kernel(int nblk, const float *__restrict__ partial,
                                                                       const float *__restrict__ cm,
                                                                       float *__restrict__ grad_W)
 {
-    // grid.y slices the block partials 32 at a time: 16x the parallelism of one thread per entry, and the
-    // final accumulation into grad_W (pre-zeroed or carrying earlier gradients) is a float atomic anyway
-    constexpr int CC = C * C, KP = C + 1;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= KP * CC) return;
-    const int k = e / CC, col = e - k * CC;
-    const int b0 = blockIdx.y * 32, b1 = min(nblk, b0 + 32);
+    // one workgroup per 64 entries: its 16 waves take the block partials round-robin, each in ascending order, and add their
+    // sums in a fixed tree; one writer per element of grad_W (pre-zeroed or carrying earlier gradients) -- the same bits on
+    // every run (the first form sliced the blocks over grid.y and finished with float atomics: arrival order)
+    constexpr int CC = C * C, KP = C + 1, PARTS = 16;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    __shared__ float red[PARTS][64];
     float s = 0.f;
-    for (int bkt = b0; bkt < b1; ++bkt) s += partial[(size_t)bkt * KP * CC + e];
-    if (k < C) atomicAdd(&grad_W[(size_t)col * 2 * C + k], s);
+    if (e < KP * CC)
+        for (int bkt = part; bkt < nblk; bkt += PARTS) s += partial[(size_t)bkt * KP * CC + e];
+    red[part][lane] = s;
+    __syncthreads();
+#pragma unroll
+    for (int h = PARTS / 2; h >= 1; h >>= 1) {
+        if (part < h) red[part][lane] += red[part + h][lane];
+        __syncthreads();
+    }
+    if (part != 0 || e >= KP * CC) return;
+    s = red[0][lane];
+    const int k = e / CC, col = e - k * CC;
+    if (k < C) grad_W[(size_t)col * 2 * C + k] += s;
     else {
         const int kk = col / C;
-        for (int j = 0; j < C; ++j) atomicAdd(&grad_W[(size_t)col * 2 * C + C + j], cm[kk * C + j] * s);
+        for (int j = 0; j < C; ++j) grad_W[(size_t)col * 2 * C + C + j] += cm[kk * C + j] * s;
     }
 }
 
@@ -840,6 +851,25 @@ __global__ __launch_bounds__(256) void tl_fill_kernel(int total_pts, int n, int 
     revc[slot] = w / S[i];
 }
 
+// wave-wide bitonic sort of (source id, coefficient) by id, ascending; lanes without an edge (id < 0) end up behind the others
+__device__ __forceinline__ void tl_sort_edges(int &id, float &cf, int lane)
+{
+    unsigned key = id < 0 ? 0xffffffffu : (unsigned)id;
+#pragma unroll
+    for (int k2 = 2; k2 <= 64; k2 <<= 1) {
+#pragma unroll
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            const unsigned pk = (unsigned)__shfl_xor((int)key, j);
+            const float pv = __shfl_xor(cf, j);
+            const bool keep_min = ((lane & k2) == 0) == ((lane & j) == 0);
+            const bool take = keep_min ? pk < key : pk > key;
+            key = take ? pk : key;
+            cf = take ? pv : cf;
+        }
+    }
+    id = key == 0xffffffffu ? -1 : (int)key;
+}
+
 // Gather backward, G consecutive points of the spatial order per wave, neighbour rows shared: a row is
 // loaded once and applied to every point of the wave that has it as an out- or an in-neighbour (most kNN
 // edges are mutual, so even a single point usually meets each neighbour twice).
@@ -885,6 +915,9 @@ __global__ __launch_bounds__(256) void tl_grad_gather_shared_kernel(
                 }
                 if (lane < nin[g]) { ji[g] = rev[r0[g] + lane]; ci[g] = two_g * revc[r0[g] + lane]; }
             }
+            // the in-edge slots were handed out by an atomic (arrival order): put them in ascending source id, so that a
+            // point's sum has the same order on every run (empty lanes -- id -1 -- go last)
+            tl_sort_edges(ji[g], ci[g], lane);
             lo[g] = __ballot(co[g] != 0.f);
             li[g] = __ballot(ci[g] != 0.f);
         }
@@ -1099,16 +1132,26 @@ __global__ __launch_bounds__(CT_MAXC * CT_MAXC) void class_transition_kernel(
     }
 }
 
-// out[e] += sum over blocks of partial[blk][e]; grid.y slices the blocks 32 at a time
-__global__ __launch_bounds__(256) void ntm_partial_reduce_kernel(int nblk, int len, const float *__restrict__ partial,
-                                                                 float *__restrict__ out)
+// out[e] += sum over blocks of partial[blk][e], in a fixed order (one workgroup per 64 entries, 16 waves round-robin over the
+// blocks, fixed tree, one writer per entry): reproducible
+__global__ __launch_bounds__(1024) void ntm_partial_reduce_kernel(int nblk, int len, const float *__restrict__ partial,
+                                                                  float *__restrict__ out)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= len) return;
-    const int b0 = blockIdx.y * 32, b1 = min(nblk, b0 + 32);
+    constexpr int PARTS = 16;
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    __shared__ float red[PARTS][64];
     float s = 0.f;
-    for (int bkt = b0; bkt < b1; ++bkt) s += partial[(size_t)bkt * len + e];
-    atomicAdd(out + e, s);
+    if (e < len)
+        for (int bkt = part; bkt < nblk; bkt += PARTS) s += partial[(size_t)bkt * len + e];
+    red[part][lane] = s;
+    __syncthreads();
+#pragma unroll
+    for (int h = PARTS / 2; h >= 1; h >>= 1) {
+        if (part < h) red[part][lane] += red[part + h][lane];
+        __syncthreads();
+    }
+    if (part == 0 && e < len) out[e] += red[0][lane];
 }
 
 template <typename K>
@@ -1194,7 +1237,7 @@ GEOT_EXPORT int geot_ntm_sig_t_mean_grad_w(int b, int n, int c, const float *p, 
     const int nblk = sig_mfma_blocks((long long)b * n, SIG_BWD_PER_CU);
     hipLaunchKernelGGL((sig_t_mean_mfma_kernel<C, true, SIG_BWD_THREADS>), dim3(nblk), dim3(SIG_BWD_THREADS), lds, (hipStream_t)stream,
                        b * n, n, p, W, cm, grad_ins_T, nullptr, workspace);
-    hipLaunchKernelGGL((sig_t_mean_wgrad_reduce_kernel<C>), dim3(((C + 1) * C * C + 255) / 256, (nblk + 31) / 32), dim3(256), 0,
+    hipLaunchKernelGGL((sig_t_mean_wgrad_reduce_kernel<C>), dim3(((C + 1) * C * C + 63) / 64), dim3(1024), 0,
                        (hipStream_t)stream, nblk, workspace, cm, grad_W);
     return hipGetLastError();
 }
@@ -1305,7 +1348,7 @@ GEOT_EXPORT int geot_ntm_correct_grad_ws(int b, int n, int c, float lam, const f
     const int nblk = ntm_blocks(b * n);
     hipLaunchKernelGGL((ntm_correct_bwd_kernel<C>), dim3(nblk), dim3(NTM_THREADS), lds, (hipStream_t)stream, b * n,
                        n, lam, logits, ins_T, ema_t, grad_out, grad_logits, grad_ins_T, grad_ema_t, workspace);
-    hipLaunchKernelGGL(ntm_partial_reduce_kernel, dim3((C * C + 255) / 256, (nblk + 31) / 32), dim3(256), 0,
+    hipLaunchKernelGGL(ntm_partial_reduce_kernel, dim3((C * C + 63) / 64), dim3(1024), 0,
                        (hipStream_t)stream, nblk, C * C, workspace, grad_ema_t);
     return hipGetLastError();
 }

@@ -382,3 +382,31 @@ def test_training_steps_are_bit_reproducible():
         runs.append((torch.stack(losses), [p.detach().clone() for p in model.parameters()]))
     assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+
+
+def test_fixmatch_iterations_are_bit_reproducible():
+    """The FixMatch+NTM iteration as well: two trainers from the same seed, two iterations each -- identical losses, student and
+    predictor parameters and EMA matrix.  (Fixed-order reduces of the sig_t_mean / logit-correction partials, the graph loss's
+    in-edges sorted by source before they are summed; hubs beyond the 64 in-edge slots would still go through float atomics.)"""
+    from geot_amd import train_step as ts
+    from geot_amd.synth import make_batch, region_labels
+    small = dict(trans_dim=384, depth=3, num_heads=4, group_size=32, num_group=128, encoder_dims=256, nclasses=17,
+                 drop_path_rate=0.0, downsample_targets=[2048, 1024, 512], extract_layers=[1, 2, 3])
+    xyz = make_batch(2, 6000, start_index=0)[0]
+    pos, target = torch.from_numpy(xyz).to(DEV), torch.from_numpy(region_labels(xyz)).to(DEV)
+    xu = torch.from_numpy(make_batch(2, 6000, start_index=50)[0]).to(DEV)
+    xs = (xu * 1.1).contiguous()
+    z = torch.zeros(2, 1, dtype=torch.long, device=DEV)
+    data = {"pos": pos, "x": pos.transpose(1, 2).contiguous(), "cls": z, "y": target}
+    data_u = {"pos_w": xu, "x_w": xu.transpose(1, 2).contiguous(), "cls_w": z, "pos_s": xs,
+              "x_s": xs.transpose(1, 2).contiguous(), "cls_s": z, "raw_pos": xu}
+    runs = []
+    for _ in range(2):
+        torch.manual_seed(2)
+        trainer = ts.build_fixmatch(DEV, seg_cfg=small, use_ddp=False)
+        out = [trainer(data, data_u) for _ in range(2)]
+        runs.append((torch.stack([v for o in out for v in o.values()]),
+                     [p.detach().clone() for p in trainer.model.parameters()] + [p.detach().clone() for p in trainer.T_predictor.parameters()]
+                     + [trainer.ema_t.clone()]))
+    assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
