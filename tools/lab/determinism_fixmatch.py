@@ -13,12 +13,16 @@ from geot_amd.synth import make_batch, region_labels  # noqa: E402
 DEV = torch.device("cuda:0")
 SMALL = dict(trans_dim=384, depth=3, num_heads=4, group_size=32, num_group=128, encoder_dims=256, nclasses=17,
              drop_path_rate=0.0, downsample_targets=[2048, 1024, 512], extract_layers=[1, 2, 3])
+N = int(os.environ.get("POINTS", "6000"))          # POINTS=24000 FULL=1: the configured model at configs[4]'s sizes
+if os.environ.get("FULL"):
+    from geot_amd.openpoints.models.backbone.transformer import TOOTH_SEG_CFG
+    SMALL = dict(TOOTH_SEG_CFG)
 torch.manual_seed(2)
 trainer = ts.build_fixmatch(DEV, seg_cfg=SMALL, use_ddp=False)
-xyz = make_batch(2, 6000, start_index=0)[0]
+xyz = make_batch(2, N, start_index=0)[0]
 pos = torch.from_numpy(xyz).to(DEV)
 target = torch.from_numpy(region_labels(xyz)).to(DEV)
-xu = torch.from_numpy(make_batch(2, 6000, start_index=50)[0]).to(DEV)
+xu = torch.from_numpy(make_batch(2, N, start_index=50)[0]).to(DEV)
 xs = (xu * 1.1).contiguous()
 z = torch.zeros(2, 1, dtype=torch.long, device=DEV)
 data = {"pos": pos, "x": pos.transpose(1, 2).contiguous(), "cls": z, "y": target}
