@@ -74,8 +74,11 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--streams", type=int, default=1, help="sa only: HIP streams the steps are dealt to")
     ap.add_argument("--graph", action="store_true",
-                    help="sa / ntm: capture one step into a hipGraph (torch.cuda.graph) and time replays -- for the "
-                         "launch-bound small-batch cases (configs[4] runs B_u = 2 clouds per rank)")
+                    help="sa / ntm: capture one step into a hipGraph (torch.cuda.graph) and time replays.  model / fixmatch "
+                         "on one GPU replay the whole iteration from a hipGraph BY DEFAULT (geot_amd/graph_step.py); see --no-graph")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="model / fixmatch: time the eager step (one kernel launch at a time from the host) instead of the "
+                         "hipGraph replay; N > 1 always runs eagerly (DistributedDataParallel is host logic)")
     return ap.parse_args()
 
 
@@ -131,39 +134,86 @@ class EventTimer:
 
     def __init__(self):
         self.pairs = []
+        self.captured = []      # pairs recorded while a hipGraph was being captured: event-record NODES of that graph
+        self.samples = []       # their elapsed times, read after replays (sample_replays)
         self.only = None        # wrap(): time a call only if only(*args) is true (e.g. the student's batch, not the teacher's)
 
-    def wrap(self, fn):
+    def _event(self):
+        """A timing event; under stream capture an `external` one (hipEventRecordWithFlags: an event-record node of the
+        graph, re-recorded by every replay and readable afterwards) -- the only way to time ONE kernel inside a replay."""
         import torch
+        if torch.cuda.is_current_stream_capturing():
+            return torch.cuda.Event(enable_timing=True, external=True), self.captured
+        return torch.cuda.Event(enable_timing=True), self.pairs
 
+    def wrap(self, fn):
         def timed(*a, **k):
             if self.only is not None and not self.only(*a, **k):
                 return fn(*a, **k)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0, dest = self._event()
+            e1, _ = self._event()
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            self.pairs.append((e0, e1))
+            dest.append((e0, e1))
             return out
         return timed
 
     def hook(self, module):
-        import torch
-
         def pre(mod, inp):
-            e0 = torch.cuda.Event(enable_timing=True)
+            e0, _ = self._event()
             e0.record()
             mod._geot_e0 = e0
 
         def post(mod, inp, out):
-            e1 = torch.cuda.Event(enable_timing=True)
+            e1, dest = self._event()
             e1.record()
-            self.pairs.append((mod._geot_e0, e1))
+            dest.append((mod._geot_e0, e1))
         return [module.register_forward_pre_hook(pre), module.register_forward_hook(post)]
+
+    def sample_replays(self, step, n):
+        """n more replays, each read back: the captured events hold the timestamps of the LAST replay only."""
+        import torch
+        for _ in range(n if self.captured else 0):
+            step()
+            torch.cuda.synchronize()
+            self.samples += [a.elapsed_time(b) for a, b in self.captured]
 
     def mean_ms(self):
         import numpy as np
+        if self.samples:
+            return float(np.mean(self.samples))
         return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
+
+
+def external_events_work(dev):
+    """Can a timing event recorded inside a captured graph be read after a replay on this runtime?  (torch's `external`
+    events = hipEventRecordWithFlags(hipEventRecordExternal); probed on a two-kernel graph, never assumed.)"""
+    import torch
+    try:
+        x = torch.zeros(1 << 20, device=dev)
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            x.add_(1.0)
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        e0, e1 = torch.cuda.Event(enable_timing=True, external=True), torch.cuda.Event(enable_timing=True, external=True)
+        with torch.cuda.graph(g):
+            e0.record()
+            for _ in range(8):
+                x.add_(1.0)
+            e1.record()
+        g.replay()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) > 0.0
+    except Exception:      # noqa: BLE001 -- any refusal (capture error, unsupported flag) = "no"
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
+        return False
 
 
 def pmc_traffic(kernel, tag):

@@ -35,6 +35,7 @@ from ....pointnet2.pytorch_utils import PointwiseConv1d, PointwiseConv2d, pointw
 from ....knn_cuda import KNN, knn_sorted
 from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_graph_feature_unfused,  # noqa: F401
                               edgeconv_tail, edgeconv_tail_eligible, edgeconv_reverse_index)
+from .... import streams
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
 from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
 from ....fused_norm import (fp_front_cl, fp_front_cl_eligible, bn_act_cl, fp_stage_cl, pointwise_to_cl, pointwise_from_cl,
@@ -537,7 +538,7 @@ class PointTransformer_seg_T(nn.Module):
         forward and the backward of batch k, so that ~6.5 ms of few-workgroup kernels run beside the GEMM-bound backward
         instead of at the head of the next step and beside its (shorter) encoder.  GEOT_LOOKAHEAD=group queues Group only.  Same kernels on the same inputs: the
         results are those forward() would compute itself.  None when the model cannot use it (CPU, overlap off)."""
-        if not (pts.is_cuda and self.overlap and self.dense == "factored"):
+        if not (pts.is_cuda and self.overlap and self.dense == "factored" and streams.may_fork(pts.device)):
             return None
         pts = pts.contiguous()
         dev = pts.device
@@ -545,7 +546,7 @@ class PointTransformer_seg_T(nn.Module):
         side.wait_stream(main)            # pts is ready; every side-stream allocation starts behind main's earlier uses
         with torch.cuda.stream(side), pointops.fps_prefix_scope():
             group = self.group_divider(pts)
-            grouped = torch.cuda.Event()
+            grouped = streams.event()
             grouped.record(side)
             plan = None
             if os.environ.get("GEOT_LOOKAHEAD", "all") == "all":
@@ -561,17 +562,23 @@ class PointTransformer_seg_T(nn.Module):
     def _forward(self, pts, x, cls_label, T, geometry=None):
         B, N, _ = pts.shape
         pts = pts.contiguous()
-        side = self._side_stream(pts.device) if (self.overlap and pts.is_cuda) else None
+        side = self._side_stream(pts.device) if (self.overlap and pts.is_cuda and streams.may_fork(pts.device)) else None
         top = max(self.downsample_targets)
         plan = None
-        if (geometry is not None and side is not None and geometry["pts"] is pts and geometry["version"] == pts._version
-                and geometry["training"] == self.training and geometry["fp_layout"] == self.fp_layout):
-            # the coordinate-only work of this batch was queued on the side stream earlier (prefetch_geometry)
+        forked = False                    # has this forward queued work on the side stream (and must wait for it)?
+        if (geometry is not None and geometry["training"] == self.training and geometry["fp_layout"] == self.fp_layout
+                and (geometry.get("static") or (side is not None and geometry["pts"] is pts and geometry["version"] == pts._version))):
+            # the coordinate-only work of this batch was queued on the side stream earlier (prefetch_geometry); "static": the
+            # caller holds the geometry in fixed buffers it refills itself and vouches for it (graph_step.py: a hipGraph replay
+            # has no tensor identities to check -- the wrapper checks them on the host before it replays)
             main = torch.cuda.current_stream(pts.device)
-            main.wait_event(geometry["grouped"])
+            if geometry.get("grouped") is not None:
+                main.wait_event(geometry["grouped"])
+            forked = not geometry.get("static")   # a queued geometry's plan is still on the side stream; a static one is memory
             neighborhood, center, idx = geometry["group"]
             plan = geometry["plan"]
-            if plan is None:                  # the long FPS and the index plan beside this batch's encoder, as without look-ahead
+            if plan is None and side is not None:   # the long FPS and the index plan beside this batch's encoder, as without look-ahead
+                forked = True
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     pointops.fps_indices(pts, top)
@@ -580,13 +587,14 @@ class PointTransformer_seg_T(nn.Module):
         else:
             # the long FPS (largest target; the shorter ones are prefixes, pointops.fps_indices) beside the encoder
             if side is not None:
+                forked = True
                 main = torch.cuda.current_stream(pts.device)
                 side.wait_stream(main)        # every side-stream allocation starts behind all earlier main-stream uses
                 with torch.cuda.stream(side):
                     pointops.fps_indices(pts, top)
             neighborhood, center, idx = self.group_divider(pts)
             if side is not None and self.dense == "factored" and os.environ.get("GEOT_INDEX_PLAN", "side") == "side":
-                grouped = torch.cuda.Event()
+                grouped = streams.event()
                 grouped.record(main)             # `center` (the 512 group centres) is the one input the plan needs from main
                 with torch.cuda.stream(side):
                     side.wait_event(grouped)
@@ -614,7 +622,7 @@ class PointTransformer_seg_T(nn.Module):
 
         assert len(inter_feats) == len(self.downsample_targets), \
             "the length of the cardinality and the features should be the same"
-        if side is not None:
+        if forked:
             main.wait_stream(side)
         if plan is not None:
             center_pts, center_pts_trans = plan["center_pts"], plan["center_pts_trans"]

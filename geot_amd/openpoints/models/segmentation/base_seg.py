@@ -28,26 +28,45 @@ class WholePartSeg(nn.Module):
         self.segmentor = build_segmentor(segmentor_args)
 
     @staticmethod
-    def batch_positions(p0, u0=None, if_teacher=False, fixmatch=False):
-        """The (B', N, 3) coordinates forward() hands to the segmentor for these arguments (labelled + strong (+ weak) views
-        concatenated, or the teacher's weak view)."""
+    def _position_views(p0, u0=None, if_teacher=False, fixmatch=False):
+        """The caller's coordinate tensors that make up the batch, in order."""
         if if_teacher:
-            return p0["pos_w"].detach()
+            return [p0["pos_w"]]
         if hasattr(p0, "keys"):
             if u0 is None:
-                return p0["pos"]
-            views = [p0["pos"], u0["pos_s"]] + ([u0["pos_w"]] if fixmatch else [])
-            return torch.cat(views, 0)
-        return p0
+                return [p0["pos"]]
+            return [p0["pos"], u0["pos_s"]] + ([u0["pos_w"]] if fixmatch else [])
+        return [p0]
+
+    @classmethod
+    def batch_positions(cls, p0, u0=None, if_teacher=False, fixmatch=False):
+        """The (B', N, 3) coordinates forward() hands to the segmentor for these arguments (labelled + strong (+ weak) views
+        concatenated, or the teacher's weak view)."""
+        views = cls._position_views(p0, u0, if_teacher, fixmatch)
+        if if_teacher:
+            return views[0].detach()
+        return views[0] if len(views) == 1 else torch.cat(views, 0)
 
     def prefetch_geometry(self, p0, u0=None, if_teacher=False, fixmatch=False):
         """Queue the coordinate-only work of the batch a LATER forward(p0, ..., geometry=<result>) will see
-        (PointTransformer_seg_T.prefetch_geometry); None when the segmentor has no such thing."""
+        (PointTransformer_seg_T.prefetch_geometry); None when the segmentor has no such thing.  The result remembers WHICH
+        tensors it was computed from (`src`: the caller's coordinate tensors and their version counters): forward() takes it
+        only for exactly those tensors, unedited."""
         if not hasattr(self.segmentor, "prefetch_geometry"):
             return None
-        return self.segmentor.prefetch_geometry(self.batch_positions(p0, u0, if_teacher, fixmatch))
+        g = self.segmentor.prefetch_geometry(self.batch_positions(p0, u0, if_teacher, fixmatch))
+        if g is not None:
+            g["src"] = tuple((t, t._version) for t in self._position_views(p0, u0, if_teacher, fixmatch))
+        return g
 
     def forward(self, p0, f0=None, cls0=None, u0=None, if_teacher=False, fixmatch=False, geometry=None):
+        if geometry is not None and not geometry.get("static"):
+            # a geometry describes the tensors it was computed from and nothing else: the same objects, not edited since
+            # (a batch of the same SHAPE is not the same batch); anything else is computed in line
+            views = self._position_views(p0, u0, if_teacher, fixmatch)
+            src = geometry.get("src")
+            if src is None or len(src) != len(views) or not all(t is v and t._version == ver for v, (t, ver) in zip(views, src)):
+                geometry = None
         if if_teacher:
             p0, f0, cls0 = p0["pos_w"].detach(), p0["x_w"].detach(), p0["cls_w"].detach()
         elif hasattr(p0, "keys"):
@@ -60,14 +79,10 @@ class WholePartSeg(nn.Module):
                 p0, f0, cls0 = p0["pos"], p0["x"], p0["cls"]
         elif f0 is None:
             f0 = p0.transpose(1, 2).contiguous()
-        if geometry is not None:
-            # the geometry was computed on a tensor of the same coordinates (batch_positions of the same arguments): take that
-            # tensor for the positions, so that the segmentor recognises it; a mismatch in shape means it is not ours
-            g = geometry["pts"]
-            if g.shape == p0.shape and g.device == p0.device:
-                p0 = g
-            else:
-                geometry = None
+        if geometry is not None and not geometry.get("static"):
+            # same coordinates (checked above): hand the segmentor the tensor the geometry was computed on, so that it
+            # recognises it (the concatenation above made a new one)
+            p0 = geometry["pts"]
         T = u0["T"] if (u0 is not None and "T" in u0.keys()) else None
         if geometry is not None:
             f, p, s, _ = self.segmentor(p0, f0, cls0, T, geometry=geometry)

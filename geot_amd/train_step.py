@@ -115,6 +115,31 @@ def _lookahead_at_blocks(segmentor, default):
     return os.environ.get("GEOT_LOOKAHEAD_AT", default) == "blocks" and hasattr(segmentor, "at_blocks_backward")
 
 
+def _is_capturing(stream):
+    with torch.cuda.stream(stream):
+        return torch.cuda.is_current_stream_capturing()
+
+
+def _rejoin(dev, *streams):
+    """Static mode (graph_step.py): the current stream waits for every side stream the iteration used, so that the iteration
+    ends as ONE stream -- a hipGraph capture must have joined all its forks, and the fixed geometry buffers are refilled
+    behind everything that read them.  Under capture only the streams that are part of the capture are joined.  (All of
+    them were forked from the current stream = the capture's origin: geot_amd/streams.py explains why nothing else is.)"""
+    if dev.type != "cuda":
+        return
+    main = torch.cuda.current_stream(dev)
+    capturing = torch.cuda.is_current_stream_capturing()
+    for s in streams:
+        if s is not None and s != main and (not capturing or _is_capturing(s)):
+            main.wait_stream(s)
+
+
+def _segmentor_side_streams(module):
+    inner = module.module if hasattr(module, "module") else module
+    seg = getattr(inner, "segmentor", inner)
+    return list(getattr(seg, "_side", {}).values())
+
+
 class SupervisedStep:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, grad_norm_clip=None):
         self.model = model
@@ -123,18 +148,30 @@ class SupervisedStep:
         self.clip = grad_norm_clip
         self._geometry = None          # coordinate-only work of the next batch, queued by the previous call
 
+    def optimizers(self):
+        return [self.optimizer]
+
     def __call__(self, pos, cls, target, next_pos=None):
         """pos (B,N,3) f32, cls (B,1) int64 jaw id, target (B,N) int64 -> detached loss.
         next_pos: the coordinates of the NEXT batch, when the loop already holds them (a data loader with one batch of
         look-ahead): their sampling / grouping / index work is queued between this batch's forward and backward
-        (PointTransformer_seg_T.prefetch_geometry) and picked up by the next call -- same results, 0.6 ms less per step."""
+        (PointTransformer_seg_T.prefetch_geometry) and picked up by the next call -- same results, 0.6 ms less per step.
+        The queued work is used only if the next call passes that very tensor, unedited (the model checks the tensor, its
+        version counter and, for WholePartSeg, the tensors it was assembled from); anything else is computed in line."""
+        geometry, self._geometry = self._geometry, None
+        loss, self._geometry = self.iteration(pos, cls, target, geometry, next_pos)
+        return loss
+
+    def iteration(self, pos, cls, target, geometry=None, next_pos=None, static=False):
+        """One iteration -> (detached loss, the geometry queued for next_pos or None).  static (graph_step.py): every side
+        stream is joined before returning (see _rejoin)."""
         _mode(self.model, True)
         inner = self.model.module if hasattr(self.model, "module") else self.model
-        geometry, self._geometry = self._geometry, None
+        queued = [None]
         queue = None
         if next_pos is not None and hasattr(inner, "prefetch_geometry"):
             def queue():
-                self._geometry = inner.prefetch_geometry(next_pos)
+                queued[0] = inner.prefetch_geometry(next_pos)
         at_blocks = _lookahead_at_blocks(inner, "blocks")
         if queue is not None and at_blocks:
             inner.at_blocks_backward = queue          # runs inside the backward, when it reaches the transformer blocks
@@ -149,7 +186,9 @@ class SupervisedStep:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
-        return loss.detach()
+        if static:
+            _rejoin(pos.device, *_segmentor_side_streams(self.model))
+        return loss.detach(), queued[0]
 
 
 class FixMatchNTMStep:
@@ -176,17 +215,31 @@ class FixMatchNTMStep:
         # the frozen teacher's forward on its own stream beside the student's (same results; GEOT_TEACHER_STREAM=0: in line)
         self.overlap_teacher = os.environ.get("GEOT_TEACHER_STREAM", "1") != "0"
 
+    def optimizers(self):
+        return [self.optimizer, self.T_optimizer]
+
     def __call__(self, data, data_u, next_batches=None):
         """data: labelled batch {pos (B_l,N,3), x (B_l,3,N), cls (B_l,1), y (B_l,N)}; data_u: unlabelled batch
         {pos_w, x_w, cls_w, pos_s, x_s, cls_s, raw_pos (B_u,N,3)} -> dict of detached losses.
         next_batches = (data', data_u') of the NEXT iteration when the loop already holds them: the coordinate-only work of
         the next student and teacher batches is queued behind this iteration's student forward (SupervisedStep's look-ahead;
-        the caller must then pass exactly those dicts next time -- the positions are matched by content, not trusted)."""
-        cfg = self.cfg
-        geom_s, geom_t = self._geometry
+        the caller must then pass exactly those dicts next time -- the positions are matched by identity and version
+        counter, not trusted)."""
+        geoms = self._geometry
         self._geometry = (None, None)
-        if geom_s is not None and not _same_positions_impl(self._geometry_src, data, data_u):
-            geom_s = geom_t = None       # not the batches the look-ahead was given: do the work in line
+        if geoms[0] is not None and not _same_positions_impl(self._geometry_src, data, data_u):
+            geoms = (None, None)         # not the batches the look-ahead was given: do the work in line
+        losses, self._geometry = self.iteration(data, data_u, geoms, next_batches)
+        if next_batches is not None:
+            src = (next_batches[0]["pos"], next_batches[1]["pos_s"], next_batches[1]["pos_w"])
+            self._geometry_src = src + (tuple(t._version for t in src),)
+        return losses
+
+    def iteration(self, data, data_u, geoms=(None, None), next_batches=None, static=False):
+        """One iteration -> (dict of detached losses, (student, teacher) geometries queued for next_batches).  static
+        (graph_step.py): ema_t is updated IN its buffer and every side stream is joined before returning."""
+        cfg = self.cfg
+        geom_s, geom_t = geoms
         bl, bu = data["pos"].shape[0], data_u["pos_w"].shape[0]
         n = data["pos"].shape[1]
         # the kNN graph of the 3-D loss needs raw_pos only: build it beside the teacher / student forwards
@@ -221,24 +274,28 @@ class FixMatchNTMStep:
         _mode(self.T_predictor, True)
         data_u = dict(data_u, T=self.ema_t)
         inner = self.model.module if hasattr(self.model, "module") else self.model
+        queued = [(None, None)]
         queue = None
         if next_batches is not None:
             nd, nu = next_batches
 
             def queue():
                 _mode(self.model_t, False)
-                self._geometry = (inner.prefetch_geometry(nd, nu, fixmatch=True), self.model_t.prefetch_geometry(nu, if_teacher=True))
-                src = (nd["pos"], nu["pos_s"], nu["pos_w"])
-                self._geometry_src = src + (tuple(t._version for t in src),)
+                queued[0] = (inner.prefetch_geometry(nd, nu, fixmatch=True), self.model_t.prefetch_geometry(nu, if_teacher=True))
         at_blocks = _lookahead_at_blocks(inner.segmentor, "forward")
         if queue is not None and at_blocks:
             inner.segmentor.at_blocks_backward = queue      # runs when the student's backward reaches the transformer blocks
         pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
         pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
-        if queue is not None and not at_blocks:
-            queue()
+        # the teacher joins BEFORE the look-ahead is queued: the look-ahead's side streams (the student's and the teacher's
+        # segmentor streams) start behind the current stream only, and a teacher forward without a prefetched geometry
+        # allocates its in-line index plan on the teacher segmentor's side stream and frees it when the no_grad forward
+        # returns -- behind this join those blocks cannot be handed to the look-ahead's kernels while the teacher's
+        # decoder still reads them (the teacher is long done by the end of the student's forward: the join costs nothing)
         if t_stream is not None:
             _join(dev, t_stream, pred_u, logits_u_aug, label_u_aug)
+        if queue is not None and not at_blocks:
+            queue()
         # 3. class-level transition matrix, prior, EMA (train.py:502-545, 556-557)
         ema_t_corr, ema_next, _, _ = ntm_mod.class_transition(
             pred_u, sigma, self.ema_t, cfg["geo_lambma"], cfg["ema_t_decay"], group=self.group,
@@ -246,7 +303,8 @@ class FixMatchNTMStep:
         # 4. per-point matrices + corrected strong logits (train.py:547-552)
         ins_t = self.T_predictor(F.softmax(pred_u_strong, dim=1).detach(), self.cm)
         pred_u_strong_corr = ntm_mod.correct_logits(pred_u_strong, ins_t, ema_t_corr, cfg["lambma"])
-        self.ema_t = ema_next.detach()
+        if not static:
+            self.ema_t = ema_next.detach()
         # 5. losses (train.py:570-602)
         if nbr is not None:
             _join(dev, self._side, nbr, order)
@@ -260,13 +318,19 @@ class FixMatchNTMStep:
         loss.backward()
         if at_blocks:
             inner.segmentor.at_blocks_backward = None
+        if static:
+            with torch.no_grad():
+                self.ema_t.copy_(ema_next)       # the EMA in its fixed buffer, behind everything that read the old one
         if cfg["grad_norm_clip"] is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["grad_norm_clip"])
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         self.T_optimizer.step()
         self.T_optimizer.zero_grad(set_to_none=True)
-        return {"loss": loss.detach(), "sup": sup_loss.detach(), "unsup": unsup_loss.detach(), "threed": loss_3d.detach()}
+        if static:
+            _rejoin(dev, self._side, self._teacher_stream, *(_segmentor_side_streams(self.model) + _segmentor_side_streams(self.model_t)))
+        losses = {"loss": loss.detach(), "sup": sup_loss.detach(), "unsup": unsup_loss.detach(), "threed": loss_3d.detach()}
+        return losses, queued[0]
 
 
 def _same_positions_impl(src, data, data_u):

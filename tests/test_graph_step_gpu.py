@@ -1,0 +1,125 @@
+"""geot_amd/graph_step.py: the two training steps replayed from a hipGraph give the SAME bits as the eager steps --
+losses of every iteration, every parameter, buffer and AdamW moment afterwards -- over alternating batches with the
+look-ahead on (the geometry of batch k + 1 is produced by replay k and consumed by replay k + 1), with the random layers
+(DropPath, the head's Dropout) left on: the philox offsets of a replay continue where eager execution would be."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+SMALL = dict(trans_dim=384, depth=3, num_heads=4, group_size=32, num_group=128, encoder_dims=256, nclasses=17,
+             drop_path_rate=0.1, downsample_targets=[2048, 1024, 512], extract_layers=[1, 2, 3])
+
+
+def _sup_batches(b, n):
+    from geot_amd.synth import make_batch, region_labels
+    out = []
+    for start in (0, 40, 90):
+        xyz = make_batch(b, n, start_index=start)[0]
+        out.append((torch.from_numpy(xyz).to(DEV), torch.randint(0, 2, (b, 1), device=DEV),
+                    torch.from_numpy(region_labels(xyz)).to(DEV)))
+    return out
+
+
+def _state(step):
+    out = {}
+    for name, mod in (("model", step.model), ("T", getattr(step, "T_predictor", None))):
+        if mod is not None:
+            out.update({name + "." + k: v.detach().clone() for k, v in mod.state_dict().items()})
+    for i, opt in enumerate(step.optimizers()):
+        for j, p in enumerate(pp for g in opt.param_groups for pp in g["params"]):
+            for k, v in opt.state.get(p, {}).items():
+                if torch.is_tensor(v):
+                    out["opt%d.%d.%s" % (i, j, k)] = v.detach().clone()
+    if hasattr(step, "ema_t"):
+        out["ema_t"] = step.ema_t.detach().clone()
+    return out
+
+
+def _same(a, b):
+    assert set(a) == set(b)
+    bad = [k for k in a if not torch.equal(a[k], b[k])]
+    assert not bad, (len(bad), bad[:8])
+
+
+@pytest.mark.parametrize("look", [True, False])
+def test_supervised_step_from_a_graph_equals_eager(look):
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd import train_step as ts, graph_step as gs
+    batches = _sup_batches(2, 6000)
+    torch.manual_seed(0)
+    init = PointTransformer_seg_T(**SMALL).state_dict()
+    order = [0, 1, 0, 1, 2, 0, 1]          # batch 2 once, unannounced in the look-ahead run: its geometry is made in line
+    runs = {}
+    for mode in ("eager", "graph"):
+        m = PointTransformer_seg_T(**SMALL).to(DEV)
+        m.load_state_dict(init)
+        step = ts.SupervisedStep(m)
+        call = gs.GraphedSupervisedStep(step, warmup=2) if mode == "graph" else step
+        torch.manual_seed(7)
+        losses = []
+        for i, k in enumerate(order):
+            cur = batches[k]
+            nxt = batches[order[i + 1]] if i + 1 < len(order) else batches[0]
+            announce = look and not (i + 1 < len(order) and order[i + 1] == 2)   # batch 2 arrives unannounced
+            wrong = batches[0][0].clone() if (look and not announce) else None   # ... a DIFFERENT tensor was announced
+            losses.append(call(cur[0], cur[1], cur[2], next_pos=nxt[0] if announce else wrong).clone())
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert call.captured and call.calls == len(order)
+        runs[mode] = (losses, _state(step))
+    for i, (a, b) in enumerate(zip(*[runs[m][0] for m in ("eager", "graph")])):
+        assert torch.equal(a, b), (i, float(a), float(b))
+    _same(runs["eager"][1], runs["graph"][1])
+
+
+def _fix_batch(seed, n=4096):
+    from geot_amd.synth import make_batch, region_labels
+    xl, xu = make_batch(2, n, start_index=seed)[0], make_batch(2, n, start_index=seed + 50)[0]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)      # noqa: E731
+    lab, unl, strong = T(xl), T(xu), T(xu * np.float32(1.04))
+    z = torch.zeros(2, 1, dtype=torch.long, device=DEV)
+    return ({"pos": lab, "x": lab.transpose(1, 2).contiguous(), "cls": z, "y": T(region_labels(xl))},
+            {"pos_w": unl, "x_w": unl.transpose(1, 2).contiguous(), "cls_w": z, "pos_s": strong,
+             "x_s": strong.transpose(1, 2).contiguous(), "cls_s": z, "raw_pos": unl})
+
+
+@pytest.mark.parametrize("look", [True, False])
+def test_fixmatch_iteration_from_a_graph_equals_eager(look):
+    from geot_amd import train_step as ts, graph_step as gs
+    cfg = dict(ts.NTM_CFG, threed_k=8)
+    batches = [_fix_batch(3), _fix_batch(400)]
+    runs = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(5)
+        step = ts.build_fixmatch(DEV, seg_cfg=SMALL, cfg=cfg, use_ddp=False)
+        call = gs.GraphedFixMatchStep(step, warmup=2) if mode == "graph" else step
+        torch.manual_seed(11)
+        out = []
+        for i in range(6):
+            cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+            res = call(cur[0], cur[1], next_batches=nxt if look else None)
+            out.append({k: v.clone() for k, v in res.items()})
+        torch.cuda.synchronize()
+        if mode == "graph":
+            assert call.captured
+        runs[mode] = (out, _state(step))
+    for i, (a, b) in enumerate(zip(runs["eager"][0], runs["graph"][0])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k, float(a[k]), float(b[k]))
+    _same(runs["eager"][1], runs["graph"][1])
+
+
+def test_a_batch_of_another_shape_is_refused():
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd import train_step as ts, graph_step as gs
+    torch.manual_seed(0)
+    m = PointTransformer_seg_T(**SMALL).to(DEV)
+    call = gs.GraphedSupervisedStep(ts.SupervisedStep(m), warmup=1)
+    a = _sup_batches(2, 6000)[0]
+    call(*a)
+    b = _sup_batches(1, 6000)[0]
+    with pytest.raises(RuntimeError, match="captured for"):
+        call(*b)
