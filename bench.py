@@ -33,6 +33,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import geot_amd  # noqa: E402,F401  (before torch touches the GPU: it pins the HIP runtime's graph switch, geot_amd/__init__.py)
 
 N_POINTS = 24000
 NPOINT, RADIUS, NSAMPLE, MLP = 6000, 0.1, 32, [3, 64, 64, 128]
@@ -134,86 +135,39 @@ class EventTimer:
 
     def __init__(self):
         self.pairs = []
-        self.captured = []      # pairs recorded while a hipGraph was being captured: event-record NODES of that graph
-        self.samples = []       # their elapsed times, read after replays (sample_replays)
         self.only = None        # wrap(): time a call only if only(*args) is true (e.g. the student's batch, not the teacher's)
 
-    def _event(self):
-        """A timing event; under stream capture an `external` one (hipEventRecordWithFlags: an event-record node of the
-        graph, re-recorded by every replay and readable afterwards) -- the only way to time ONE kernel inside a replay."""
-        import torch
-        if torch.cuda.is_current_stream_capturing():
-            return torch.cuda.Event(enable_timing=True, external=True), self.captured
-        return torch.cuda.Event(enable_timing=True), self.pairs
-
     def wrap(self, fn):
+        import torch
+
         def timed(*a, **k):
             if self.only is not None and not self.only(*a, **k):
                 return fn(*a, **k)
-            e0, dest = self._event()
-            e1, _ = self._event()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            dest.append((e0, e1))
+            self.pairs.append((e0, e1))
             return out
         return timed
 
     def hook(self, module):
+        import torch
+
         def pre(mod, inp):
-            e0, _ = self._event()
+            e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
             mod._geot_e0 = e0
 
         def post(mod, inp, out):
-            e1, dest = self._event()
+            e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            dest.append((mod._geot_e0, e1))
+            self.pairs.append((mod._geot_e0, e1))
         return [module.register_forward_pre_hook(pre), module.register_forward_hook(post)]
-
-    def sample_replays(self, step, n):
-        """n more replays, each read back: the captured events hold the timestamps of the LAST replay only."""
-        import torch
-        for _ in range(n if self.captured else 0):
-            step()
-            torch.cuda.synchronize()
-            self.samples += [a.elapsed_time(b) for a, b in self.captured]
 
     def mean_ms(self):
         import numpy as np
-        if self.samples:
-            return float(np.mean(self.samples))
         return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
-
-
-def external_events_work(dev):
-    """Can a timing event recorded inside a captured graph be read after a replay on this runtime?  (torch's `external`
-    events = hipEventRecordWithFlags(hipEventRecordExternal); probed on a two-kernel graph, never assumed.)"""
-    import torch
-    try:
-        x = torch.zeros(1 << 20, device=dev)
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            x.add_(1.0)
-        torch.cuda.current_stream(dev).wait_stream(s)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        e0, e1 = torch.cuda.Event(enable_timing=True, external=True), torch.cuda.Event(enable_timing=True, external=True)
-        with torch.cuda.graph(g):
-            e0.record()
-            for _ in range(8):
-                x.add_(1.0)
-            e1.record()
-        g.replay()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) > 0.0
-    except Exception:      # noqa: BLE001 -- any refusal (capture error, unsupported flag) = "no"
-        try:
-            torch.cuda.synchronize()
-        except Exception:  # noqa: BLE001
-            pass
-        return False
 
 
 def pmc_traffic(kernel, tag):
@@ -335,10 +289,11 @@ def timed_steps(step, steps, dev, rehearsal):
     torch.cuda.synchronize()
     dist_utils.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     for _ in range(steps):
         out = step()
     HOST_ISSUE["s"] = time.perf_counter() - t0          # the host has queued every step; the GPU may still be running
+    HOST_ISSUE["cpu_s"] = time.process_time() - c0      # CPU time of all threads while queueing (blocked time excluded)
     torch.cuda.synchronize()
     dist_utils.barrier()
     torch.cuda.synchronize()
@@ -517,9 +472,31 @@ def main():
             return wl.ntm_step(nt, xyz, pw, ps)
 
     graph_note = ""
-    if args.graph:
-        assert workload in ("sa", "ntm"), "--graph: sa / ntm only"
-        eager_step = step
+    use_graph = workload in ("model", "fixmatch") and world == 1 and not args.no_graph
+    eager_step = step
+    graphed = None
+    if use_graph:
+        # The iteration replayed from two single-stream hipGraphs (geot_amd/graph_step.py): M = forward, losses, backward,
+        # AdamW over static buffers on the current stream; P = the batch-only work of the NEXT batch (geometry; FixMatch:
+        # also the frozen teacher's forward and the 3-D loss's kNN graph) on a side stream beside it.  Same kernels, same
+        # bits (tests/test_graph_step_gpu.py); what goes away is the host: ~1100 / ~1500 launches + autograd bookkeeping
+        # per iteration -> a few copies + two graph launches.
+        from geot_amd import graph_step as gs
+        graphed = (gs.GraphedSupervisedStep if workload == "model" else gs.GraphedFixMatchStep)(trainer)
+
+        def step():
+            cur, nxt = batches[turn[0] % 2], batches[(turn[0] + 1) % 2]
+            turn[0] += 1
+            if workload == "model":
+                return graphed(cur[0], cur[1], cur[2], next_pos=nxt[0] if lookahead else None)
+            return graphed(cur[0], cur[1], next_batches=nxt if lookahead else None)["loss"]
+        for _ in range(graphed.warmup + 1):     # eager over the static buffers, then the capture + first replay
+            step()
+        assert graphed.captured
+        graph_note = "; the iteration replayed from two single-stream hipGraphs (static buffers, batch copied in per step)"
+    if args.graph and not use_graph:
+        assert workload in ("sa", "ntm"), "--graph: sa / ntm capture one step here; model / fixmatch replay by default"
+        from geot_amd import streams
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -528,7 +505,7 @@ def main():
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
         hip_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(hip_graph):
+        with streams.capture(hip_graph, dev):
             graph_out = eager_step()
 
         def step():
@@ -538,21 +515,33 @@ def main():
         graph_note = "; one step captured into a hipGraph, replays timed"
     for _ in range(args.warmup):
         step()
-    if patch_owner is not None:
-        orig_fn = getattr(patch_owner, patch_name)
-        setattr(patch_owner, patch_name, fps_timer.wrap(orig_fn))
-    if workload == "model":
-        # the decoder's widest GEMM (1536 -> 384 over B*N points): a module call in the channels-first layout, a
-        # pointwise_from_cl() call (same rocBLAS GEMM, transposed operand) in the point-major one
-        unpatch += gemm_timer.hook(model.propogation_0.mlp.layer1.conv)
-        import geot_amd.openpoints.models.backbone.transformer as tr_mod
-        orig_from_cl = tr_mod.pointwise_from_cl
-        gemm_timer.only = lambda w, z, **kw: tuple(w.shape) == (384, 1536) and z.shape[1] == N_POINTS
-        tr_mod.pointwise_from_cl = gemm_timer.wrap(orig_from_cl)
-    if workload == "sa" and not args.graph:
-        import geot_amd.sa_fused as sa_fused_mod
-        orig_mlp = sa_fused_mod.fused_group_mlp_max
-        sa_fused_mod.fused_group_mlp_max = mlp_timer.wrap(orig_mlp)
+
+    def install_timers():
+        """HIP events around the dominant kernel's launch (and, model: the decoder's widest GEMM) -- on eager steps only:
+        events cannot be recorded inside a graph replay (torch's `external` events are refused by this runtime), so under
+        the default replay the kernel timings come from the eager leg that follows the timed region."""
+        undo = []
+        if patch_owner is not None:
+            orig_fn = getattr(patch_owner, patch_name)
+            setattr(patch_owner, patch_name, fps_timer.wrap(orig_fn))
+            undo.append(lambda: setattr(patch_owner, patch_name, orig_fn))
+        if workload == "model":
+            # the decoder's widest GEMM (1536 -> 384 over B*N points): a module call in the channels-first layout, a
+            # pointwise_from_cl() call (same rocBLAS GEMM, transposed operand) in the point-major one
+            hooks = gemm_timer.hook(model.propogation_0.mlp.layer1.conv)
+            import geot_amd.openpoints.models.backbone.transformer as tr_mod
+            orig_from_cl = tr_mod.pointwise_from_cl
+            gemm_timer.only = lambda w, z, **kw: tuple(w.shape) == (384, 1536) and z.shape[1] == N_POINTS
+            tr_mod.pointwise_from_cl = gemm_timer.wrap(orig_from_cl)
+            undo.append(lambda: [setattr(tr_mod, "pointwise_from_cl", orig_from_cl)] + [h.remove() for h in hooks])
+        if workload == "sa" and not args.graph:
+            import geot_amd.sa_fused as sa_fused_mod
+            orig_mlp = sa_fused_mod.fused_group_mlp_max
+            sa_fused_mod.fused_group_mlp_max = mlp_timer.wrap(orig_mlp)
+            undo.append(lambda: setattr(sa_fused_mod, "fused_group_mlp_max", orig_mlp))
+        return undo
+
+    undo = [] if use_graph else install_timers()
     if args.streams > 1 and workload == "sa":
         pool = [torch.cuda.Stream(device=dev) for _ in range(args.streams)]
         dealt = [0]
@@ -565,15 +554,24 @@ def main():
     else:
         elapsed, out = timed_steps(step, args.steps, dev, rehearsal)
     HOST_ISSUE_MAIN["ms"] = 1e3 * HOST_ISSUE["s"] / max(args.steps, 1)
-    if patch_owner is not None:
-        setattr(patch_owner, patch_name, orig_fn)
-    if workload == "sa" and not args.graph:
-        sa_fused_mod.fused_group_mlp_max = orig_mlp
-    if workload == "model":
-        tr_mod.pointwise_from_cl = orig_from_cl
-    for h in unpatch:
-        h.remove()
+    HOST_ISSUE_MAIN["cpu_ms"] = 1e3 * HOST_ISSUE["cpu_s"] / max(args.steps, 1)
     assert torch.isfinite(out).all()
+    eager_leg = None
+    if use_graph:
+        # the same iterations issued eagerly (one launch at a time from the host), in this run: what the replay is worth,
+        # and where the per-kernel HIP events are taken
+        undo = install_timers()
+        k_e = max(2, min(args.steps, 10))
+        eager_step()                            # untimed: the eager look-ahead restarts here
+        t_e, out_e = timed_steps(eager_step, k_e, dev, rehearsal)
+        assert torch.isfinite(out_e).all()
+        eager_leg = {"ms_per_step": 1e3 * t_e / k_e, "clouds_per_s": clouds_per_step * k_e / t_e,
+                     "host_issue_ms_per_step": 1e3 * HOST_ISSUE["s"] / k_e,
+                     "host_cpu_ms_per_step": 1e3 * HOST_ISSUE["cpu_s"] / k_e, "steps": k_e,
+                     "note": "the same iterations, same model state continuing, launched kernel by kernel from the host "
+                             "(--no-graph times this leg alone)"}
+    for u in undo:
+        u()
 
     ms_per_step = 1e3 * elapsed / args.steps
     fps_ms = fps_timer.mean_ms()
@@ -600,7 +598,8 @@ def main():
         "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic flop = clouds*N*(m-1) updates "
                 "* 10 (what the reference executes); the pruned kernel skips most of them exactly; one workgroup "
                 "(one CU of 256) per cloud; avg_launch_ms is the launch as it ran inside the step (side stream, sharing its CUs "
-                "with the main stream's GEMMs), alone_launch_ms the same launch with the chip to itself"}
+                "with the main stream's GEMMs) -- under the default hipGraph replay taken on the eager leg of the same run, "
+                "where HIP events can bracket one launch; alone_launch_ms the same launch with the chip to itself"}
     result = {
         "metric": "point-clouds/sec (24k pts, 17 classes) fwd+bwd" if workload in ("model", "fixmatch") else
                   "point-clouds/sec (24k pts, 17 classes)",
@@ -610,7 +609,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
-        "host_issue_ms_per_step": HOST_ISSUE_MAIN.get("ms"),   # host time to queue a step (rank 0): << ms_per_step = GPU-bound
+        "host_issue_ms_per_step": HOST_ISSUE_MAIN.get("ms"),   # wall time until the host has queued a step (rank 0); it
+        # includes time BLOCKED on a full hardware queue, so it approaches ms_per_step whenever the GPU is the bottleneck
+        "host_cpu_ms_per_step": HOST_ISSUE_MAIN.get("cpu_ms"),  # CPU time (all threads) spent queueing a step: the host's cost
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -637,7 +638,7 @@ def main():
             "frac": g_tf / FP32_MATRIX_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": g_ms,
             "note": "algorithmic flop = 2*384*1536*B*N per forward launch; library kernel (dense layers are stock "
                     "PyTorch -> rocBLAS, SURVEY.md 2.1 row 12), timed with HIP events from module hooks"}
-        att = hot_path_attribution(step)
+        att = hot_path_attribution(eager_step)
         hot_ms = sum(att.values())
         top = dict(sorted(att.items(), key=lambda kv: -kv[1])[:8])
         result["hot_path"] = {"c_abi_gpu_ms_per_step": hot_ms, "share_of_step": hot_ms / ms_per_step,
@@ -673,7 +674,7 @@ def main():
     if workload == "fixmatch":
         fps_roofline.update(kernel="fps_pruned_kernel<768,32,false,8> (the student's pointops.fps 24000 -> 8192 over its "
                                    "%d clouds: the longest kernel of the iteration; the teacher runs the same on %d)" % (fps_clouds, bu))
-        att = hot_path_attribution(step)
+        att = hot_path_attribution(eager_step)
         hot_ms = sum(att.values())
         result["hot_path"] = {"c_abi_gpu_ms_per_step": hot_ms, "share_of_step": hot_ms / ms_per_step,
                               "top_entry_points_ms": dict(sorted(att.items(), key=lambda kv: -kv[1])[:8]),
@@ -703,15 +704,25 @@ def main():
                           "exposed_allreduce_ms": ms_per_step - 1e3 * t_local / k2,
                           "note": "exposed = timed step minus the same step under DDP.no_sync() (%d steps); negative = noise" % k2}
     if workload in ("model", "fixmatch"):
+        result["graph"] = {"replayed": bool(use_graph),
+                           "note": ("geot_amd/graph_step.py: two single-stream hipGraphs per iteration (training graph + the next "
+                                    "batch's look-ahead graph on a side stream), bit-identical to the eager step "
+                                    "(tests/test_graph_step_gpu.py); host_issue_ms_per_step is the host's whole share of a step") if use_graph else
+                                   ("eager: N > 1 runs DistributedDataParallel, whose buckets and collectives are host logic"
+                                    if world > 1 else "eager (--no-graph)")}
+        if eager_leg is not None:
+            result["eager"] = eager_leg
         result["config"]["lookahead"] = ("the step is handed the next batch's coordinates (two batches alternate) and queues "
                                          "their sampling / grouping / index work beside its own backward"
                                          if lookahead else "off: all of a batch's work inside its own step")
     if workload in ("model", "fixmatch") and world == 1 and lookahead and not args.no_dense_reference:
         # the same steps without the look-ahead (every batch's sampling at the head of its own step), observed in this run
+        runner = graphed if use_graph else trainer      # (the replay's "plain" variant is captured by the first call)
+
         def plain_step():
             cur = batches[turn[0] % 2]
             turn[0] += 1
-            return trainer(cur[0], cur[1], cur[2]) if workload == "model" else trainer(cur[0], cur[1])["loss"]
+            return runner(cur[0], cur[1], cur[2]) if workload == "model" else runner(cur[0], cur[1])["loss"]
         plain_step()
         k3 = min(args.steps, 10)
         t_plain, _ = timed_steps(plain_step, k3, dev, rehearsal)
@@ -722,6 +733,8 @@ def main():
         # the same step with every layer in the REFERENCE's op order (first 1x1 conv after the gather, op-by-op attention /
         # LayerNorm) on the same kernels: what the algebraic re-ordering is worth, observed in this run
         del trainer, net
+        graphed = runner = eager_step = step = None      # (the replay holds the trainer and its graph's memory pool)
+        torch.cuda.empty_cache()
         torch.manual_seed(1609)
         ref_model = PointTransformer_seg_T(**TOOTH_SEG_CFG, dense="reference").to(dev)
         ref_model.load_state_dict(model.state_dict())

@@ -1,70 +1,73 @@
-"""The training steps of train_step.py replayed from a hipGraph: the host queues ONE graph launch per iteration instead of
-the ~1100 (supervised) / ~1500 (FixMatch+NTM) kernel launches, autograd bookkeeping included, that take 21-28 ms of host
-time per step -- at the authors' own operating point (16 000 points, 2 + 2 clouds) the whole step.
+"""The training steps of train_step.py replayed from hipGraphs: per iteration the host issues a handful of small copies and
+TWO graph launches instead of ~1100 (supervised) / ~1500 (FixMatch+NTM) kernel launches with their autograd bookkeeping
+(18-24 ms of host time per iteration -- at one or two clouds per step, the whole step).
 
     step    = SupervisedStep(model)                      # or build_fixmatch(...)
     graphed = GraphedSupervisedStep(step)                # or GraphedFixMatchStep(step)
     loss    = graphed(pos, cls, target, next_pos=...)    # same call, same results, bit for bit
 
-What is captured is the step's own `iteration()` -- forward, loss, backward, AdamW, the side-stream index plan, the
-teacher's stream and the look-ahead, as fork / joins of one graph -- over FIXED buffers:
+An iteration is two SINGLE-STREAM graphs (geot_amd/streams.py: on ROCm 7.0 a graph with fork / join branches costs the host
+6-17 ms per launch, a single-stream one of the same kernels 0.3 ms):
 
-* the batch is copied into static input tensors before every replay (a few small device-to-device copies);
-* the look-ahead's product -- the geometry of the NEXT batch (Group, the 8192-sample FPS, the index plan) -- is written by
-  the graph into buffers of its own and copied into a static geometry at the graph's tail, behind everything that read the
-  current one; the next replay consumes it.  Whether the static geometry describes the batch a call passes is checked on
-  the host (the tensor the previous call announced, unedited); otherwise it is recomputed before the replay;
-* the optimisers run with capturable=True (the step counters live on the device either way under fused=True: the same
-  kernel, the same arithmetic), the EMA transition matrix is updated in its buffer.
+* **P** -- the step's `lookahead_work()`: everything that depends on a batch and on frozen state alone.  Supervised step:
+  the batch's geometry (Group, the 8192-sample FPS, the index plan).  FixMatch+NTM: the student's and the teacher's
+  geometry, the frozen teacher's forward -> pseudo labels, the kNN graph and Morton order of the 3-D loss.
+* **M** -- the training iteration proper over P's product: forward, losses, backward, AdamW (capturable=True; under
+  fused=True the step counters live on the device either way: the same kernel), the EMA transition matrix updated in
+  its buffer.
 
-The first `warmup` calls run the same iteration eagerly over the same buffers (library handles, workspaces, lazily
-initialised state), the next call captures and replays.  Shapes are fixed at the first call; a batch of another shape is an
-error (build another wrapper).  DistributedDataParallel is not captured: its bucket hooks and RCCL's collectives are host
-logic (train_step.ddp() wraps eagerly; graph_step refuses a DDP-wrapped model).
+With `next_pos` / `next_batches` given, P of the NEXT batch replays on a side stream beside M of the current one -- the
+overlap the eager steps build from side streams inside the iteration, here between two graphs; its product is copied into
+M's input buffers at the head of the next call, behind M.  Whether that product describes the batch a call passes is
+checked on the host (the very tensors the previous call announced, unedited); otherwise -- the first call, a reshuffled
+loader, no look-ahead at all -- P runs for the current batch on the current stream before M.
 
-Mirrors the loop body of examples/segmentation/train.py:410-669; the reference has no counterpart (it never leaves eager
-mode) -- this is the MI355X answer to a step that is host-bound at the reference's own batch sizes.
+Inputs are copied into static buffers before every replay; shapes are fixed by the first call (another shape is an error:
+build another wrapper).  The first `warmup` executions of each graph's body run eagerly over the same buffers, the next
+one captures.  DistributedDataParallel is not captured (gradient buckets and RCCL's collectives are host logic): N > 1
+runs the eager steps.
+
+Mirrors the loop body of examples/segmentation/train.py:410-669; the reference never leaves eager mode.
 """
 import copy
+import os
 
 import torch
 
 from . import streams
 from .fused_norm import ReverseIndex
 
+_IDENTITY_KEYS = ("pts", "version", "grouped", "src")     # of a geometry: tensor identities and events, never copied
 
-# ---- structure helpers: geometries are dicts / tuples of tensors, ReverseIndex objects, events and python scalars ------
+
+# ---- structure helpers: P's product is a tree of dicts / tuples of tensors, ReverseIndex objects and python scalars ------
 def tree_clone(obj):
-    """Fresh buffers with the same contents (events dropped)."""
+    """Fresh buffers with the same contents."""
     if torch.is_tensor(obj):
         return obj.detach().clone()
     if isinstance(obj, dict):
-        return {k: tree_clone(v) for k, v in obj.items()}
+        return {k: (None if k in _IDENTITY_KEYS else tree_clone(v)) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
         return type(obj)(tree_clone(v) for v in obj)
     if isinstance(obj, ReverseIndex):
         new = copy.copy(obj)
         new.ws, new.order = tree_clone(obj.ws), tree_clone(obj.order)
         return new
-    if isinstance(obj, torch.cuda.Event):
-        return None
     return obj
 
 
-def tree_copy_(dst, src, path="geometry"):
+def tree_copy_(dst, src, path="pre"):
     """Copy every tensor of `src` into the matching buffer of `dst`; the structure (and every python scalar) must agree."""
     if torch.is_tensor(dst):
         if not torch.is_tensor(src) or dst.shape != src.shape or dst.dtype != src.dtype:
             raise RuntimeError("%s: the captured buffer does not fit (shape / dtype changed)" % path)
-        if dst.data_ptr() != src.data_ptr():
-            dst.copy_(src)
+        dst.copy_(src)
     elif isinstance(dst, dict):
         for k, v in dst.items():
-            if k in ("pts", "version", "grouped", "src", "static"):
-                continue
-            tree_copy_(v, src[k], "%s[%r]" % (path, k))
+            if k not in _IDENTITY_KEYS:
+                tree_copy_(v, src[k], "%s[%r]" % (path, k))
     elif isinstance(dst, (list, tuple)):
-        if len(dst) != len(src):
+        if not isinstance(src, (list, tuple)) or len(dst) != len(src):
             raise RuntimeError("%s: structure changed" % path)
         for i, (d, s) in enumerate(zip(dst, src)):
             tree_copy_(d, s, "%s[%d]" % (path, i))
@@ -74,213 +77,179 @@ def tree_copy_(dst, src, path="geometry"):
         tree_copy_(dst.ws, src.ws, path + ".ws")
         if dst.order is not None:
             tree_copy_(dst.order, src.order, path + ".order")
-    elif dst is None:
-        if src is not None and not isinstance(src, torch.cuda.Event):
-            raise RuntimeError("%s: structure changed" % path)
     elif dst != src:
         raise RuntimeError("%s: %r became %r" % (path, dst, src))
 
 
-def _static_geometry(g, pts):
-    """A geometry in buffers of its own that the model takes on the caller's word (transformer.py `static`)."""
-    if g is None:
-        return None
-    out = tree_clone({k: v for k, v in g.items() if k not in ("pts", "version", "grouped", "src")})
-    out.update(pts=pts, version=None, grouped=None, static=True)
-    return out
+def _fits(dst, src, what):
+    if dst.shape != src.shape or dst.dtype != src.dtype:
+        raise RuntimeError("graphed step: %s is %s %s, captured for %s %s" % (what, tuple(src.shape), src.dtype,
+                                                                              tuple(dst.shape), dst.dtype))
 
 
 class _Graphed:
-    def __init__(self, step, warmup=3):
-        for net in self._modules(step):
+    """P / M bookkeeping shared by the two steps; subclasses supply the static buffers and the two bodies."""
+
+    def __init__(self, step, warmup=2):
+        for net in (getattr(step, n, None) for n in ("model", "model_t", "T_predictor")):
             if isinstance(net, torch.nn.parallel.DistributedDataParallel):
                 raise RuntimeError("graph_step: a DistributedDataParallel model is not captured (its gradient buckets and "
                                    "collectives are host logic); run N > 1 eagerly")
+        import geot_amd
+        if not geot_amd.graph_replay_is_safe() and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
+            raise RuntimeError(
+                "graph_step: %s must be 0 before the HIP runtime initialises (import geot_amd before the first torch.cuda "
+                "call, or export it): with graph packet capture on, eager launches between two replays corrupt the "
+                "graph's memset nodes -- wrong gradients, no error (geot_amd/__init__.py)" % geot_amd.GRAPH_PACKET_CAPTURE_ENV)
         self.step = step
         self.warmup = int(warmup)
         self.calls = 0
-        self.graphs = {}                     # variant (look-ahead or not) -> (CUDAGraph, static outputs)
-        self._stream = None
-        self._pool = None
+        self.device = None
+        self.graphs = {}          # "P" / "M" -> (CUDAGraph, static outputs)
+        self._eager_runs = {"P": 0, "M": 0}
+        self.side = None          # the stream P replays on beside M
+        self.pre = None           # P's product in M's input buffers
+        self._pre_next = None     # P's product as P left it (for the batch `_announced` describes)
+        self._announced = None
+        self._pending = False     # a P is in flight on the side stream
         for opt in step.optimizers():
             for group in opt.param_groups:
                 group["capturable"] = True   # fused AdamW: the step counter is a device tensor already; same kernel
 
-    @staticmethod
-    def _modules(step):
-        return [m for m in (getattr(step, "model", None), getattr(step, "model_t", None), getattr(step, "T_predictor", None))
-                if m is not None]
-
-    def _run(self, variant, fn):
-        """fn() = the iteration over the static buffers, returning its static outputs.  Eager for the first `warmup` calls
-        (on a side stream, torch's capture recipe), then captured once per variant and replayed."""
-        dev = self.device
-        if variant not in self.graphs and self.calls < self.warmup:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream(device=dev)
-            main = torch.cuda.current_stream(dev)
-            self._stream.wait_stream(main)
-            with torch.cuda.stream(self._stream):
-                out = fn()
-            main.wait_stream(self._stream)
-            self.calls += 1
-            return out
-        if variant not in self.graphs:
-            torch.cuda.synchronize(dev)
+    def _run(self, name, fn):
+        """fn() = a graph's body over the static buffers.  Eager for its first `warmup` executions, then captured once
+        and replayed on the current stream."""
+        if name not in self.graphs:
+            if self._eager_runs[name] < self.warmup:
+                self._eager_runs[name] += 1
+                return fn()
+            torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
-            if self._pool is None:
-                self._pool = torch.cuda.graph_pool_handle()
-            with streams.capture(graph, dev, pool=self._pool):
+            with streams.capture(graph, self.device):
                 out = fn()
-            self.graphs[variant] = (graph, out)
-        graph, out = self.graphs[variant]
+            self.graphs[name] = (graph, out)
+        graph, out = self.graphs[name]
         graph.replay()
-        self.calls += 1
         return out
 
     @property
     def captured(self):
-        return bool(self.graphs)
+        return "M" in self.graphs and "P" in self.graphs
+
+    def _join_pending(self):
+        """The current stream waits for the P of the previous call (its product, and its reads of P's static inputs)."""
+        if self._pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+            self._pending = False
+
+    def _iterate(self, announced_now, next_src, load_next, lookahead, train):
+        """announced_now: does the pending look-ahead describe the batch that was just copied in?  next_src: the tensors
+        of the announced next batch (None: no look-ahead); load_next(current: bool): fill P's static inputs from the
+        current batch / the announced one; lookahead() / train(): the bodies of P / M.  (_join_pending() has run.)"""
+        dev = self.device
+        main = torch.cuda.current_stream(dev)
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=dev)
+        if not (announced_now and self._pre_next is not None):
+            # nobody looked ahead for this batch (first call, an unannounced batch, no look-ahead): P now, in line
+            load_next(True)
+            self._pre_next = self._run("P", lookahead)
+        with torch.no_grad():
+            if self.pre is None:
+                self.pre = tree_clone(self._pre_next)
+            else:
+                tree_copy_(self.pre, self._pre_next)
+        self._pre_next = None
+        self._announced = None
+        if next_src is not None:
+            load_next(False)
+            self.side.wait_stream(main)              # behind the copies above (and behind M's previous replay)
+            with torch.cuda.stream(self.side):
+                self._pre_next = self._run("P", lookahead)
+            self._pending = True
+            self._announced = tuple((t, t._version) for t in next_src)
+        out = self._run("M", train)
+        self.calls += 1
+        return out
+
+    def _is_announced(self, tensors):
+        a = self._announced
+        return a is not None and len(a) == len(tensors) and all(t is s and t._version == v for t, (s, v) in zip(tensors, a))
 
 
 class GraphedSupervisedStep(_Graphed):
-    """SupervisedStep.__call__ from a hipGraph (see the module docstring).  The returned loss is a static tensor the next
+    """SupervisedStep.__call__ from hipGraphs (see the module docstring).  The returned loss is a static tensor the next
     call overwrites: clone it to keep it."""
 
-    def __init__(self, step, warmup=3):
+    def __init__(self, step, warmup=2):
         super().__init__(step, warmup)
         self.x = None            # static (pos, cls, target)
-        self.next_pos = None     # static coordinates of the announced batch
-        self.geometry = None     # static geometry of x's coordinates
-        self._announced = None   # (tensor, version) the static geometry describes
-
-    def _inner(self):
-        m = self.step.model
-        return m.module if hasattr(m, "module") else m
+        self.next_pos = None     # static coordinates P works on
 
     def __call__(self, pos, cls, target, next_pos=None):
-        inner = self._inner()
-        look = next_pos is not None and hasattr(inner, "prefetch_geometry")
         if self.x is None:
             self.device = pos.device
             self.x = (pos.detach().clone().contiguous(), cls.detach().clone(), target.detach().clone())
             self.next_pos = torch.empty_like(self.x[0])
         for dst, src, name in zip(self.x, (pos, cls, target), ("pos", "cls", "target")):
-            if dst.shape != src.shape or dst.dtype != src.dtype:
-                raise RuntimeError("graphed step: %s is %s %s, captured for %s %s" % (name, tuple(src.shape), src.dtype,
-                                                                                      tuple(dst.shape), dst.dtype))
-        fresh = not (self._announced is not None and pos is self._announced[0] and pos._version == self._announced[1])
-        self.x[0].copy_(pos)
-        self.x[1].copy_(cls)
-        self.x[2].copy_(target)
-        geometry = None
-        if look:
-            if fresh or self.geometry is None:
-                # not the batch the previous call announced (the first call, a reshuffle): its geometry now, in line
-                from .train_step import _mode
-                _mode(self.step.model, True)
-                g = inner.prefetch_geometry(self.x[0])
-                if g is None:
-                    look = False
-                else:
-                    torch.cuda.current_stream(self.device).wait_stream(inner_side(inner, self.device))
-                    if self.geometry is None:
-                        self.geometry = _static_geometry(g, self.x[0])
-                    else:
-                        tree_copy_(self.geometry, g)
-            geometry = self.geometry if look else None
-        if look:
-            self.next_pos.copy_(next_pos)
-        self._announced = None
+            _fits(dst, src, name)
+        if next_pos is not None:
+            _fits(self.next_pos, next_pos, "next_pos")
+        announced_now = self._is_announced((pos,))
+        self._join_pending()
+        for dst, src in zip(self.x, (pos, cls, target)):
+            dst.copy_(src)
 
-        def iteration():
-            loss, g_next = self.step.iteration(self.x[0], self.x[1], self.x[2], geometry, self.next_pos if look else None,
-                                               static=True)
-            if look:
-                with torch.no_grad():
-                    tree_copy_(self.geometry, g_next)      # behind the joins: every reader of the current one is done
-            return loss
-        loss = self._run("lookahead" if look else "plain", iteration)
-        if look:
-            self._announced = (next_pos, next_pos._version)
-        return loss
+        def load_next(current):
+            self.next_pos.copy_(self.x[0] if current else next_pos)
+
+        def lookahead():
+            return self.step.lookahead_work(self.next_pos)
+
+        def train():
+            return self.step.iteration(self.x[0], self.x[1], self.x[2], self.pre, None)[0]
+        return self._iterate(announced_now, None if next_pos is None else (next_pos,), load_next, lookahead, train)
 
 
-def inner_side(segmentor_or_wrapper, device):
-    seg = getattr(segmentor_or_wrapper, "segmentor", segmentor_or_wrapper)
-    return seg._side_stream(device)
-
-
-_NEXT_KEYS = (("pos",), ("pos_s", "pos_w"))
+_P_KEYS = (("pos",), ("pos_s", "pos_w", "x_w", "cls_w", "raw_pos"))      # what FixMatchNTMStep.lookahead_work reads
 
 
 class GraphedFixMatchStep(_Graphed):
-    """FixMatchNTMStep.__call__ from a hipGraph.  The returned losses are static tensors the next call overwrites."""
+    """FixMatchNTMStep.__call__ from hipGraphs.  The returned losses are static tensors the next call overwrites."""
 
-    def __init__(self, step, warmup=3):
+    def __init__(self, step, warmup=2):
         super().__init__(step, warmup)
         self.data = self.data_u = None       # static batch dicts
-        self.next = None                     # static coordinates of the announced batches
-        self.geometry = None                 # [student, teacher] static geometries
-        self._announced = None
-
-    def _copy_in(self, dst, src, what):
-        for k, v in dst.items():
-            s = src[k]
-            if v.shape != s.shape or v.dtype != s.dtype:
-                raise RuntimeError("graphed FixMatch step: %s[%r] is %s, captured for %s" % (what, k, tuple(s.shape), tuple(v.shape)))
-            v.copy_(s)
+        self.next = None                     # static inputs of P
 
     def __call__(self, data, data_u, next_batches=None):
         step = self.step
-        inner = step.model.module if hasattr(step.model, "module") else step.model
-        look = next_batches is not None
         if self.data is None:
             self.device = data["pos"].device
             self.data = {k: v.detach().clone().contiguous() for k, v in data.items() if torch.is_tensor(v)}
             self.data_u = {k: v.detach().clone().contiguous() for k, v in data_u.items() if torch.is_tensor(v) and k != "T"}
-            self.next = ({"pos": torch.empty_like(self.data["pos"])},
-                         {"pos_s": torch.empty_like(self.data_u["pos_s"]), "pos_w": torch.empty_like(self.data_u["pos_w"])})
-        src = (data["pos"], data_u["pos_s"], data_u["pos_w"])
-        fresh = not (self._announced is not None and all(t is a for t, a in zip(src, self._announced[0]))
-                     and all(t._version == v for t, v in zip(src, self._announced[1])))
-        self._copy_in(self.data, data, "data")
-        self._copy_in(self.data_u, data_u, "data_u")
-        geoms = (None, None)
-        if look:
-            if fresh or self.geometry is None:
-                from .train_step import _mode
-                _mode(step.model, True)
-                _mode(step.model_t, False)
-                g_s = inner.prefetch_geometry(self.data, self.data_u, fixmatch=True)
-                g_t = step.model_t.prefetch_geometry(self.data_u, if_teacher=True)
-                if g_s is None or g_t is None:
-                    look = False
-                else:
-                    main = torch.cuda.current_stream(self.device)
-                    main.wait_stream(inner_side(inner, self.device))
-                    main.wait_stream(inner_side(step.model_t, self.device))
-                    if self.geometry is None:
-                        self.geometry = [_static_geometry(g_s, None), _static_geometry(g_t, None)]
-                    else:
-                        tree_copy_(self.geometry[0], g_s)
-                        tree_copy_(self.geometry[1], g_t)
-            if look:
-                geoms = tuple(self.geometry)
-                for dst, batch, keys in zip(self.next, next_batches, _NEXT_KEYS):
-                    for k in keys:
-                        dst[k].copy_(batch[k])
-        self._announced = None
+            self.next = tuple({k: torch.empty_like(d[k]) for k in keys} for d, keys in zip((self.data, self.data_u), _P_KEYS))
+        for dst, src, what in ((self.data, data, "data"), (self.data_u, data_u, "data_u")):
+            for k, v in dst.items():
+                _fits(v, src[k], "%s[%r]" % (what, k))
+        announced_now = self._is_announced([b[k] for b, keys in zip((data, data_u), _P_KEYS) for k in keys])
+        self._join_pending()
+        for dst, src in ((self.data, data), (self.data_u, data_u)):
+            for k, v in dst.items():
+                v.copy_(src[k])
 
-        def iteration():
-            losses, g_next = step.iteration(self.data, self.data_u, geoms, self.next if look else None, static=True)
-            if look:
-                with torch.no_grad():
-                    tree_copy_(self.geometry[0], g_next[0])
-                    tree_copy_(self.geometry[1], g_next[1])
-            return losses
-        losses = self._run("lookahead" if look else "plain", iteration)
-        if look:
-            nsrc = (next_batches[0]["pos"], next_batches[1]["pos_s"], next_batches[1]["pos_w"])
-            self._announced = (nsrc, tuple(t._version for t in nsrc))
-        return losses
+        def load_next(current):
+            srcs = (self.data, self.data_u) if current else next_batches
+            for dst, src, keys in zip(self.next, srcs, _P_KEYS):
+                for k in keys:
+                    _fits(dst[k], src[k], "next[%r]" % k)
+                    dst[k].copy_(src[k])
+
+        def lookahead():
+            return step.lookahead_work(self.next[0], self.next[1])
+
+        def train():
+            pre = self.pre
+            return step.student_iteration(self.data, self.data_u, pre["geom_s"], pre["pseudo"], pre["knn"], ema_in_place=True)
+        next_src = None if next_batches is None else [b[k] for b, keys in zip(next_batches, _P_KEYS) for k in keys]
+        return self._iterate(announced_now, next_src, load_next, lookahead, train)

@@ -531,13 +531,25 @@ class PointTransformer_seg_T(nn.Module):
             return self._forward(pts, x, cls_label, T, geometry)
 
     @torch.no_grad()
-    def prefetch_geometry(self, pts):
+    def prefetch_geometry(self, pts, inline=False):
         """Queue everything forward() derives from the COORDINATES of a batch -- Group (512-sample FPS, kNN, the
         neighbourhoods), the 8192-sample FPS and the index plan -- on the side stream, for a batch that will be passed
         to forward(pts, ..., geometry=<the result>) later: a training loop calls this with batch k + 1 between the
         forward and the backward of batch k, so that ~6.5 ms of few-workgroup kernels run beside the GEMM-bound backward
         instead of at the head of the next step and beside its (shorter) encoder.  GEOT_LOOKAHEAD=group queues Group only.  Same kernels on the same inputs: the
         results are those forward() would compute itself.  None when the model cannot use it (CPU, overlap off)."""
+        if inline:
+            # the same work on the CURRENT stream, handed back as a geometry the caller vouches for ("static"): graph_step.py
+            # captures it as a single-stream graph and replays that beside the training graph
+            if not (pts.is_cuda and self.dense == "factored"):
+                return None
+            pts = pts.contiguous()
+            with pointops.fps_prefix_scope():
+                group = self.group_divider(pts)
+                pointops.fps_indices(pts, max(self.downsample_targets))
+                plan = self._index_plan(pts, group[1])
+            return {"pts": pts, "version": None, "group": group, "grouped": None, "plan": plan, "training": self.training,
+                    "fp_layout": self.fp_layout, "static": True}
         if not (pts.is_cuda and self.overlap and self.dense == "factored" and streams.may_fork(pts.device)):
             return None
         pts = pts.contiguous()

@@ -47,13 +47,15 @@ class WholePartSeg(nn.Module):
             return views[0].detach()
         return views[0] if len(views) == 1 else torch.cat(views, 0)
 
-    def prefetch_geometry(self, p0, u0=None, if_teacher=False, fixmatch=False):
+    def prefetch_geometry(self, p0, u0=None, if_teacher=False, fixmatch=False, inline=False):
         """Queue the coordinate-only work of the batch a LATER forward(p0, ..., geometry=<result>) will see
         (PointTransformer_seg_T.prefetch_geometry); None when the segmentor has no such thing.  The result remembers WHICH
         tensors it was computed from (`src`: the caller's coordinate tensors and their version counters): forward() takes it
         only for exactly those tensors, unedited."""
         if not hasattr(self.segmentor, "prefetch_geometry"):
             return None
+        if inline:       # on the current stream, for a caller that vouches for it (graph_step.py)
+            return self.segmentor.prefetch_geometry(self.batch_positions(p0, u0, if_teacher, fixmatch), inline=True)
         g = self.segmentor.prefetch_geometry(self.batch_positions(p0, u0, if_teacher, fixmatch))
         if g is not None:
             g["src"] = tuple((t, t._version) for t in self._position_views(p0, u0, if_teacher, fixmatch))

@@ -1,24 +1,27 @@
 """Stream plumbing for hipGraph capture (graph_step.py, bench.py --graph, the capture tests).
 
-Two properties of ROCm 7.0's stream capture shape how this package forks work onto side streams while capturing:
+What ROCm 7.0's graphs can and cannot do shaped how this package uses them (profiles/r04_graph_capture_notes.txt):
 
-* **Forks only from the capture's origin stream.**  hipStreamWaitEvent re-registers every NON-origin stream that waits on a
-  captured event as a "parallel capture stream" of the stream the event was recorded on.  Two forks that wait on each other
-  (a side stream started behind the teacher's stream and joined back into it) are then in each other's lists, and
-  hipStreamEndCapture -- which ends the capture on every stream of those lists, recursively -- never returns: the process
-  dies of a stack overflow inside hip::Stream::EndCapture (native backtrace: profiles/r04_graph_capture_notes.txt).  Waits
-  between the origin and a fork are fine in both directions.  `may_fork(dev)` is therefore false on any stream but the
-  origin while a capture is in progress, and the segmentor keeps its sampling in line there.
-* Events recorded during a capture are kept alive until it has ended (torch's Stream.wait_stream drops its temporary event
-  at once; the runtime keeps a list of the capture's events and visits it at the end).  Not observed to fault; it costs a
-  list of a few dozen handles.
+* A captured graph with fork / join branches replays, but its launch costs the HOST 6-17 ms (the runtime walks the branches
+  and synchronises them from the host), and two forks that wait on EACH OTHER -- a side stream started behind the
+  teacher's stream and joined back into it -- put each stream into the other's "parallel capture streams" list, on which
+  hipStreamEndCapture recurses without end: a stack overflow inside hip::Stream::EndCapture.  A SINGLE-STREAM graph of the
+  same ~1000 kernels launches in 0.3 ms.
+* So nothing forks while a capture is in progress (`may_fork` is false): the captured pieces are single-stream graphs, and
+  the overlap the eager steps get from side streams comes from replaying two such graphs on two streams (graph_step.py).
+* Events recorded during a capture are kept alive until it has ended (torch's Stream.wait_stream drops its temporary
+  event at once; the runtime keeps the capture's events in a list it visits at the end).  Not observed to fault; it costs
+  a list of handles.
 """
 import contextlib
 
 import torch
 
 _KEPT = None        # events of the capture in progress (None: no capture)
-_ORIGIN = None      # the stream the capture in progress was begun on
+
+
+def capturing():
+    return _KEPT is not None
 
 
 def event(**kw):
@@ -30,17 +33,15 @@ def event(**kw):
 
 
 def may_fork(device):
-    """May work be queued on a side stream behind the current stream of `device`?  Always outside a capture; inside one
-    only from the origin stream (see the module docstring)."""
-    return _ORIGIN is None or torch.cuda.current_stream(device) == _ORIGIN
+    """May work be queued on a side stream behind the current stream of `device`?  Not while a capture is in progress."""
+    return _KEPT is None
 
 
 @contextlib.contextmanager
-def capture(graph, device, pool=None):
-    """`with torch.cuda.graph(graph, pool=pool)` that records the origin stream for may_fork() and keeps the capture's
-    events alive until hipStreamEndCapture has returned."""
-    global _KEPT, _ORIGIN
-    if _ORIGIN is not None:
+def capture(graph, device=None, pool=None):
+    """`with torch.cuda.graph(graph, pool=pool)` during which may_fork() is false and every event stays alive."""
+    global _KEPT
+    if _KEPT is not None:
         raise RuntimeError("geot_amd.streams.capture: a capture is already in progress")
     orig = torch.cuda.Stream.record_event
 
@@ -53,11 +54,7 @@ def capture(graph, device, pool=None):
     torch.cuda.Stream.record_event = record_event
     try:
         with torch.cuda.graph(graph, pool=pool):
-            _ORIGIN = torch.cuda.current_stream(device)
-            try:
-                yield
-            finally:
-                _ORIGIN = None
+            yield
     finally:
         torch.cuda.Stream.record_event = orig
         kept, _KEPT = _KEPT, None

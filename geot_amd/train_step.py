@@ -115,31 +115,6 @@ def _lookahead_at_blocks(segmentor, default):
     return os.environ.get("GEOT_LOOKAHEAD_AT", default) == "blocks" and hasattr(segmentor, "at_blocks_backward")
 
 
-def _is_capturing(stream):
-    with torch.cuda.stream(stream):
-        return torch.cuda.is_current_stream_capturing()
-
-
-def _rejoin(dev, *streams):
-    """Static mode (graph_step.py): the current stream waits for every side stream the iteration used, so that the iteration
-    ends as ONE stream -- a hipGraph capture must have joined all its forks, and the fixed geometry buffers are refilled
-    behind everything that read them.  Under capture only the streams that are part of the capture are joined.  (All of
-    them were forked from the current stream = the capture's origin: geot_amd/streams.py explains why nothing else is.)"""
-    if dev.type != "cuda":
-        return
-    main = torch.cuda.current_stream(dev)
-    capturing = torch.cuda.is_current_stream_capturing()
-    for s in streams:
-        if s is not None and s != main and (not capturing or _is_capturing(s)):
-            main.wait_stream(s)
-
-
-def _segmentor_side_streams(module):
-    inner = module.module if hasattr(module, "module") else module
-    seg = getattr(inner, "segmentor", inner)
-    return list(getattr(seg, "_side", {}).values())
-
-
 class SupervisedStep:
     def __init__(self, model, lr=1e-3, weight_decay=1e-4, grad_norm_clip=None):
         self.model = model
@@ -162,9 +137,16 @@ class SupervisedStep:
         loss, self._geometry = self.iteration(pos, cls, target, geometry, next_pos)
         return loss
 
-    def iteration(self, pos, cls, target, geometry=None, next_pos=None, static=False):
-        """One iteration -> (detached loss, the geometry queued for next_pos or None).  static (graph_step.py): every side
-        stream is joined before returning (see _rejoin)."""
+    def lookahead_work(self, pos):
+        """Everything of an iteration that depends on its batch alone (the geometry: Group, the 8192-sample FPS, the index
+        plan), on the CURRENT stream -> what iteration(geometry=...) takes.  graph_step.py replays this as a graph of its
+        own beside the previous iteration's training graph."""
+        _mode(self.model, True)
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        return inner.prefetch_geometry(pos, inline=True) if hasattr(inner, "prefetch_geometry") else None
+
+    def iteration(self, pos, cls, target, geometry=None, next_pos=None):
+        """One iteration -> (detached loss, the geometry queued for next_pos or None)."""
         _mode(self.model, True)
         inner = self.model.module if hasattr(self.model, "module") else self.model
         queued = [None]
@@ -186,8 +168,6 @@ class SupervisedStep:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
-        if static:
-            _rejoin(pos.device, *_segmentor_side_streams(self.model))
         return loss.detach(), queued[0]
 
 
@@ -235,13 +215,37 @@ class FixMatchNTMStep:
             self._geometry_src = src + (tuple(t._version for t in src),)
         return losses
 
-    def iteration(self, data, data_u, geoms=(None, None), next_batches=None, static=False):
-        """One iteration -> (dict of detached losses, (student, teacher) geometries queued for next_batches).  static
-        (graph_step.py): ema_t is updated IN its buffer and every side stream is joined before returning."""
-        cfg = self.cfg
+    def _pseudo_labels(self, data_u, geom_t):
+        """train.py:462-475: the frozen teacher on the weak view -> (softmax, its maximum, its arg-max)."""
+        with torch.no_grad():
+            _mode(self.model_t, False)
+            pred_u = F.softmax(self.model_t(data_u, if_teacher=True, geometry=geom_t)[0], dim=1)
+            logits_u_aug, label_u_aug = torch.max(pred_u, dim=1)
+        return pred_u, logits_u_aug, label_u_aug
+
+    def lookahead_work(self, data, data_u):
+        """Everything of an iteration that depends on its batches and on FROZEN state alone, on the CURRENT stream: the
+        student's and the teacher's geometry, the teacher's forward -> pseudo labels (the teacher is never updated:
+        train.py:218-222 loads and freezes it; it is in eval mode and draws no random numbers), the kNN graph and Morton
+        order of the 3-D loss.  -> the `pre` dict student_iteration() takes.  graph_step.py replays this as a graph of its own
+        on a second stream beside the PREVIOUS iteration's training graph; the eager iteration() below spreads the same work
+        over side streams inside the iteration instead."""
+        _mode(self.model, True)
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        with torch.no_grad():
+            geom_s = inner.prefetch_geometry(data, data_u, fixmatch=True, inline=True)
+            _mode(self.model_t, False)
+            geom_t = self.model_t.prefetch_geometry(data_u, if_teacher=True, inline=True)
+            raw = data_u["raw_pos"].contiguous()
+            nbr = self.threed_loss.neighbours(raw)
+            order = ntm_mod.spatial_order(raw)
+        pred_u, logits_u_aug, label_u_aug = self._pseudo_labels(data_u, geom_t)
+        return {"geom_s": geom_s, "pseudo": (pred_u, logits_u_aug, label_u_aug), "knn": (nbr, order)}
+
+    def iteration(self, data, data_u, geoms=(None, None), next_batches=None):
+        """One iteration, eagerly, its batch-only work spread over side streams -> (dict of detached losses, (student,
+        teacher) geometries queued for next_batches)."""
         geom_s, geom_t = geoms
-        bl, bu = data["pos"].shape[0], data_u["pos_w"].shape[0]
-        n = data["pos"].shape[1]
         # the kNN graph of the 3-D loss needs raw_pos only: build it beside the teacher / student forwards
         dev = data["pos"].device
         nbr = order = None
@@ -265,14 +269,8 @@ class FixMatchNTMStep:
                 self._teacher_stream = torch.cuda.Stream(device=dev)
             t_stream = self._teacher_stream
             t_stream.wait_stream(torch.cuda.current_stream(dev))
-        with torch.no_grad(), (torch.cuda.stream(t_stream) if t_stream is not None else contextlib.nullcontext()):
-            _mode(self.model_t, False)
-            pred_u = F.softmax(self.model_t(data_u, if_teacher=True, geometry=geom_t)[0], dim=1)
-            logits_u_aug, label_u_aug = torch.max(pred_u, dim=1)
-        # 2. student on labelled + strong + weak (train.py:478-492)
-        _mode(self.model, True)
-        _mode(self.T_predictor, True)
-        data_u = dict(data_u, T=self.ema_t)
+        with (torch.cuda.stream(t_stream) if t_stream is not None else contextlib.nullcontext()):
+            pseudo = self._pseudo_labels(data_u, geom_t)
         inner = self.model.module if hasattr(self.model, "module") else self.model
         queued = [(None, None)]
         queue = None
@@ -285,17 +283,46 @@ class FixMatchNTMStep:
         at_blocks = _lookahead_at_blocks(inner.segmentor, "forward")
         if queue is not None and at_blocks:
             inner.segmentor.at_blocks_backward = queue      # runs when the student's backward reaches the transformer blocks
+
+        def after_forward():
+            # the teacher joins BEFORE the look-ahead is queued: the look-ahead's side streams (the student's and the
+            # teacher's segmentor streams) start behind the current stream only, and a teacher forward without a prefetched
+            # geometry allocates its in-line index plan on the teacher segmentor's side stream and frees it when the no_grad
+            # forward returns -- behind this join those blocks cannot be handed to the look-ahead's kernels while the
+            # teacher's decoder still reads them (the teacher is long done by the end of the student's forward: free)
+            if t_stream is not None:
+                _join(dev, t_stream, *pseudo)
+            if queue is not None and not at_blocks:
+                queue()
+
+        def knn_graph():
+            if nbr is not None:
+                _join(dev, self._side, nbr, order)
+            return nbr, order
+        losses = self.student_iteration(data, data_u, geom_s, pseudo, knn_graph, after_forward)
+        if at_blocks:
+            inner.segmentor.at_blocks_backward = None
+        return losses, queued[0]
+
+    def student_iteration(self, data, data_u, geom_s, pseudo, knn_graph, after_forward=None, ema_in_place=False):
+        """Steps 2-5 of the iteration (train.py:478-602, 646-660): the student on labelled + strong + weak views, the class
+        transition, the per-point matrices, the corrected logits, the losses, backward, both optimisers.
+        pseudo = (pred_u, logits_u_aug, label_u_aug) of the teacher; knn_graph = (nbr, order) of raw_pos or a callable that
+        returns them (called where they are first needed); after_forward(): called behind the student's forward (the eager
+        iteration joins its teacher stream and queues its look-ahead there); ema_in_place: update ema_t IN its buffer
+        (a captured graph holds the buffer, not the attribute)."""
+        cfg = self.cfg
+        bl, bu = data["pos"].shape[0], data_u["pos_w"].shape[0]
+        n = data["pos"].shape[1]
+        # 2. student on labelled + strong + weak (train.py:478-492)
+        _mode(self.model, True)
+        _mode(self.T_predictor, True)
+        data_u = dict(data_u, T=self.ema_t)
         pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
         pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
-        # the teacher joins BEFORE the look-ahead is queued: the look-ahead's side streams (the student's and the teacher's
-        # segmentor streams) start behind the current stream only, and a teacher forward without a prefetched geometry
-        # allocates its in-line index plan on the teacher segmentor's side stream and frees it when the no_grad forward
-        # returns -- behind this join those blocks cannot be handed to the look-ahead's kernels while the teacher's
-        # decoder still reads them (the teacher is long done by the end of the student's forward: the join costs nothing)
-        if t_stream is not None:
-            _join(dev, t_stream, pred_u, logits_u_aug, label_u_aug)
-        if queue is not None and not at_blocks:
-            queue()
+        if after_forward is not None:
+            after_forward()
+        pred_u, logits_u_aug, label_u_aug = pseudo
         # 3. class-level transition matrix, prior, EMA (train.py:502-545, 556-557)
         ema_t_corr, ema_next, _, _ = ntm_mod.class_transition(
             pred_u, sigma, self.ema_t, cfg["geo_lambma"], cfg["ema_t_decay"], group=self.group,
@@ -303,11 +330,10 @@ class FixMatchNTMStep:
         # 4. per-point matrices + corrected strong logits (train.py:547-552)
         ins_t = self.T_predictor(F.softmax(pred_u_strong, dim=1).detach(), self.cm)
         pred_u_strong_corr = ntm_mod.correct_logits(pred_u_strong, ins_t, ema_t_corr, cfg["lambma"])
-        if not static:
+        if not ema_in_place:
             self.ema_t = ema_next.detach()
         # 5. losses (train.py:570-602)
-        if nbr is not None:
-            _join(dev, self._side, nbr, order)
+        nbr, order = knn_graph() if callable(knn_graph) else knn_graph
         loss_3d = self.threed_loss(data_u["raw_pos"], label_u_aug, ins_t, nbr=nbr, order=order) * cfg["threed_loss_weight"]
         sup_loss = self.criterion(pred_l, data["y"])
         unsup_loss = self.criterion_u(pred_u_strong_corr, label_u_aug.detach(), logits_u_aug.detach(),
@@ -316,21 +342,16 @@ class FixMatchNTMStep:
         unsup_loss = unsup_loss * (cfg["unsupervised_loss_weight"] * (bu * n) / thresh_mask.sum())
         loss = sup_loss + unsup_loss + loss_3d
         loss.backward()
-        if at_blocks:
-            inner.segmentor.at_blocks_backward = None
-        if static:
+        if ema_in_place:
             with torch.no_grad():
-                self.ema_t.copy_(ema_next)       # the EMA in its fixed buffer, behind everything that read the old one
+                self.ema_t.copy_(ema_next)       # behind everything that read the old one
         if cfg["grad_norm_clip"] is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["grad_norm_clip"])
         self.optimizer.step()
         self.optimizer.zero_grad(set_to_none=True)
         self.T_optimizer.step()
         self.T_optimizer.zero_grad(set_to_none=True)
-        if static:
-            _rejoin(dev, self._side, self._teacher_stream, *(_segmentor_side_streams(self.model) + _segmentor_side_streams(self.model_t)))
-        losses = {"loss": loss.detach(), "sup": sup_loss.detach(), "unsup": unsup_loss.detach(), "threed": loss_3d.detach()}
-        return losses, queued[0]
+        return {"loss": loss.detach(), "sup": sup_loss.detach(), "unsup": unsup_loss.detach(), "threed": loss_3d.detach()}
 
 
 def _same_positions_impl(src, data, data_u):

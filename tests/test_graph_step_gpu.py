@@ -123,3 +123,43 @@ def test_a_batch_of_another_shape_is_refused():
     b = _sup_batches(1, 6000)[0]
     with pytest.raises(RuntimeError, match="captured for"):
         call(*b)
+
+
+def test_replays_survive_eager_launches_between_them():
+    """The ROCm 7.0 hazard geot_amd/__init__.py switches off (graph packet capture: the captured packets of a graph's
+    hipMemsetAsync nodes point into the device's shared kernel-argument ring): a captured torch reduction that zeroes its
+    semaphores by memset returned garbage after ~20 000 eager launches between two replays (tools/lab/packet_capture_repro.py;
+    in the training step: four bias / weight gradients at 1e36 after 13 eager iterations between two replays).  With the
+    switch off -- what conftest.py and `import geot_amd` arrange -- the second replay equals the first."""
+    import geot_amd
+    assert geot_amd.graph_replay_is_safe()
+    x = torch.randn(8, 5, 24000, device=DEV)
+    out = torch.zeros(5, dtype=torch.float64, device=DEV)
+    lin = torch.nn.Linear(128, 384).to(DEV)
+    xin = torch.randn(4096, 128, device=DEV)
+    gb = torch.zeros(384, device=DEV)
+
+    def body():
+        for _ in range(10):
+            out.copy_(x.sum((0, 2), dtype=torch.float64))
+            gb.copy_(torch.autograd.grad(lin(xin).square().sum(), lin.bias)[0])
+    s = torch.cuda.Stream(device=DEV)
+    s.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.current_stream(DEV).wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        body()
+    g.replay()
+    torch.cuda.synchronize()
+    want, want_gb = out.clone(), gb.clone()
+    a = torch.randn(1 << 16, device=DEV)
+    for _ in range(60000):
+        a.mul_(1.0)
+    out.zero_()
+    gb.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want) and torch.equal(gb, want_gb)
