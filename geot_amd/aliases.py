@@ -17,17 +17,33 @@ reference packages.
 import sys
 import types
 
+installed_binding = None
 
-def install(force=False, binding="ctypes"):
-    """binding: how `pointnet2._ext` reaches the C ABI -- "ctypes" (geot_amd/ext/pointnet2_ext.py, no compiler needed)
-    or "cpp" (the host-only PyTorch cpp_extension geot_amd/csrc_torch/pointnet2_ext_bindings.cpp, built in-tree by
-    geot_amd.build_torch_ext: pybind11 functions taking at::Tensor, as the reference's bindings.cpp:9-22)."""
+
+def extension_modules(binding="auto"):
+    """(pointnet2._ext, pointops_cuda, pointnet2_batch_cuda, binding used) for `binding`:
+    "cpp"    the host-only PyTorch cpp_extension modules of geot_amd/csrc_torch/ (pybind11 functions taking at::Tensor, as
+             the reference's bindings.cpp:9-22 / pointops_api.cpp / pointnet2_api.cpp), built in-tree by build_torch_ext;
+    "ctypes" geot_amd/ext/*.py (no compiler needed; the only binding under GEOT_DISTANCE=fma / fma_xy);
+    "auto"   (default) cpp when the modules build and load, ctypes otherwise."""
     from .ext import pointnet2_ext, pointops_cuda, pointnet2_batch_cuda
-    if binding == "cpp":
-        from . import build_torch_ext
-        pointnet2_ext = build_torch_ext.load()
-    elif binding != "ctypes":
-        raise ValueError("binding must be 'ctypes' or 'cpp'")
+    if binding not in ("auto", "cpp", "ctypes"):
+        raise ValueError("binding must be 'auto', 'cpp' or 'ctypes'")
+    if binding != "ctypes":
+        try:
+            from . import build_torch_ext
+            mods = tuple(build_torch_ext.load(n) for n in ("_pointnet2_ext_cpp", "_pointops_cuda_cpp", "_pointnet2_batch_cpp"))
+            return mods + ("cpp",)
+        except Exception:      # noqa: BLE001 -- no g++ / torch headers / matching library
+            if binding == "cpp":
+                raise
+    return pointnet2_ext, pointops_cuda, pointnet2_batch_cuda, "ctypes"
+
+
+def install(force=False, binding="auto"):
+    """Register the modules; binding: see extension_modules().  The binding that was used is kept in `installed_binding`."""
+    global installed_binding
+    pointnet2_ext, pointops_cuda, pointnet2_batch_cuda, installed_binding = extension_modules(binding)
     from . import knn_cuda
     from .pointnet2 import pointnet2_utils
 

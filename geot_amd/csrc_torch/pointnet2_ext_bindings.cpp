@@ -5,44 +5,9 @@
 // include/geot_hip.h on torch's current stream.  No device code here (nothing for hipify to touch): g++ against the
 // torch headers, linked with libgeot_hip.so.  The ctypes module geot_amd/ext/pointnet2_ext.py makes the same nine
 // calls; tests/test_cpp_binding_gpu.py holds the two to identical outputs and times both.
-#include <torch/extension.h>
-#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
-#include <c10/core/DeviceGuard.h>
-#include <vector>
+#include "binding_common.h"
 
-#include "geot_hip.h"
-
-namespace {
-
-void *stream_of(const at::Tensor &t)
-{
-    return (void *)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
-}
-
-void check_f32(const at::Tensor &t, const char *name, int64_t ndim)
-{
-    TORCH_CHECK(t.is_cuda(), name, ": CPU not supported (tensor must live on the GPU)");
-    TORCH_CHECK(t.scalar_type() == at::ScalarType::Float, name, " must be a float tensor");
-    TORCH_CHECK(t.is_contiguous(), name, " must be a contiguous tensor");
-    TORCH_CHECK(t.dim() == ndim, name, " must have ", ndim, " dimensions, got ", t.dim());
-}
-
-void check_i32(const at::Tensor &t, const char *name, int64_t ndim)
-{
-    TORCH_CHECK(t.is_cuda(), name, ": CPU not supported (tensor must live on the GPU)");
-    TORCH_CHECK(t.scalar_type() == at::ScalarType::Int, name, " must be an int tensor");
-    TORCH_CHECK(t.is_contiguous(), name, " must be a contiguous tensor");
-    TORCH_CHECK(t.dim() == ndim, name, " must have ", ndim, " dimensions, got ", t.dim());
-}
-
-void ok(int err, const char *what)
-{
-    TORCH_CHECK(err == 0, what, ": ", geot_error_string(err));
-}
-
-at::TensorOptions like(const at::Tensor &t, at::ScalarType dtype) { return at::device(t.device()).dtype(dtype); }
-
-} // namespace
+using namespace geot_binding;
 
 at::Tensor gather_points(at::Tensor points, at::Tensor idx)
 {

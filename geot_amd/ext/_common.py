@@ -64,6 +64,31 @@ def stream_of(dev):
 
 trace = None     # bench.py's attribution pass sets this to a callable(launch, name) that brackets the launch
 
+# How a launch reaches the C ABI: through the compiled dispatcher (csrc_torch/gen_dispatch.py -> _geot_dispatch_cpp.so:
+# one pybind11 forwarder per entry point; the current stream and the device guard are taken in C++) when it can be built
+# and loaded, through ctypes otherwise (no compiler, another GEOT_DISTANCE than the one the module is linked against).
+# GEOT_BINDING=ctypes forces the fallback, =cpp makes a missing dispatcher an error.  Same library, same arguments.
+BINDING = os.environ.get("GEOT_BINDING", "auto")
+_dispatch = None          # the module, False when unavailable, None before the first launch
+
+
+def dispatcher():
+    """The compiled dispatcher module, or None when launches go through ctypes."""
+    global _dispatch
+    if _dispatch is None:
+        _dispatch = False
+        if BINDING not in ("auto", "cpp", "ctypes"):
+            raise RuntimeError("GEOT_BINDING must be auto, cpp or ctypes, got %r" % BINDING)
+        if BINDING != "ctypes":
+            try:
+                from .. import build_torch_ext
+                _dispatch = build_torch_ext.load("_geot_dispatch_cpp")
+            except Exception as e:      # noqa: BLE001 -- no compiler / headers / matching library: ctypes serves
+                if BINDING == "cpp":
+                    raise RuntimeError("GEOT_BINDING=cpp: the compiled dispatcher is unavailable: %s" % e)
+                _dispatch = False
+    return _dispatch or None
+
 
 def call(name, dev, *args):
     """Launch C-ABI entry `name` on torch's current stream of `dev` (under a device guard when `dev` is not
@@ -74,6 +99,14 @@ def call(name, dev, *args):
 
 
 def _launch(name, dev, *args):
+    disp = _dispatch if _dispatch is not None else dispatcher()
+    if disp:
+        fn = getattr(disp, name, None)
+        if fn is not None:
+            err = fn(dev.index if dev.index is not None else torch.cuda.current_device(), *args)
+            if err:
+                _lib.check(err, name)
+            return
     lib = _lib.load()
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx == torch.cuda.current_device():
