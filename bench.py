@@ -254,6 +254,51 @@ def cpu_baseline_model():
                      "sample": "same step, index-producing ops from the C/OpenMP oracle (exact CUDA semantics), %.1f s" % t_port}}
 
 
+def cpu_baseline_fixmatch(bl, bu):
+    """configs[4] on the host, bounded sample, composed from two measured pieces: (a) the supervised step of the same
+    model on 2 clouds (cpu_baseline_model: forward + loss + backward + AdamW) -- the student's 6-cloud forward + backward
+    and the teacher's 2-cloud forward are priced from it by cloud count (a forward alone at 1/3 of a step); (b) the NTM block
+    of ONE iteration (sig_t_mean, class transition, logit correction, threeD_space_loss with its k = 32 graph) on the bu
+    unlabelled clouds, timed on oracle/np_ntm.py -- the fp64 numpy restatement of transformer.py:1099-1131,
+    train.py:505-557 and utils/insT_loss.py:61-110 (the reference's own code for this block hard-codes .cuda()) -- with the
+    neighbour search from the C/OpenMP oracle.  Checker code, used here only as the reported baseline."""
+    import numpy as np
+    from oracle import capi, np_ntm
+    from geot_amd.synth import make_batch, make_logits
+    base = cpu_baseline_model()
+    cores = base["cores"]
+    capi.set_threads(cores)
+    xyz = make_batch(1, N_POINTS, start_index=10_000)[0]       # ONE unlabelled cloud (clouds are independent here): x bu below
+    pw, ps = make_logits(xyz, index=0), make_logits(xyz, index=1, sharp=3.0)
+
+    def softmax(z):
+        e = np.exp(z - z.max(1, keepdims=True))
+        return e / e.sum(1, keepdims=True)
+    C = pw.shape[1]
+    rng = np.random.default_rng(1609)
+    W = rng.standard_normal((C, C, 2 * C)) * 0.1
+    cm, ema, sigma = np.full((C, C), 1.0 / C), np.eye(C), np.full(C, 0.4)
+    t0 = time.perf_counter()
+    eta, p = softmax(pw), softmax(ps)
+    tr = np_ntm.class_transition(eta, sigma, ema)
+    ins = np_ntm.sig_t_mean(p, cm, W)
+    np_ntm.correct_logits(ps, ins, tr["ema_t_corr"], 0.9)
+    nbr = capi.knn_sorted(xyz, xyz, 33)[0][:, :, 1:]
+    np_ntm.threed_space_loss(xyz, eta.argmax(1), ins, nbr, 1.0)
+    t_ntm = (time.perf_counter() - t0) * bu
+    t_step2 = 2.0 / base["value"]                        # seconds of one supervised step on 2 clouds
+    t_iter = t_step2 * (bl + 2 * bu) / 2.0 + (t_step2 / 3.0) * bu / 2.0 + t_ntm
+    return {"value": (bl + bu) / t_iter, "unit": "clouds/s", "cores": cores, "kind": "reference-fallback + port, composed",
+            "torch": base.get("torch"),
+            "sample": "one FixMatch+NTM iteration priced from two measured pieces: the supervised step on 2 clouds (%.1f s: %s) "
+                      "scaled to the student's %d clouds fwd+bwd and the teacher's %d clouds fwd (1/3 of a step per cloud), "
+                      "plus the NTM block (sig_t_mean + class transition + correction + threeD_space_loss k=32 with its "
+                      "gradient) in fp64 numpy with the C/OpenMP kNN, timed on 1 cloud x %d points and scaled to the %d "
+                      "unlabelled clouds (%.1f s)"
+                      % (t_step2, base["kind"], bl + 2 * bu, bu, N_POINTS, bu, t_ntm),
+            "ntm_block_s": t_ntm, "supervised_step_2_clouds_s": t_step2, "supervised": base}
+
+
 # ---------------------------------------------------------------------------------------------------------------
 def hot_path_attribution(step, steps=2):
     """Run `steps` extra (untimed) steps with HIP events around every C-ABI launch: per-entry-point GPU time.
@@ -775,12 +820,7 @@ def main():
         elif workload == "model":
             result["cpu_baseline"] = cpu_baseline_model()
         elif workload == "fixmatch":
-            # the NTM kernels have no CPU path (the reference's own code hard-codes .cuda()); the iteration is dominated by
-            # the student's forward + backward, so the host figure is the supervised step of the same model, said so here
-            base = cpu_baseline_model()
-            base["sample"] = ("PROXY for the FixMatch iteration -- the supervised step of the same model (the NTM block has no "
-                              "CPU implementation to time): ") + base["sample"]
-            result["cpu_baseline"] = base
+            result["cpu_baseline"] = cpu_baseline_fixmatch(bl, bu)
     if rank == 0:
         print(json.dumps(_finite(result), allow_nan=False), flush=True)
     if world > 1:

@@ -62,8 +62,8 @@ PROTOTYPES.update({
     "geot_graph_feature": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_graph_feature_grad": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_class_anchors": [_c_int, _c_int, _c_int, _P, _P, _P, _c_void_p],
-    "geot_ntm_class_transition": [_c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
-    "geot_ntm_class_transition_grad": [_c_int, _c_float, _c_float, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_class_transition": [_c_int, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
+    "geot_ntm_class_transition_grad": [_c_int, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean_grad_w": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_ntm_sig_t_mean_grad_raw": [_c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
@@ -158,7 +158,7 @@ PLAIN = {
     "geot_rowdot_small_slices": ([_c_int] * 2, _c_int),
     "geot_colsum_ws_floats": ([_c_int] * 2, ctypes.c_longlong),
 }
-ABI_VERSION = 5     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
+ABI_VERSION = 6     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
 
 _lib = None
 

@@ -1071,15 +1071,73 @@ __device__ __forceinline__ float ct_rowsum(float v, int r, int k, int C, float *
     return s;
 }
 
-template <bool BACKWARD>
+__device__ __forceinline__ double ct_rowsum(double v, int r, int k, int C, double *buf)
+{
+    __syncthreads();
+    buf[r * CT_MAXC + k] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int j = 0; j < C; ++j) s += buf[k * CT_MAXC + j];
+    return s;
+}
+
+// d(sum g_corr * ema_corr + sum g_prior * prior) / d sigma, in fp64: the derivative fields are differences of quotients
+// (dA / RA - A dRA / RA^2, three normalisations deep) whose fp32 evaluation lost 2.6e-5 of the result against the reference's
+// fp64 run -- 100 x the error of the reference's own fp32 autograd (tests/test_ref_fixtures_gpu.py, round 4).  32 x 32
+// threads on 17 x 17 numbers: the precision is free.  The forward kernel below stays fp32, op for op what train.py:505-545
+// computes.
+__global__ __launch_bounds__(CT_MAXC * CT_MAXC) void class_transition_grad_kernel(
+    int C, double geo, double dec, const float *__restrict__ class_T, const float *__restrict__ sigma,
+    const float *__restrict__ ema_t, const float *__restrict__ proj, const float *__restrict__ g_corr,
+    const float *__restrict__ g_prior, float *__restrict__ g_sigma)
+{
+    __shared__ double buf[CT_MAXC * CT_MAXC];
+    __shared__ double red[CT_MAXC * CT_MAXC / 64];
+    const int tid = threadIdx.x, r = tid / CT_MAXC, k = tid % CT_MAXC;
+    const bool in = r < C && k < C;
+    const double cT = in ? class_T[r * C + k] : 0.0, eT = in ? ema_t[r * C + k] : 0.0;
+    const double sg = in ? sigma[r] : 1.0, delta = in ? (double)proj[k] - (double)proj[r] : 0.0;
+    const double P0 = in ? (1.0 / (sg * 2.5066282746310002)) * exp(-(delta * delta) / (2.0 * sg * sg)) : 0.0;
+    const double A = !in ? 0.0 : (r == 0 ? (k == 0 ? 1.0 : 0.0) : (k == 0 ? 0.0 : P0));
+    const double RA = ct_rowsum(A, r, k, C, buf);
+    const double Bv = in ? A / RA : 0.0;
+    const double N = !in ? 0.0 : (r == 0 ? cT : geo * cT + (1.0 - geo) * Bv);
+    const double SN = ct_rowsum(N, r, k, C, buf);
+    const double M = in ? N / SN : 0.0;
+    const double E = in ? dec * eT + (1.0 - dec) * M : 0.0;
+    const double UE = ct_rowsum(E, r, k, C, buf);
+    const double gc = (in && g_corr) ? g_corr[r * C + k] : 0.0, gp = (in && g_prior) ? g_prior[r * C + k] : 0.0;
+    const int c0 = blockIdx.x;   // one workgroup per sigma component (the forward fields are recomputed: cheap)
+    const double dP0 = (in && r == c0) ? P0 * (-1.0 / sg + delta * delta / (sg * sg * sg)) : 0.0;
+    const double dA = (r >= 1 && k >= 1) ? dP0 : 0.0;
+    const double dRA = ct_rowsum(dA, r, k, C, buf);
+    const double dB = in ? dA / RA - A * dRA / (RA * RA) : 0.0;
+    const double dN = (in && r >= 1) ? (1.0 - geo) * dB : 0.0;
+    const double dSN = ct_rowsum(dN, r, k, C, buf);
+    const double dM = in ? dN / SN - N * dSN / (SN * SN) : 0.0;
+    const double dE = (1.0 - dec) * dM;
+    const double dUE = ct_rowsum(dE, r, k, C, buf);
+    const double dF = in ? dE / UE - E * dUE / (UE * UE) : 0.0;
+    double contrib = gc * dF + gp * dB;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = contrib;
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        for (int w = 0; w < CT_MAXC * CT_MAXC / 64; ++w) t += red[w];
+        g_sigma[c0] = (float)t;   // sole writer: the caller's buffer needs no zero-fill
+    }
+}
+
 __global__ __launch_bounds__(CT_MAXC * CT_MAXC) void class_transition_kernel(
-    int C, float geo, float dec, const float *__restrict__ class_T, const float *__restrict__ sigma,
+    int C, float geo, float geo1, float dec, float dec1,       // geo1 = fl32(1 - geo_lambda) formed in double, as Python forms it
+    const float *__restrict__ class_T, const float *__restrict__ sigma,
     const float *__restrict__ ema_t, const float *__restrict__ proj, float *__restrict__ ema_corr,
-    float *__restrict__ ema_next, float *__restrict__ prior, float *__restrict__ ema_keep,
-    const float *__restrict__ g_corr, const float *__restrict__ g_prior, float *__restrict__ g_sigma)
+    float *__restrict__ ema_next, float *__restrict__ prior, float *__restrict__ ema_keep)
 {
     __shared__ float buf[CT_MAXC * CT_MAXC];
-    __shared__ float red[CT_MAXC * CT_MAXC / 64];
     const int tid = threadIdx.x, r = tid / CT_MAXC, k = tid % CT_MAXC;
     const bool in = r < C && k < C;
     const float cT = in ? class_T[r * C + k] : 0.f, eT = in ? ema_t[r * C + k] : 0.f;
@@ -1088,47 +1146,18 @@ __global__ __launch_bounds__(CT_MAXC * CT_MAXC) void class_transition_kernel(
     const float A = !in ? 0.f : (r == 0 ? (k == 0 ? 1.f : 0.f) : (k == 0 ? 0.f : P0));
     const float RA = ct_rowsum(A, r, k, C, buf);
     const float Bv = in ? A / RA : 0.f;
-    const float N = !in ? 0.f : (r == 0 ? cT : geo * cT + (1.f - geo) * Bv);
+    const float N = !in ? 0.f : (r == 0 ? cT : geo * cT + geo1 * Bv);
     const float SN = ct_rowsum(N, r, k, C, buf);
     const float M = in ? N / SN : 0.f;
-    const float E = in ? dec * eT + (1.f - dec) * M : 0.f;
+    const float E = in ? dec * eT + dec1 * M : 0.f;
     const float UE = ct_rowsum(E, r, k, C, buf);
-    if (!BACKWARD) {
-        const float X = in ? dec * eT + (1.f - dec) * cT : 0.f;
-        const float UX = ct_rowsum(X, r, k, C, buf);
-        if (in) {
-            ema_corr[r * C + k] = E / UE;
-            ema_next[r * C + k] = X / UX;
-            prior[r * C + k] = Bv;
-            if (ema_keep) ema_keep[r * C + k] = eT;
-        }
-        return;
-    }
-    const float gc = (in && g_corr) ? g_corr[r * C + k] : 0.f, gp = (in && g_prior) ? g_prior[r * C + k] : 0.f;
-    {
-        const int c0 = blockIdx.x;   // one workgroup per sigma component (the forward fields are recomputed: cheap)
-        // derivative fields w.r.t. sigma[c0]
-        const float dP0 = (in && r == c0) ? P0 * (-1.f / sg + delta * delta / (sg * sg * sg)) : 0.f;
-        const float dA = (r >= 1 && k >= 1) ? dP0 : 0.f;
-        const float dRA = ct_rowsum(dA, r, k, C, buf);
-        const float dB = in ? dA / RA - A * dRA / (RA * RA) : 0.f;
-        const float dN = (in && r >= 1) ? (1.f - geo) * dB : 0.f;
-        const float dSN = ct_rowsum(dN, r, k, C, buf);
-        const float dM = in ? dN / SN - N * dSN / (SN * SN) : 0.f;
-        const float dE = (1.f - dec) * dM;
-        const float dUE = ct_rowsum(dE, r, k, C, buf);
-        const float dF = in ? dE / UE - E * dUE / (UE * UE) : 0.f;
-        float contrib = gc * dF + gp * dB;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) contrib += __shfl_xor(contrib, o);
-        __syncthreads();
-        if ((tid & 63) == 0) red[tid >> 6] = contrib;
-        __syncthreads();
-        if (tid == 0) {
-            float t = 0.f;
-            for (int w = 0; w < CT_MAXC * CT_MAXC / 64; ++w) t += red[w];
-            g_sigma[c0] = t;   // sole writer: the caller's buffer needs no zero-fill
-        }
+    const float X = in ? dec * eT + dec1 * cT : 0.f;
+    const float UX = ct_rowsum(X, r, k, C, buf);
+    if (in) {
+        ema_corr[r * C + k] = E / UE;
+        ema_next[r * C + k] = X / UX;
+        prior[r * C + k] = Bv;
+        if (ema_keep) ema_keep[r * C + k] = eT;
     }
 }
 
@@ -1300,26 +1329,25 @@ GEOT_EXPORT int geot_ntm_class_anchors(int b, int n, int c, const float *eta, fl
     return hipGetLastError();
 }
 
-GEOT_EXPORT int geot_ntm_class_transition(int c, float geo_lambda, float ema_decay, const float *class_T,
+GEOT_EXPORT int geot_ntm_class_transition(int c, double geo_lambda, double ema_decay, const float *class_T,
                                           const float *sigma, const float *ema_t, const float *proj, float *ema_t_corr,
                                           float *ema_t_next, float *prior_T, float *ema_t_keep, void *stream)
 {
     if (c < 1 || c > CT_MAXC) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((class_transition_kernel<false>), dim3(1), dim3(CT_MAXC * CT_MAXC), 0, (hipStream_t)stream, c,
-                       geo_lambda, ema_decay, class_T, sigma, ema_t, proj, ema_t_corr, ema_t_next, prior_T, ema_t_keep,
-                       nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL(class_transition_kernel, dim3(1), dim3(CT_MAXC * CT_MAXC), 0, (hipStream_t)stream, c,
+                       (float)geo_lambda, (float)(1.0 - geo_lambda), (float)ema_decay, (float)(1.0 - ema_decay), class_T, sigma,
+                       ema_t, proj, ema_t_corr, ema_t_next, prior_T, ema_t_keep);
     return hipGetLastError();
 }
 
-GEOT_EXPORT int geot_ntm_class_transition_grad(int c, float geo_lambda, float ema_decay, const float *class_T,
+GEOT_EXPORT int geot_ntm_class_transition_grad(int c, double geo_lambda, double ema_decay, const float *class_T,
                                                const float *sigma, const float *ema_t, const float *proj,
                                                const float *grad_ema_t_corr, const float *grad_prior_T,
                                                float *grad_sigma, void *stream)
 {
     if (c < 1 || c > CT_MAXC || !grad_sigma) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((class_transition_kernel<true>), dim3(c), dim3(CT_MAXC * CT_MAXC), 0, (hipStream_t)stream, c,
-                       geo_lambda, ema_decay, class_T, sigma, ema_t, proj, nullptr, nullptr, nullptr, nullptr,
-                       grad_ema_t_corr, grad_prior_T, grad_sigma);
+    hipLaunchKernelGGL(class_transition_grad_kernel, dim3(c), dim3(CT_MAXC * CT_MAXC), 0, (hipStream_t)stream, c,
+                       geo_lambda, ema_decay, class_T, sigma, ema_t, proj, grad_ema_t_corr, grad_prior_T, grad_sigma);
     return hipGetLastError();
 }
 

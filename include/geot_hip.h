@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEOT_ABI_VERSION 5
+#define GEOT_ABI_VERSION 6
 #define GEOT_NTM_MAX_C 32   /* largest class count of the geot_ntm_* entry points */
 
 /* ABI version / diagnostics. */
@@ -475,11 +475,14 @@ int geot_ntm_class_anchors(int b, int n, int c, const float *eta, float *class_T
  * Writes ema_t_corr, ema_t_next, prior_T (c,c) and, when ema_t_keep is not NULL, a copy of ema_t there (a caller
  * that keeps ema_t in one persistent buffer overwrites it with ema_t_next, train.py:556-557, before backward).
  * _grad writes d/d sigma (c) given d/d ema_t_corr and d/d prior_T (either may be NULL); sigma is the only
- * learnable input. */
-int geot_ntm_class_transition(int c, float geo_lambda, float ema_decay, const float *class_T, const float *sigma,
+ * learnable input.  geo_lambda / ema_decay are DOUBLES (ABI 6): the reference multiplies fp32 tensors by the Python
+ * floats cfg.geo_lambma and (1 - cfg.geo_lambma) (train.py:533-534, 540-545), i.e. by fl32(0.999) and fl32(1 - 0.999);
+ * from a float argument the complement could only be formed as 1.f - fl32(0.999), 4.7e-5 off -- which is the whole
+ * sigma gradient's relative error, since that gradient is proportional to (1 - geo)(1 - decay). */
+int geot_ntm_class_transition(int c, double geo_lambda, double ema_decay, const float *class_T, const float *sigma,
                               const float *ema_t, const float *proj, float *ema_t_corr, float *ema_t_next,
                               float *prior_T, float *ema_t_keep, void *stream);
-int geot_ntm_class_transition_grad(int c, float geo_lambda, float ema_decay, const float *class_T,
+int geot_ntm_class_transition_grad(int c, double geo_lambda, double ema_decay, const float *class_T,
                                    const float *sigma, const float *ema_t, const float *proj,
                                    const float *grad_ema_t_corr, const float *grad_prior_T, float *grad_sigma,
                                    void *stream);

@@ -296,15 +296,13 @@ def gen_losses(ns):
                     loss.backward()
                     key = "%s_%s_" % (case, name)
                     out[key + "loss_" + dn] = npf(loss)
-                    if dn == "f32" or case == "k7":           # fp64 gradients for the small case only (size)
-                        out[key + "grad_" + dn] = npf(Tt.grad)
+                    out[key + "grad_" + dn] = npf(Tt.grad)   # (fp64 too: the referee of the fp32 gradients' tolerance)
                     out[key + "nbr_" + dn] = npf(calls[0][:, :, 1:]).astype(np.int32)   # what the reference kept
                 Tt = torch.from_numpy(T).to(dt).requires_grad_(True)
                 loss = ns["Idenyity_loss"]()(Tt, torch.from_numpy(ident).to(dt))
                 loss.backward()
                 out[case + "_ident_loss_" + dn] = npf(loss)
-                if dn == "f32" or case == "k7":
-                    out[case + "_ident_grad_" + dn] = npf(Tt.grad)
+                out[case + "_ident_grad_" + dn] = npf(Tt.grad)
     np.savez_compressed(os.path.join(HERE, "ntm_ref_losses.npz"), meta=meta("sigma 1.0; *_nbr_* = the reference's own "
                         "knn_point(k+1)[..., 1:] (torch.cdist + topk) in that precision"), **out)
 
@@ -427,11 +425,10 @@ def gen_dgcnn(ns):
             (y * torch.from_numpy(Gout).to(dt)).sum().backward()
             feat = mod.get_graph_feature(ins[2], ins[3], ins[0], ins[1])
         out["y_" + dn] = npf(y)
-        if dn == "f64":                                    # the fp64 run referees the output only (size)
-            continue
-        out["g_f_" + dn] = npf(ins[1].grad)
+        out["g_f_" + dn] = npf(ins[1].grad)                 # (fp64 too: the referee of the fp32 gradients' tolerance)
         out["g_fq_" + dn] = npf(ins[3].grad)
-        out["graph_feature_slice_" + dn] = npf(feat[:, ::37, ::7, :])          # (B, 2C, N, k) subsampled
+        if dn == "f32":
+            out["graph_feature_slice_" + dn] = npf(feat[:, ::37, ::7, :])      # (B, 2C, N, k) subsampled
         for n in ("layer1.0.weight", "layer1.1.weight", "layer2.1.bias"):
             g = npf(dict(mod.named_parameters())[n].grad)
             out["gw_%s_%s" % (n.replace(".", "__"), dn)] = g.reshape(-1)[::41] if g.size > 4096 else g

@@ -99,7 +99,7 @@ def test_reference_wrapper_files_import_against_our_modules(built):
             "u = load('/root/reference/pointnet2/pointnet2_utils.py', 'ref_pointnet2_utils')\n"
             "p = load('/root/reference/pointops/functions/pointops.py', 'ref_pointops')\n"
             "s = load('/root/reference/openpoints/models/layers/subsample.py', 'ref_subsample')\n"
-            "assert u._ext.__name__.endswith('pointnet2_ext') and hasattr(p, 'knnquery') and hasattr(s, 'furthest_point_sample')\n"
+            "assert u._ext.__name__ in ('_pointnet2_ext_cpp', 'geot_amd.ext.pointnet2_ext') and hasattr(p, 'knnquery') and hasattr(s, 'furthest_point_sample')\n"
             "print('DROPIN_OK')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert "DROPIN_OK" in out.stdout, out.stderr[-2000:]

@@ -1,8 +1,15 @@
 """GPU suite: the HIP kernels of the NTM / loss / model half of the hot path against fixtures PRODUCED BY THE
 REFERENCE'S OWN CODE (tests/golden/make_ntm_golden.py: the class bodies / statement ranges of /root/reference
-executed in place on the CPU, fp32 and fp64).  Tolerance: north_star's 1e-5 relative, measured against the scale
-of the tensor (rows of a transition matrix sum to 1), for everything computed in one pass; the fp64 run referees:
-our fp32 result must not be farther from it than 1e-5 either."""
+executed in place on the CPU, fp32 and fp64).
+
+Tolerance = north_star's 1e-5 relative, read two ways and never looser:
+* `close`: every element within 1e-5 of the scale of ITS ROW (the last axis: a row of a transition matrix sums to 1,
+  a row of logits has the magnitude of its logits) -- not of the whole tensor -- against the reference's fp32 AND fp64
+  results, for everything computed in one pass;
+* `referee`: for long fp32 reductions (weight / sigma gradients: hundreds of cancelling terms), where the reference's
+  OWN fp32 result is farther than 1e-5 from its fp64 one, ours must be no farther from the fp64 result than the
+  reference's fp32 run is (x 2: two different summation orders), or within 1e-5 of the row scale -- whichever is larger.
+"""
 import os
 import sys
 
@@ -28,12 +35,38 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
+def _row_scale(want):
+    """|want| maximum over the last axis (the row an element sits in), floored at 1 % of the tensor's maximum: a row of
+    zeros (an unused class) is held to the rounding of its neighbours, not to 1e-5 of nothing."""
+    want = np.abs(np.asarray(want, dtype=np.float64))
+    shape = want.shape
+    while want.ndim and want.shape[-1] == 1:       # (a 1x1-conv weight is (out, in, 1): its rows run along `in`)
+        want = want[..., 0]
+    if want.ndim == 0:
+        return np.maximum(want, 1e-30).reshape((1,) * len(shape))
+    top = want.max() if want.size else 0.0
+    row = np.maximum(np.maximum(want.max(axis=-1, keepdims=True), 1e-2 * top), 1e-30)
+    return row.reshape(row.shape + (1,) * (len(shape) - row.ndim))
+
+
 def close(got, *wants, rel=REL, what=""):
-    """max |got - want| <= rel * max |want| for the reference's fp32 AND its fp64 result."""
+    """|got - want| <= rel * (scale of the element's row), element-wise, for the reference's fp32 AND its fp64 result."""
+    got = np.asarray(got, dtype=np.float64)
     for want in wants:
         want = np.asarray(want, dtype=np.float64)
-        err = np.abs(np.asarray(got, dtype=np.float64) - want).max()
-        assert err <= rel * max(np.abs(want).max(), 1e-30), (what, err, np.abs(want).max())
+        ratio = np.abs(got - want) / _row_scale(want)
+        assert ratio.max() <= rel, (what, float(ratio.max()), float(np.abs(want).max()))
+
+
+def referee(got, ref32, ref64, what="", factor=2.0, rel=REL):
+    """Ours is no farther from the reference's fp64 result than the reference's own fp32 result is (x factor), or within
+    rel of the row scale: the bound for long fp32 reductions whose fp32 reference is itself not 1e-5-accurate."""
+    got, ref32, ref64 = (np.asarray(a, dtype=np.float64) for a in (got, ref32, ref64))
+    scale = _row_scale(ref64)
+    ours, theirs = np.abs(got - ref64) / scale, np.abs(ref32 - ref64) / scale
+    bound = max(factor * float(theirs.max()), rel)
+    assert float(ours.max()) <= bound, (what, "ours %.3g" % ours.max(), "reference fp32 %.3g" % theirs.max(), "bound %.3g" % bound)
+    return float(ours.max()), float(theirs.max())
 
 
 def _predictor(W):
@@ -55,11 +88,7 @@ def test_sig_t_mean_kernel_equals_the_reference_class(golden, C):
     close(host(out), g[t + "ins_T_f32"], g[t + "ins_T_f64"], what="ins_T")
     (out * T(g[t + "G"])).sum().backward()
     gW = host(torch.stack([l.weight.grad for l in mod.fc]))
-    close(gW, g[t + "gW_f64"], rel=2e-5, what="grad W")       # 96-term fp32 sums behind a 1/row-norm: 2e-5 of the largest entry
-    # the reference's own fp32 gradient is no closer to its fp64 one than ours
-    ref_err = np.abs(g[t + "gW_f32"].astype(np.float64) - g[t + "gW_f64"]).max()
-    our_err = np.abs(gW.astype(np.float64) - g[t + "gW_f64"]).max()
-    assert our_err <= max(4 * ref_err, 1e-6 * np.abs(g[t + "gW_f64"]).max())
+    referee(gW, g[t + "gW_f32"], g[t + "gW_f64"], what="grad W")      # a (B*N)-term fp32 sum behind a 1 / row-norm
 
 
 @pytest.mark.parametrize("tag,filt", [("c17_plain_", False), ("c17_filt_", True), ("c5_plain_", False)])
@@ -83,9 +112,9 @@ def test_transition_block_kernels_equal_the_reference_statements(golden, tag, fi
     close(host(out), g[tag + "pred_u_strong_corr_f32"], g[tag + "pred_u_strong_corr_f64"], what="pred_corr")
     (out * T(g[tag + "G"])).sum().backward()
     close(host(strong.grad), g[tag + "g_strong_f32"], g[tag + "g_strong_f64"], what="d strong")
-    close(host(sigma.grad), g[tag + "g_sigma_f64"], rel=1e-4, what="d sigma")     # a 2 x 96 x 17-term reduction of cancelling terms
+    referee(host(sigma.grad), g[tag + "g_sigma_f32"], g[tag + "g_sigma_f64"], what="d sigma")   # 2 x 96 x 17 cancelling terms
     gW = host(torch.stack([l.weight.grad for l in pred.fc]))
-    close(gW, g[tag + "g_W_f64"], rel=1e-4, what="d W")
+    referee(gW, g[tag + "g_W_f32"], g[tag + "g_W_f64"], what="d W")
 
 
 @pytest.mark.parametrize("case,k", [("k32", 32), ("k7", 7), ("k7dup", 7)])
@@ -105,17 +134,20 @@ def test_graph_loss_kernels_equal_the_reference_classes(golden, case, k):
         finally:
             del os.environ["GEOT_NTM_GRAD"]
         close(loss.item(), g[case + "_threed_loss_f32"], what="threeD loss " + grad_mode)
-        close(host(Tt.grad), g[case + "_threed_grad_f32"], rel=1e-4 if grad_mode == "atomic" else REL, what="threeD grad " + grad_mode)
+        if grad_mode == "atomic":      # (the A/B scatter form: float atomics in arrival order)
+            referee(host(Tt.grad), g[case + "_threed_grad_f32"], g[case + "_threed_grad_f64"], what="threeD grad atomic")
+        else:
+            close(host(Tt.grad), g[case + "_threed_grad_f32"], g[case + "_threed_grad_f64"], what="threeD grad " + grad_mode)
     Tt = T(Tm).requires_grad_(True)
     floss = ntm.feature_space_loss(k=k, sigma=1.0)(T(probs), T(labels, torch.int64), Tt, nbr=T(g[case + "_feat_nbr_f32"], torch.int64))
     floss.backward()
     close(floss.item(), g[case + "_feat_loss_f32"], what="feature loss")
-    close(host(Tt.grad), g[case + "_feat_grad_f32"], rel=1e-4, what="feature grad")     # float atomics
+    referee(host(Tt.grad), g[case + "_feat_grad_f32"], g[case + "_feat_grad_f64"], what="feature grad")     # float atomics
     Tt = T(Tm).requires_grad_(True)
     iloss = ntm.Idenyity_loss()(Tt, torch.eye(17, device=DEV))
     iloss.backward()
     close(iloss.item(), g[case + "_ident_loss_f32"], g[case + "_ident_loss_f64"], what="identity loss")
-    close(host(Tt.grad), g[case + "_ident_grad_f32"], what="identity grad")
+    close(host(Tt.grad), g[case + "_ident_grad_f32"], g[case + "_ident_grad_f64"], what="identity grad")
     if case != "k7dup":
         Tt = T(Tm).requires_grad_(True)
         loss = ntm.threeD_space_loss(k=k, sigma=1.0)(T(xyz), T(labels, torch.int64), Tt)
@@ -178,16 +210,17 @@ def test_transformer_blocks_equal_the_reference_classes(golden, name, mode):
     for i, yy in enumerate(ys):
         close(host(yy), g["%s_y%d_f64" % (name, i)], what="%s y%d" % (name, i))
     for i, t in enumerate(ins):
-        close(host(t.grad), g["%s_gin%d_f64" % (name, i)], rel=2e-5, what="%s gin%d" % (name, i))
+        referee(host(t.grad), g["%s_gin%d_f32" % (name, i)], g["%s_gin%d_f64" % (name, i)], what="%s gin%d" % (name, i))
     params = dict(mod.named_parameters())
     pre = "%s_gw_" % name
     for key in g.files:
         if key.startswith(pre) and key.endswith("_f64"):
             pname = key[len(pre):-4].replace("__", ".")
             want = g[key]
-            err = np.abs(host(params[pname].grad).astype(np.float64) - want).max()
-            # (a bias in front of a BatchNorm has an analytically zero gradient: absolute floor at the scale of G)
-            assert err <= 2e-5 * max(np.abs(want).max(), 1.0), (name, pname, err)
+            if np.abs(want).max() < 1e-6:     # a bias in front of a BatchNorm: analytically zero, rounding noise at the scale of G
+                assert np.abs(host(params[pname].grad)).max() <= 2e-5, (name, pname)
+                continue
+            referee(host(params[pname].grad), g[key[:-4] + "_f32"], want, what="%s %s" % (name, pname))
     if name == "encoder_train":
         for n in ("first_conv.1.running_mean", "first_conv.1.running_var", "second_conv.1.running_mean",
                   "second_conv.1.running_var"):
@@ -208,13 +241,13 @@ def test_dgcnn_propagation_equals_the_reference_class(golden, dense):
     y = mod(T(g["coor"]), f, T(g["coor_q"]), f_q)
     close(host(y), g["y_f32"], g["y_f64"], what="DGCNN y")
     (y * T(g["G"])).sum().backward()
-    close(host(f.grad), g["g_f_f32"], rel=5e-5, what="d f")
-    close(host(f_q.grad), g["g_fq_f32"], rel=5e-5, what="d f_q")
+    referee(host(f.grad), g["g_f_f32"], g["g_f_f64"], what="d f")
+    referee(host(f_q.grad), g["g_fq_f32"], g["g_fq_f64"], what="d f_q")
     feat = mod.get_graph_feature(T(g["coor_q"]), f_q.detach(), T(g["coor"]), f.detach())
     assert np.array_equal(host(feat[:, ::37, ::7, :]), g["graph_feature_slice_f32"])          # differences of fp32: exact
     params = dict(mod.named_parameters())
     for n in ("layer1.0.weight", "layer1.1.weight", "layer2.1.bias"):
-        want = g["gw_%s_f32" % n.replace(".", "__")]
+        key = "gw_%s_" % n.replace(".", "__")
         got = host(params[n].grad)
         got = got.reshape(-1)[::41] if got.size > 4096 else got
-        close(got, want, rel=5e-5, what=n)
+        referee(got, g[key + "f32"], g[key + "f64"], what=n)
