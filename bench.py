@@ -665,6 +665,7 @@ def main():
         "config": {"workload": desc + graph_note, "clouds_per_gpu": clouds_per_step, "points": N_POINTS,
                    "parallelism": parallelism, "stand_in": workload in ("ops_only", "ntm")},
         "roofline": fps_roofline if (fps_rounds and not args.graph) else None,
+        "final_loss": float(out.float().mean()) if workload in ("model", "fixmatch") else None,   # of the last timed step (rank 0)
     }
     if workload == "model":
         # dominant kernel of the step by rocprofv3 time (profiles/r02_bench_model_*_window.csv): the 8192-sample FPS
@@ -748,6 +749,46 @@ def main():
                           "ms_per_step_without_gradient_allreduce": 1e3 * t_local / k2,
                           "exposed_allreduce_ms": ms_per_step - 1e3 * t_local / k2,
                           "note": "exposed = timed step minus the same step under DDP.no_sync() (%d steps); negative = noise" % k2}
+        # What a scaling line needs to be attributed: the host side of every rank (N ranks share one host: issue time is
+        # the first suspect when N x the one-GPU rate is not reached), the collectives a step really issues, and the step
+        # with the look-ahead off (its FPS / index kernels run beside RCCL's all-reduce kernels when it is on)
+        gdev = "cpu" if rehearsal else dev
+        issue = dist_utils.gather_over_ranks(HOST_ISSUE_MAIN["ms"], gdev)
+        cpu = dist_utils.gather_over_ranks(HOST_ISSUE_MAIN["cpu_ms"], gdev)
+        cores = dist_utils.gather_over_ranks(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0, gdev)
+        counts = {}
+        real = {n: getattr(dist, n) for n in ("all_reduce", "all_gather", "all_gather_into_tensor", "broadcast")}
+
+        def counted(name):
+            def fn(*a, **k):
+                counts[name] = counts.get(name, 0) + 1
+                return real[name](*a, **k)
+            return fn
+        for n_ in real:
+            setattr(dist, n_, counted(n_))
+        try:
+            step()                 # one untimed step with the python-level collectives counted (SyncBatchNorm in bn_act, anchors)
+        finally:
+            for n_, f_ in real.items():
+                setattr(dist, n_, f_)
+        torch.cuda.synchronize()
+        result["ranks"] = {"host_issue_ms_per_step": {"max": max(issue), "mean": sum(issue) / len(issue), "per_rank": issue},
+                           "host_cpu_ms_per_step": {"max": max(cpu), "mean": sum(cpu) / len(cpu)},
+                           "cores_visible_per_rank": cores, "host_cpu_count": os.cpu_count(),
+                           "python_level_collectives_per_step": counts,
+                           "note": "python_level_collectives: the all-reduces / all-gathers this package issues itself in one step "
+                                   "(SyncBatchNorm statistics each way in fused_norm.bn_act, the class-anchor exchange); DDP's "
+                                   "bucketed gradient all-reduces are issued from C++ and are not in this count"}
+        if workload in ("model", "fixmatch") and lookahead:
+            def plain_ddp_step():
+                cur = batches[turn[0] % 2]
+                turn[0] += 1
+                return trainer(cur[0], cur[1], cur[2]) if workload == "model" else trainer(cur[0], cur[1])["loss"]
+            plain_ddp_step()
+            t_pl, _ = timed_steps(plain_ddp_step, k2, dev, rehearsal)
+            result["comm"]["ms_per_step_without_lookahead"] = 1e3 * t_pl / k2
+            result["comm"]["lookahead_note"] = ("the same DDP step with next_pos / next_batches withheld (%d steps): lower than "
+                                                "ms_per_step = the look-ahead's kernels hurt beside the collectives" % k2)
     if workload in ("model", "fixmatch"):
         result["graph"] = {"replayed": bool(use_graph),
                            "note": ("geot_amd/graph_step.py: two single-stream hipGraphs per iteration (training graph + the next "

@@ -29,9 +29,24 @@ def init(backend=None):
     return world, rank, local
 
 
-def cloud_range(rank, clouds_per_rank):
-    """Global indices [start, stop) of the synthetic clouds rank `rank` owns."""
-    return rank * clouds_per_rank, (rank + 1) * clouds_per_rank
+def cloud_range(rank, clouds_per_rank, total=None):
+    """Global indices [start, stop) of the clouds rank `rank` owns: contiguous blocks of `clouds_per_rank` in rank order
+    (what exchange_anchor_rows' lowest-rank tie rule assumes), clipped to `total` clouds when given -- the last ranks of an
+    uneven split own fewer (possibly zero) clouds."""
+    lo, hi = rank * clouds_per_rank, (rank + 1) * clouds_per_rank
+    if total is not None:
+        lo, hi = min(lo, total), min(hi, total)
+    return lo, hi
+
+
+def gather_over_ranks(value, device="cpu"):
+    """[value of rank 0, ..., value of rank W-1] on every rank (a float per rank; control plane only)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
 
 
 def barrier():

@@ -220,8 +220,15 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group
     fused = eta.is_cuda and C <= 32 and eta.dtype == torch.float32 and os.environ.get("GEOT_NTM_CT", "fused") == "fused"
     need(sigma.numel() == C and tuple(ema_t.shape) == (C, C), "class_transition: sigma must be (C,), ema_t (C, C)")
     fused = fused and C <= len(LABEL_PROJ)            # the tooth-adjacency projection has 17 entries (train.py:48)
+    empty = B == 0 or N == 0      # a rank of an uneven split that owns no unlabelled cloud: it only takes part in the exchange
+    if empty:
+        need(group is not None, "class_transition: an empty batch has no anchors (only a rank of a sharded batch may pass one)")
+        class_T_e = torch.zeros((C, C), dtype=eta.dtype, device=eta.device)
+        v_star_e = torch.full((C,), float("-inf"), dtype=eta.dtype, device=eta.device)
     if fused:      # anchors in one launch (+ the transition block in another) instead of ~6 + ~40 torch launches
-        if filter_outlier:
+        if empty:
+            class_T, v_star = class_T_e, v_star_e
+        elif filter_outlier:
             class_T, v_star = _filtered_anchor_rows(eta, outlier_q)
         else:
             eta_c = eta.contiguous()
@@ -238,7 +245,9 @@ def class_transition(eta, sigma, ema_t, geo_lambda=0.999, ema_decay=0.999, group
         return ema_t_corr, ema_next, class_T, prior_T
     # first maximum of class cc over the flattened (b, n) order, without materialising the two (C, B*N) /
     # (B*N, C) transposes the reference builds: arg-max over n per (b, cc), then the first b that attains it
-    if filter_outlier:
+    if empty:
+        class_T, v_star = class_T_e, v_star_e
+    elif filter_outlier:
         class_T, v_star = _filtered_anchor_rows(eta, outlier_q)
     else:
         n_best = torch.argmax(eta, dim=2)                                     # (B, C), first maximum along n

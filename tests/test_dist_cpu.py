@@ -122,3 +122,70 @@ def test_two_rank_anchor_rows_match_single_process():
         np.testing.assert_allclose(r_nxt, nxt.numpy(), rtol=1e-14)
     assert not np.array_equal(res[0][4], res[1][4])          # per-rank anchors do differ without the exchange
     assert np.array_equal(cT.numpy()[3], eta[1, :, 250]) and np.array_equal(cT.numpy()[5], eta[2, :, 200])
+
+
+# ---- eight ranks (the node the scaling bench runs on), uneven shards -------------------------------------------------------
+def _anchor_batch8(total=11):
+    """11 unlabelled clouds over 8 ranks at 2 per rank: ranks 0-4 own two, rank 5 owns one, ranks 6-7 own NONE.  Exact
+    ties between ranks for three classes: the first maximum in flattened (b, n) order -- the lowest rank's -- must win."""
+    rng = np.random.default_rng(8)
+    logits = rng.standard_normal((total, 17, 120))
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    eta = e / e.sum(1, keepdims=True)
+    ties = ((2, (1, 30), (9, 4)), (7, (4, 100), (10, 0)), (11, (6, 5), (8, 77)))       # class, first site, later site
+    for cls, (b1, n1), (b2, n2) in ties:
+        row = np.full(17, 0.001)
+        row[cls] = 1 - 0.016
+        eta[b1, :, n1] = row
+        row2 = row.copy()
+        row2[(cls + 1) % 17], row2[(cls + 2) % 17] = 0.0015, 0.0005
+        eta[b2, :, n2] = row2
+    sigma = 0.5 + rng.random(17)
+    ema = rng.random((17, 17)) + 0.1
+    return eta, sigma, ema / ema.sum(1, keepdims=True), ties
+
+
+def _anchor_worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from geot_amd import dist_utils
+    from geot_amd.ntm import class_transition
+    dist_utils.init("gloo")
+    eta, sigma, ema, _ = _anchor_batch8()
+    lo, hi = dist_utils.cloud_range(rank, 2, total=eta.shape[0])
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))       # noqa: E731
+    corr, nxt, cT, _ = class_transition(T(eta[lo:hi]), T(sigma), T(ema), group=dist.group.WORLD)
+    owned = dist_utils.gather_over_ranks(hi - lo)
+    q.put((rank, lo, hi, corr.numpy(), nxt.numpy(), cT.numpy(), owned, dist_utils.max_over_ranks(rank), dist_utils.sum_over_ranks(hi - lo)))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_uneven_shards_and_anchor_exchange():
+    """world 8 over gloo: cloud_range with a total (the last ranks own one / zero clouds), the control-plane reductions,
+    and the anchor all-gather -- every rank, the empty ones included, ends with the single-process class_T / ema_t."""
+    from geot_amd.ntm import class_transition
+    from geot_amd import dist_utils
+    assert [dist_utils.cloud_range(r, 2, total=11) for r in range(8)] == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10), (10, 11), (11, 11), (11, 11)]
+    assert dist_utils.cloud_range(3, 8) == (24, 32)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_anchor_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    eta, sigma, ema, ties = _anchor_batch8()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))       # noqa: E731
+    corr, nxt, cT, _ = class_transition(T(eta), T(sigma), T(ema))
+    for cls, (b1, n1), _late in ties:
+        assert np.array_equal(cT.numpy()[cls], eta[b1, :, n1])
+    for rank, lo, hi, r_corr, r_nxt, r_cT, owned, t_max, total in res:
+        assert (lo, hi) == dist_utils.cloud_range(rank, 2, total=11)
+        assert np.array_equal(r_cT, cT.numpy()), "rank %d anchors differ from the single-process ones" % rank
+        np.testing.assert_allclose(r_corr, corr.numpy(), rtol=1e-14)
+        np.testing.assert_allclose(r_nxt, nxt.numpy(), rtol=1e-14)
+        assert owned == [2, 2, 2, 2, 2, 1, 0, 0] and t_max == 7.0 and total == 11.0

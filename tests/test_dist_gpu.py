@@ -54,7 +54,36 @@ def test_bench_two_rank_rehearsal_emits_an_auditable_line(workload):
     assert comm["ranks_in_collective"] == 2 and comm["backend"] == "gloo"
     assert comm["gradient_allreduce_mb_per_step"] > 100            # 27 M fp32 parameters
     assert np.isfinite(comm["exposed_allreduce_ms"]) and comm["ms_per_step_without_gradient_allreduce"] > 0
-    assert "cpu_baseline" not in rec
+    assert comm["ms_per_step_without_lookahead"] > 0
+    assert "cpu_baseline" not in rec and rec["graph"]["replayed"] is False          # N > 1 runs DDP eagerly
+    ranks = rec["ranks"]                                                            # what a scaling line is attributed with
+    assert len(ranks["host_issue_ms_per_step"]["per_rank"]) == 2 and ranks["host_issue_ms_per_step"]["max"] >= ranks["host_issue_ms_per_step"]["mean"] > 0
+    assert len(ranks["cores_visible_per_rank"]) == 2 and ranks["host_cpu_ms_per_step"]["max"] > 0
+    coll = ranks["python_level_collectives_per_step"]
+    # SyncBatchNorm through fused_norm.bn_act: one all-reduce of the statistics forward, one backward, per BatchNorm layer
+    assert coll.get("all_reduce", 0) >= 2 * 9
+    if workload == "fixmatch":
+        assert coll.get("all_gather", 0) >= 1                                       # the class-anchor exchange
+    assert np.isfinite(rec["final_loss"])
+
+
+@pytest.mark.parametrize("workload", ["model", "fixmatch"])
+def test_two_rank_rehearsal_gives_the_same_losses_wherever_the_lookahead_is_queued(workload):
+    """GEOT_LOOKAHEAD_AT=blocks (inside the backward, beside DDP's bucketed all-reduces) and =forward (behind the forward):
+    the look-ahead only moves kernels between streams -- under DDP + SyncBatchNorm on two ranks the last step's loss is the
+    same to the last bit, and the same as with the look-ahead off."""
+    losses = {}
+    for at, extra in (("blocks", []), ("forward", []), ("off", ["--no-lookahead"])):
+        env = dict(os.environ, GEOT_BENCH_REHEARSAL="1", GEOT_LOOKAHEAD_AT=at if at != "off" else "blocks")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clouds", "1", "--steps", "3",
+                            "--warmup", "1", "--workload", workload, "--points", "8192"] + extra, env=env, capture_output=True,
+                           text=True, timeout=900, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        losses[at] = rec["final_loss"]
+    assert losses["blocks"] == losses["forward"] == losses["off"], losses
 
 
 # ---- FixMatch + NTM iteration: 2 ranks == 1 process -------------------------------------------------------------------
