@@ -1331,8 +1331,10 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_cl_kernel(int c4, int T,
     __shared__ unsigned s_tgt[GR_CAP];       // output row | last flag
     __shared__ int s_empty[GR_CAP];
     __shared__ int s_nempty;
-    const bool on = (int)threadIdx.x < c4;
-    const int q = on ? threadIdx.x : c4 - 1;
+    // gridDim.y channel slabs: this workgroup's lanes are float4 columns [blockIdx.y * c4s, + c4s) of the rows
+    const int c4s = c4 / (int)gridDim.y;
+    const bool on = (int)threadIdx.x < c4s;
+    const int q = (int)blockIdx.y * c4s + (on ? (int)threadIdx.x : c4s - 1);
     const cl_f4 zero = {0.f, 0.f, 0.f, 0.f};
     // rows of targets without pairs: this workgroup's share of the target range
     {
@@ -1436,8 +1438,9 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_bn_cl_kernel(
     __shared__ unsigned s_tgt[GR_CAP];
     __shared__ int s_empty[GR_CAP];
     __shared__ int s_nempty;
-    const bool on = (int)threadIdx.x < c4;
-    const int q = on ? threadIdx.x : c4 - 1;
+    const int c4s = c4 / (int)gridDim.y;          // gridDim.y channel slabs (see gr_slabs)
+    const bool on = (int)threadIdx.x < c4s;
+    const int q = (int)blockIdx.y * c4s + (on ? (int)threadIdx.x : c4s - 1);
     const cl_f4 zero = {0.f, 0.f, 0.f, 0.f};
     const cl_f4 k0 = scale[q], sh = shift[q], mu = mean[q];
     const cl_f4 A = -(k0 * rstd[q] * c2[q]), k0c1 = k0 * c1[q];
@@ -1792,6 +1795,28 @@ GEOT_EXPORT int geot_rix_build(int b, int L, int m, int nt, const int *idx, cons
     return hipGetLastError();
 }
 
+// Channel slabs of the row gathers: the grid's y dimension cuts a row into `slabs` pieces of c4 / slabs float4 columns, and
+// the workgroups are dispatched slab after slab (x runs fastest).  Why: a source row is used by three targets that are
+// neighbours in the walk; between two uses the XCD's workgroups read (workgroups x pairs in flight) other rows, and at
+// 6 KB per row (x 2 tensors in the BatchNorm form) that window does not fit the XCD's 4-MB L2 -- rocprofv3 FETCH_SIZE 2.2x
+// the algorithmic bytes, L2 hit rate 29 %.  A 1-KB slab of the same rows does: at C = 1536 (one wave per workgroup, 6 slabs,
+// 4 rounds of workgroups) FETCH_SIZE 5210 -> 3610 MB (1.5x) / 2263 -> 1334 MB (1.1x), L2 hits 29 -> 53 %, 800 -> 682 us and
+// 492 -> 387 us (profiles/r04_gr_slabs.txt).  Narrow rows (C <= 1024) are best left whole: the per-workgroup staging of the
+// pair stream is then shared by fewer lanes (C = 384: 96 -> 128 us with 3 slabs).  Lists, their order and the one-writer rule
+// are untouched: bit-identical results.  GEOT_GR_SLABS / GEOT_CL_TILES_MULT override (lab).
+static inline int gr_slabs(int c4)
+{
+    int slabs = (c4 >= 384 && c4 % 64 == 0) ? c4 / 64 : 1;
+    if (const char *e = getenv("GEOT_GR_SLABS")) slabs = atoi(e);
+    if (slabs < 1 || c4 % slabs) slabs = 1;
+    return slabs;
+}
+static inline int gr_rounds(int c4)
+{
+    if (const char *mult = getenv("GEOT_CL_TILES_MULT")) return atoi(mult) > 0 ? atoi(mult) : 1;
+    return c4 >= 256 ? 4 : 2;       // rounds of co-resident workgroups per slab: shorter shares keep a band of lists closer together
+}
+
 // g_cl (B, L, C) -> out_cl (B, m, C) through the index geot_rix_build left in `ws` (same b, L, m, nt and the SAME
 // `order` it was built with)
 GEOT_EXPORT int geot_gather_rows_csr_cl(int b, int c, int L, int m, int nt, const float *g_cl, const int *ws, const int *order,
@@ -1802,7 +1827,7 @@ GEOT_EXPORT int geot_gather_rows_csr_cl(int b, int c, int L, int m, int nt, cons
     if (c % 4 || c / 4 > 1024) return hipErrorInvalidValue;
     const RixLayout r = rix_layout(b, L, m, nt);
     if (r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL) return hipErrorInvalidValue;
-    const int c4 = c / 4, waves = (c4 + 63) / 64;
+    const int c4 = c / 4, slabs = gr_slabs(c4), waves = (c4 / slabs + 63) / 64;
     static int cus = 0;
     if (!cus) {
         hipDeviceProp_t prop;
@@ -1814,10 +1839,9 @@ GEOT_EXPORT int geot_gather_rows_csr_cl(int b, int c, int L, int m, int nt, cons
     int &per_cu = per_cu_of[waves];
     if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_rows_csr_cl_kernel, waves * 64, 0) != hipSuccess || per_cu < 1))
         per_cu = 1;
-    long long grid = (long long)cus * per_cu;                 // one round of co-resident workgroups, equal shares of the stream
-    if (const char *mult = getenv("GEOT_CL_TILES_MULT")) grid *= atoi(mult) > 0 ? atoi(mult) : 1;   // lab
+    long long grid = (long long)cus * per_cu * gr_rounds(c4);  // rounds of co-resident workgroups, equal shares of the targets
     if (grid > r.t) grid = r.t;
-    hipLaunchKernelGGL(gather_rows_csr_cl_kernel, dim3((unsigned)grid), dim3((c4 + 63) & ~63), 0, (hipStream_t)stream, c4, (int)r.t,
+    hipLaunchKernelGGL(gather_rows_csr_cl_kernel, dim3((unsigned)grid, slabs), dim3(waves * 64), 0, (hipStream_t)stream, c4, (int)r.t,
                        (int)r.pairs, (const cl_f4 *)g_cl, ws + r.off, ws + r.rev, (const float *)(ws + r.revw),
                        (const unsigned *)(ws + r.rtgt), order, m, (cl_f4 *)out_cl);
     return hipGetLastError();
@@ -1835,7 +1859,7 @@ GEOT_EXPORT int geot_gather_rows_csr_bn_cl(int b, int c, int L, int m, int nt, i
     if (c % 4 || c / 4 > 1024) return hipErrorInvalidValue;
     const RixLayout r = rix_layout(b, L, m, nt);
     if (r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL) return hipErrorInvalidValue;
-    const int c4 = c / 4, waves = (c4 + 63) / 64;
+    const int c4 = c / 4, slabs = gr_slabs(c4), waves = (c4 / slabs + 63) / 64;
     int cus = 256;
     {
         hipDeviceProp_t prop;
@@ -1849,10 +1873,9 @@ GEOT_EXPORT int geot_gather_rows_csr_bn_cl(int b, int c, int L, int m, int nt, i
     int &per_cu = per_cu_of[waves];
     if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_rows_csr_bn_cl_kernel, waves * 64, 0) != hipSuccess || per_cu < 1))
         per_cu = 1;
-    long long grid = (long long)cus * per_cu;
-    if (const char *mult = getenv("GEOT_CL_TILES_MULT")) grid *= atoi(mult) > 0 ? atoi(mult) : 1;   // lab
+    long long grid = (long long)cus * per_cu * gr_rounds(c4);
     if (grid > r.t) grid = r.t;
-    hipLaunchKernelGGL(gather_rows_csr_bn_cl_kernel, dim3((unsigned)grid), dim3(waves * 64), 0, (hipStream_t)stream, c4, (int)r.t,
+    hipLaunchKernelGGL(gather_rows_csr_bn_cl_kernel, dim3((unsigned)grid, slabs), dim3(waves * 64), 0, (hipStream_t)stream, c4, (int)r.t,
                        (int)r.pairs, relu, (const cl_f4 *)y_cl, (const cl_f4 *)dz_cl, (const cl_f4 *)scale, (const cl_f4 *)shift,
                        (const cl_f4 *)mean, (const cl_f4 *)rstd, (const cl_f4 *)c1, (const cl_f4 *)c2, ws + r.off, ws + r.rev,
                        (const float *)(ws + r.revw), (const unsigned *)(ws + r.rtgt), order, m, (cl_f4 *)out_cl);
