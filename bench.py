@@ -20,7 +20,7 @@ backbone alone (dense layers replaced by nothing); `ntm` = the unlabelled half o
 `fixmatch` = configs[4], one full FixMatch+NTM iteration (teacher 2 clouds, student 6 clouds, NTM block, losses,
 both optimisers) per rank.
 
-Prints ONE JSON line on rank 0 (DESIGN.md section 5 explains every field).
+Prints ONE JSON line on rank 0 (DESIGN.md section 7 explains every field).
 """
 import argparse
 import json

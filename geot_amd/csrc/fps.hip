@@ -5,7 +5,7 @@
 //   openpoints/cpp/pointnet2_batch/src/sampling_gpu.cu:101-260 (dense, block<=1024)
 //   pointops/src/sampling/sampling_cuda_kernel.cu:15-171, 175-349 (offset-batched, weighted)
 //
-// Design (MI355X-first):
+// Design (MI355X-first; history: profiles/DESIGN_r01_r03.md 4.1):
 //   * the reference's block-size-dependent tie rule is reproduced with an explicit key
 //     bitreverse(k mod bs) : (k div bs)  instead of inheriting whatever order our own reduction
 //     has, which frees the launch geometry from the reference's;

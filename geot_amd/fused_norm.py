@@ -7,7 +7,7 @@ unbiased variance), ``num_batches_tracked``, eval mode on the running statistics
 sums in both directions -- in 2 passes forward and 2 backward instead of 5 and 8 (csrc/bnrelu.hip).  The module is
 only a parameter / buffer container here; tensors the kernels do not cover (CPU, other dtypes) take ``bn(x)``.
 
-Further down: the small autograd ops that replace runs of torch launches around the dense layers --
+Further down: the small autograd ops that replace runs of torch launches around the dense layers (profiles/DESIGN_r01_r03.md 4.10) --
 ``max_last``, ``add_last_broadcast``, ``thin_mm``, ``linear`` (bias gradient as column sums), ``res_ln`` (residual add +
 LayerNorm), ``qkv_split`` (attention head split) and ``softmax_last``.  Each falls back to the torch composition where its
 kernel does not apply, so callers never branch.

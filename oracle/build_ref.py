@@ -7,7 +7,7 @@ from its own sources with g++ alone: the dataloader's grid_subsampling (SURVEY.m
   -> oracle/_ref/libgrid_subsampling_ref.so
 
 The sources are compiled where they lie; nothing is copied into the repo and the output directory is
-git-ignored.  (The CUDA extensions are unbuildable here -- no nvcc, no CUDA torch -- see DESIGN.md §3.)
+git-ignored.  (The CUDA extensions are unbuildable here -- no nvcc, no CUDA torch -- see DESIGN.md §4.)
 The flags mirror the reference's own setup.py (-std=c++11, default x86-64 code generation: no FMA
 contraction), so the float arithmetic is the reference's.
 """

@@ -4,7 +4,7 @@ written into the captured input buffers, compared bit for bit with the eager res
 composite steps (SetAbstraction forward, NTM half-step with and without its side stream).
 
 Each family is its own test so that a failure names the family.  Round 1 recorded a fault on replay of a captured
-NTM step; what was changed since is listed in DESIGN.md section 7 (LDS opt-in raised once per kernel instead of per
+NTM step; what was changed since is listed in profiles/DESIGN_r01_r03.md section 7 (LDS opt-in raised once per kernel instead of per
 call, scratch cleared by a kernel instead of hipMemsetAsync, no record_stream on pool tensors)."""
 import numpy as np
 import pytest

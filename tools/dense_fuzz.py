@@ -1,4 +1,4 @@
-"""Randomised check of the small kernels around the dense layers against their torch compositions in fp64:
+"""Randomised check of the small kernels around the dense layers (profiles/DESIGN_r01_r03.md 4.10) against their torch compositions in fp64:
 res_ln, qkv_split, softmax_last, linear (bias gradient), add_last_broadcast, thin_mm, bn_relu_max, bn_act(pre_bias) and the
 two Poly-1 focal losses -- random shapes incl. row counts that do not fill a workgroup, all optional inputs on / off.
 

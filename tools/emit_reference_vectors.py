@@ -10,7 +10,7 @@ executed in the build container (no nvcc, no NVIDIA device).
 tests/test_external_vectors.py then (a) finds which squared-distance arithmetic of the oracle -- exact | fma |
 fma_xy (csrc/geot_common.h sqdist3; nvcc's -fmad decides which one the CUDA binaries use) -- reproduces every
 index of the file, (b) fails if none does, and (c) on a GPU box runs the HIP library built for that arithmetic
-against the same file.  Without a file the test is skipped and DESIGN.md section 2 keeps saying "unpinned" for
+against the same file.  Without a file the test is skipped and DESIGN.md section 4 keeps saying "unpinned" for
 these rows.
 
 Only numpy + torch + the reference's own modules are needed; the clouds come from this repository's seeded

@@ -60,7 +60,7 @@ cases = {
                                         ptr(gl), ptr(gI), ptr(gE), ptr(ws_cor)), 4 * B * N * (17 * 3 + 2 * 289)),
 }
 if CI >= 256 and CI % 4 == 0:
-    # the point-major FP stage (csrc/channels_last.hip) at the same shape: 24000 <- 8192, CI channels
+    # the point-major FP stage (csrc/channels_last.hip, profiles/DESIGN_r01_r03.md 4.11) at the same shape: 24000 <- 8192, CI channels
     from geot_amd import fused_norm as fnm
     lib = _lib.load()
     CS = 5
