@@ -98,10 +98,21 @@ def make_optimizer(model, lr=1e-3, weight_decay=1e-4):
     return torch.optim.AdamW(groups, lr=lr, weight_decay=0.0 if weight_decay else weight_decay, fused=fused)
 
 
+_MODE_SENSITIVE = (nn.modules.batchnorm._BatchNorm, nn.modules.dropout._DropoutNd, nn.GroupNorm, nn.LayerNorm)
+
+
 def _mode(module, training):
-    """module.train(training) when the root is not in that mode already: train.py sets the modes once per epoch
-    (train_one_epoch: model.train(), model_t.eval()); walking ~180 modules three times per iteration cost 2 ms of host time."""
-    if module.training != training:
+    """module.train(training) unless the tree is in that mode already: train.py sets the modes once per epoch
+    (train_one_epoch: model.train(), model_t.eval()); walking ~180 modules three times per iteration cost 2 ms of host time.
+    "Already" = the root's flag AND the flag of every submodule whose behaviour depends on it (BatchNorm, Dropout, DropPath --
+    a short list cached on the module): a child toggled on its own (a BatchNorm put in eval() for a partial validation, a
+    helper that flips the teacher's children) is put back instead of silently running in the wrong mode."""
+    watch = module.__dict__.get("_geot_mode_watch")
+    if watch is None:
+        watch = [m for m in module.modules()
+                 if isinstance(m, _MODE_SENSITIVE) or type(m).__name__ == "DropPath"]
+        module.__dict__["_geot_mode_watch"] = watch
+    if module.training != training or any(m.training != training for m in watch):
         module.train(training)
 
 

@@ -180,3 +180,21 @@ def test_lean_transformer_block_is_the_same_function():
             outs.append([y] + list(torch.autograd.grad(y.square().sum(), [x] + list(blk.parameters()))))
         for a, b in zip(*outs):
             assert float((a - b).abs().max()) < 1e-12
+
+
+def test_mode_guard_reasserts_a_child_toggled_on_its_own():
+    """train_step._mode skips the 180-module walk when the tree is in the wanted mode -- judged by the root AND by every
+    BatchNorm / Dropout / DropPath child, so a child flipped on its own is put back."""
+    import torch.nn as nn
+    from geot_amd.train_step import _mode
+    m = nn.Sequential(nn.Linear(3, 3), nn.BatchNorm1d(3), nn.Sequential(nn.Dropout(0.5)))
+    _mode(m, True)
+    assert m[1].training and m[2][0].training
+    m[1].eval()                                   # the root still says "training"
+    _mode(m, True)
+    assert m[1].training
+    m[2][0].eval()
+    _mode(m, True)
+    assert m[2][0].training
+    _mode(m, False)
+    assert not m.training and not m[1].training and not m[2][0].training

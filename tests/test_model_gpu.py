@@ -715,3 +715,30 @@ def test_fixmatch_look_ahead_changes_nothing_but_the_schedule():
     for i in (1, 2):
         for k in runs[False][i]:
             assert abs(runs[False][i][k] - runs[True][i][k]) <= 3e-4 * abs(runs[False][i][k]) + 1e-6, (i, k, runs)
+
+
+def test_wholepartseg_geometry_is_keyed_to_its_source_tensors():
+    """A queued geometry describes the tensors it was computed from, not a shape: WholePartSeg takes it for
+    exactly those tensors, unedited -- another batch of the SAME shape, or the same tensor after an in-place edit, is computed
+    in line (same logits as without any geometry)."""
+    from geot_amd.openpoints.models.segmentation import WholePartSeg
+    from geot_amd.synth import make_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = WholePartSeg(segmentor_args=dict(NAME="PointTransformer_seg_T", **SMALL)).to(dev).train()
+    model.segmentor.seg_head[2].p = 0.0
+    pos_a = torch.from_numpy(make_batch(2, 6000, start_index=0)[0]).to(dev)
+    pos_b = torch.from_numpy(make_batch(2, 6000, start_index=70)[0]).to(dev)
+    cls = torch.zeros(2, 1, dtype=torch.long, device=dev)
+    with torch.no_grad():
+        want_b = model(pos_b, pos_b.transpose(1, 2).contiguous(), cls)[0]
+        g_a = model.prefetch_geometry(pos_a)
+        assert g_a["src"][0][0] is pos_a
+        got = model(pos_b, pos_b.transpose(1, 2).contiguous(), cls, geometry=g_a)[0]      # same shape, another batch
+        assert torch.equal(got, want_b)
+        g_b = model.prefetch_geometry(pos_b)
+        assert torch.equal(model(pos_b, pos_b.transpose(1, 2).contiguous(), cls, geometry=g_b)[0], want_b)
+        edited = pos_b.clone()
+        g_e = model.prefetch_geometry(edited)
+        edited.add_(0.0)                                  # version bump: the geometry no longer describes this tensor's history
+        assert torch.equal(model(edited, edited.transpose(1, 2).contiguous(), cls, geometry=g_e)[0], want_b)
