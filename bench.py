@@ -75,11 +75,13 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=24)
     ap.add_argument("--streams", type=int, default=1, help="sa only: HIP streams the steps are dealt to")
     ap.add_argument("--graph", action="store_true",
-                    help="sa / ntm: capture one step into a hipGraph (torch.cuda.graph) and time replays.  model / fixmatch "
-                         "on one GPU replay the whole iteration from a hipGraph BY DEFAULT (geot_amd/graph_step.py); see --no-graph")
+                    help="sa / ntm: capture one step into a hipGraph (torch.cuda.graph) and time replays.  model / fixmatch on one "
+                         "GPU: make the hipGraph replay (geot_amd/graph_step.py) the PRIMARY mode whatever the size (default: the "
+                         "replay at <= 2 clouds in the training forward, the eager step above; the other mode is timed in the "
+                         "same run and reported beside it)")
     ap.add_argument("--no-graph", action="store_true",
-                    help="model / fixmatch: time the eager step (one kernel launch at a time from the host) instead of the "
-                         "hipGraph replay; N > 1 always runs eagerly (DistributedDataParallel is host logic)")
+                    help="model / fixmatch: time the eager step only, no replay leg; N > 1 always runs eagerly "
+                         "(DistributedDataParallel is host logic)")
     return ap.parse_args()
 
 
@@ -517,30 +519,35 @@ def main():
             return wl.ntm_step(nt, xyz, pw, ps)
 
     graph_note = ""
-    use_graph = workload in ("model", "fixmatch") and world == 1 and not args.no_graph
+    # model / fixmatch on one GPU: the iteration can be issued EAGERLY (one kernel launch at a time from the host) or REPLAYED
+    # from two single-stream hipGraphs (geot_amd/graph_step.py: M = forward, losses, backward, AdamW over static buffers on
+    # the current stream; P = the batch-only work of the NEXT batch on a side stream beside it; same kernels, same bits:
+    # tests/test_graph_step_gpu.py).  Both are timed in every run and both are in the JSON; `value` is the PRIMARY mode:
+    # the replay where the eager step is host-bound (<= 2 clouds in the training forward: 18 ms flat eagerly, 10-13 ms
+    # replayed), the eager step otherwise (4-8 clouds: GPU-bound either way, the replay 1-5 % behind because its look-ahead
+    # graph starts with the forward).  --graph / --no-graph force the primary mode (--no-graph also skips the replay leg).
+    can_replay = workload in ("model", "fixmatch") and world == 1 and not args.no_graph
+    use_graph = can_replay and (args.graph or (fps_clouds if workload == "fixmatch" else B) <= 2)
     eager_step = step
-    graphed = None
-    if use_graph:
-        # The iteration replayed from two single-stream hipGraphs (geot_amd/graph_step.py): M = forward, losses, backward,
-        # AdamW over static buffers on the current stream; P = the batch-only work of the NEXT batch (geometry; FixMatch:
-        # also the frozen teacher's forward and the 3-D loss's kNN graph) on a side stream beside it.  Same kernels, same
-        # bits (tests/test_graph_step_gpu.py); what goes away is the host: ~1100 / ~1500 launches + autograd bookkeeping
-        # per iteration -> a few copies + two graph launches.
+    graphed = replay_step = None
+    if can_replay:
         from geot_amd import graph_step as gs
         graphed = (gs.GraphedSupervisedStep if workload == "model" else gs.GraphedFixMatchStep)(trainer)
 
-        def step():
+        def replay_step():
             cur, nxt = batches[turn[0] % 2], batches[(turn[0] + 1) % 2]
             turn[0] += 1
             if workload == "model":
                 return graphed(cur[0], cur[1], cur[2], next_pos=nxt[0] if lookahead else None)
             return graphed(cur[0], cur[1], next_batches=nxt if lookahead else None)["loss"]
+    if use_graph:
+        step = replay_step
         for _ in range(graphed.warmup + 1):     # eager over the static buffers, then the capture + first replay
             step()
         assert graphed.captured
         graph_note = "; the iteration replayed from two single-stream hipGraphs (static buffers, batch copied in per step)"
-    if args.graph and not use_graph:
-        assert workload in ("sa", "ntm"), "--graph: sa / ntm capture one step here; model / fixmatch replay by default"
+    if args.graph and not can_replay:
+        assert workload in ("sa", "ntm"), "--graph: sa / ntm capture one step here; model / fixmatch have the replay of graph_step.py"
         from geot_amd import streams
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -601,20 +608,32 @@ def main():
     HOST_ISSUE_MAIN["ms"] = 1e3 * HOST_ISSUE["s"] / max(args.steps, 1)
     HOST_ISSUE_MAIN["cpu_ms"] = 1e3 * HOST_ISSUE["cpu_s"] / max(args.steps, 1)
     assert torch.isfinite(out).all()
-    eager_leg = None
-    if use_graph:
-        # the same iterations issued eagerly (one launch at a time from the host), in this run: what the replay is worth,
-        # and where the per-kernel HIP events are taken
-        undo = install_timers()
+    other_leg = None
+    if can_replay:
+        # the same iterations in the OTHER mode, in this run (same model state continuing): what the replay is worth at this
+        # size.  The per-kernel HIP events are taken on eager steps -- no event can be recorded inside a replay.
         k_e = max(2, min(args.steps, 10))
-        eager_step()                            # untimed: the eager look-ahead restarts here
-        t_e, out_e = timed_steps(eager_step, k_e, dev, rehearsal)
+        if use_graph:
+            undo = install_timers()
+            other = eager_step
+            other()                             # untimed: the eager look-ahead restarts here
+        else:
+            for u in undo:
+                u()
+            undo = []
+            other = replay_step
+            for _ in range(graphed.warmup + 2):  # eager over the static buffers, capture, first replays
+                other()
+            assert graphed.captured
+        t_e, out_e = timed_steps(other, k_e, dev, rehearsal)
         assert torch.isfinite(out_e).all()
-        eager_leg = {"ms_per_step": 1e3 * t_e / k_e, "clouds_per_s": clouds_per_step * k_e / t_e,
+        other_leg = {"ms_per_step": 1e3 * t_e / k_e, "clouds_per_s": clouds_per_step * k_e / t_e,
                      "host_issue_ms_per_step": 1e3 * HOST_ISSUE["s"] / k_e,
                      "host_cpu_ms_per_step": 1e3 * HOST_ISSUE["cpu_s"] / k_e, "steps": k_e,
-                     "note": "the same iterations, same model state continuing, launched kernel by kernel from the host "
-                             "(--no-graph times this leg alone)"}
+                     "note": ("the same iterations, same model state continuing, launched kernel by kernel from the host"
+                              if use_graph else
+                              "the same iterations, same model state continuing, replayed from two single-stream hipGraphs "
+                              "(geot_amd/graph_step.py)")}
     for u in undo:
         u()
 
@@ -791,13 +810,15 @@ def main():
                                                 "ms_per_step = the look-ahead's kernels hurt beside the collectives" % k2)
     if workload in ("model", "fixmatch"):
         result["graph"] = {"replayed": bool(use_graph),
-                           "note": ("geot_amd/graph_step.py: two single-stream hipGraphs per iteration (training graph + the next "
-                                    "batch's look-ahead graph on a side stream), bit-identical to the eager step "
-                                    "(tests/test_graph_step_gpu.py); host_issue_ms_per_step is the host's whole share of a step") if use_graph else
-                                   ("eager: N > 1 runs DistributedDataParallel, whose buckets and collectives are host logic"
-                                    if world > 1 else "eager (--no-graph)")}
-        if eager_leg is not None:
-            result["eager"] = eager_leg
+                           "note": ("primary mode = hipGraph replay (geot_amd/graph_step.py: training graph + the next batch's "
+                                    "look-ahead graph on a side stream, bit-identical to the eager step, "
+                                    "tests/test_graph_step_gpu.py); the eager leg of the same run is `eager`") if use_graph else
+                                   ("primary mode = eager: N > 1 runs DistributedDataParallel, whose buckets and collectives are "
+                                    "host logic" if world > 1 else
+                                    "primary mode = eager" + ("; the hipGraph replay of the same iterations is `replay` (primary at <= 2 "
+                                                              "clouds, where the eager step is host-bound)" if can_replay else " (--no-graph)"))}
+        if other_leg is not None:
+            result["eager" if use_graph else "replay"] = other_leg
         result["config"]["lookahead"] = ("the step is handed the next batch's coordinates (two batches alternate) and queues "
                                          "their sampling / grouping / index work beside its own backward"
                                          if lookahead else "off: all of a batch's work inside its own step")
