@@ -38,10 +38,12 @@ UNUSED_SUPERVISED = ("T_revision.weight", "T_linear.weight", "sigma")
 UNUSED_FIXMATCH = ("T_revision.weight", "T_linear.weight")
 
 
-def ddp(module, device, sync_bn=True, unused=(), **kw):
-    """train.py:159-166: SyncBatchNorm conversion + DistributedDataParallel when a process group is up."""
+def ddp(module, device, sync_bn=True, unused=(), min_world=2, **kw):
+    """train.py:159-166: SyncBatchNorm conversion + DistributedDataParallel when a process group of at least `min_world`
+    ranks is up (min_world=1: wrap even a single rank -- the one way to put DDP's reducer and RCCL under a step on a
+    one-GPU box, tests/test_dist_gpu.py)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world):
         return module
     if sync_bn:
         module = nn.SyncBatchNorm.convert_sync_batchnorm(module)

@@ -189,3 +189,63 @@ def test_fixmatch_iteration_on_two_ranks_equals_the_single_process_iteration():
         np.testing.assert_array_equal(g0[k], g1[k])                 # DDP: both ranks step with the same averaged gradient
         err = np.linalg.norm(g0[k] - w) / (np.linalg.norm(w) + 1e-12)
         assert err <= 5e-3, (k, err)                                # fp32: batch-size dependent GEMM blocking / summation order
+
+
+def _rccl_single_rank_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import geot_amd  # noqa: F401
+    import torch.distributed as dist
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd import train_step as ts
+    from geot_amd.synth import make_batch, region_labels
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    x = torch.arange(1 << 20, device=dev, dtype=torch.float32)
+    dist.all_reduce(x)
+    parts = [torch.empty(4, device=dev)]
+    dist.all_gather(parts, torch.arange(4.0, device=dev))
+    torch.manual_seed(3)
+    init = PointTransformer_seg_T(**SMALL).state_dict()
+    xyz = make_batch(2, N, start_index=5)[0]
+    pos, tgt = torch.from_numpy(xyz).to(dev), torch.from_numpy(region_labels(xyz)).to(dev)
+    cls = torch.zeros(2, 1, dtype=torch.long, device=dev)
+    losses = {}
+    for wrapped in (True, False):
+        m = PointTransformer_seg_T(**SMALL).to(dev)
+        m.load_state_dict(init)
+        m.seg_head[2].p = 0.0
+        net = ts.ddp(m, dev, unused=ts.UNUSED_SUPERVISED, min_world=1) if wrapped else m
+        assert isinstance(net, torch.nn.parallel.DistributedDataParallel) == wrapped
+        step = ts.SupervisedStep(net)
+        losses[wrapped] = [float(step(pos, cls, tgt)) for _ in range(3)]
+    torch.cuda.synchronize()
+    q.put((dist.get_backend(), float(x[-1]), parts[0].tolist(), losses))
+    dist.destroy_process_group()
+
+
+def test_rccl_backend_runs_a_ddp_step_on_one_rank():
+    """The only RCCL execution a one-GPU box allows: a process group over backend "nccl" (= RCCL on ROCm) with ONE rank --
+    all-reduce and all-gather go through the library, and DistributedDataParallel + SyncBatchNorm over it drive three
+    supervised steps (bucketed gradient all-reduce in the backward, look-ahead off) to the same losses as the bare model.
+    What it cannot show is a transfer between GPUs; that needs the driver's multi-GPU node."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank_worker, args=(_free_port(), q))
+    p.start()
+    import queue
+    res = None
+    for _ in range(120):
+        try:
+            res = q.get(timeout=5)
+            break
+        except queue.Empty:
+            if p.exitcode not in (None, 0):
+                pytest.fail("the RCCL rank exited with %s" % p.exitcode)
+    p.join(timeout=120)
+    assert res is not None and p.exitcode == 0
+    backend, last, gathered, losses = res
+    assert backend == "nccl" and last == float((1 << 20) - 1) and gathered == [0.0, 1.0, 2.0, 3.0]
+    assert losses[True] == losses[False], losses
