@@ -22,6 +22,8 @@ M's input buffers at the head of the next call, behind M.  Whether that product 
 checked on the host (the very tensors the previous call announced, unedited); otherwise -- the first call, a reshuffled
 loader, no look-ahead at all -- P runs for the current batch on the current stream before M.
 
+A learning-rate schedule reaches a captured AdamW step through memory: make `lr` a float32 device tensor in the optimizer's
+parameter groups and fill_ it between calls (tests/test_graph_step_gpu.py); a python float is baked into the graph.
 Inputs are copied into static buffers before every replay; shapes are fixed by the first call (another shape is an error:
 build another wrapper).  The first `warmup` executions of each graph's body run eagerly over the same buffers, the next
 one captures.  DistributedDataParallel is not captured (gradient buckets and RCCL's collectives are host logic): N > 1

@@ -163,3 +163,47 @@ def test_replays_survive_eager_launches_between_them():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want) and torch.equal(gb, want_gb)
+
+
+def test_a_learning_rate_schedule_reaches_the_replayed_step_through_a_tensor():
+    """A captured AdamW step bakes a python-float lr into the graph.  The reference steps its scheduler every epoch
+    (train.py:283 scheduler.step(epoch)): with `lr` a float32 DEVICE tensor in the parameter groups (fused AdamW reads it from
+    memory) a schedule is a fill_ between two replays -- and the replayed run equals the eager run with the same tensor lr."""
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd import train_step as ts, graph_step as gs
+    batches = _sup_batches(2, 6000)
+    torch.manual_seed(0)
+    init = PointTransformer_seg_T(**SMALL).state_dict()
+    schedule = [1e-3, 1e-3, 1e-3, 5e-4, 5e-4, 2e-4]
+    runs = {}
+    for mode in ("eager", "graph"):
+        m = PointTransformer_seg_T(**SMALL).to(DEV)
+        m.load_state_dict(init)
+        step = ts.SupervisedStep(m)
+        lr = torch.tensor(schedule[0], dtype=torch.float32, device=DEV)
+        for group in step.optimizer.param_groups:
+            group["lr"] = lr
+        call = gs.GraphedSupervisedStep(step, warmup=2) if mode == "graph" else step
+        if mode == "eager":
+            for group in step.optimizer.param_groups:
+                group["capturable"] = True       # (a tensor lr needs it; the graphed wrapper sets it itself)
+        torch.manual_seed(7)
+        losses = []
+        for i, value in enumerate(schedule):
+            lr.fill_(value)
+            cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+            losses.append(call(cur[0], cur[1], cur[2], next_pos=nxt[0]).clone())
+        torch.cuda.synchronize()
+        runs[mode] = (losses, _state(step))
+    for a, b in zip(runs["eager"][0], runs["graph"][0]):
+        assert torch.equal(a, b)
+    _same(runs["eager"][1], runs["graph"][1])
+    # and the schedule did something: the run with a constant lr ends elsewhere
+    m = PointTransformer_seg_T(**SMALL).to(DEV)
+    m.load_state_dict(init)
+    step = ts.SupervisedStep(m)
+    torch.manual_seed(7)
+    for i in range(len(schedule)):
+        cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+        step(cur[0], cur[1], cur[2], next_pos=nxt[0])
+    assert not torch.equal(m.seg_head[3].weight, runs["graph"][1]["model.seg_head.3.weight"])
