@@ -659,6 +659,9 @@ def main():
         "kernel": "fps_pruned_kernel", "bound": "valu", "achieved": fps_tf, "peak": FP32_VECTOR_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": fps_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
         "avg_launch_ms": fps_ms, "alone_launch_ms": fps_alone_ms, "cus_used": fps_clouds,
+        # the same rate against the peak of the CUs the launch can occupy (one workgroup per cloud): context for `frac`, which
+        # divides by all 256 CUs and is capped at clouds / 256 whatever the kernel does
+        "frac_of_occupied_cus": fps_tf / (FP32_VECTOR_PEAK_TFLOPS * min(fps_clouds, 256) / 256.0) if fps_clouds else None,
         "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic flop = clouds*N*(m-1) updates "
                 "* 10 (what the reference executes); the pruned kernel skips most of them exactly; one workgroup "
                 "(one CU of 256) per cloud; avg_launch_ms is the launch as it ran inside the step (side stream, sharing its CUs "
