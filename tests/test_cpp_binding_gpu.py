@@ -323,3 +323,40 @@ def test_the_package_launches_through_the_compiled_dispatcher(capsys):
         print("\n[launch cost] _common.call('geot_gather_points', ...): ctypes %.2f us, compiled dispatcher %.2f us" %
               (cost["ctypes"], cost["dispatcher"]))
     assert cost["dispatcher"] <= 2.0 * cost["ctypes"]
+
+
+@pytest.mark.gpu
+def test_compiled_modules_on_empty_and_ragged_inputs():
+    """Edge cases through the compiled modules: zero clouds, zero samples, zero neighbours, an empty segment of an
+    offset-batched call -- the same outputs as the ctypes modules (empty tensors, zero-filled where the reference zero-fills),
+    no launch on nothing, and a shape violation is a RuntimeError, not a crash."""
+    from geot_amd import build_torch_ext
+    from geot_amd.ext import pointnet2_ext as py_ext, pointops_cuda as py_pops
+    from geot_amd.synth import make_batch
+    ext, pops = build_torch_ext.load("_pointnet2_ext_cpp"), build_torch_ext.load("_pointops_cuda_cpp")
+    xyz = torch.from_numpy(make_batch(2, 500)[0]).to(DEV)
+    for mod in (py_ext, ext):
+        assert tuple(mod.furthest_point_sampling(xyz[:0], 8).shape) == (0, 8)
+        assert tuple(mod.furthest_point_sampling(xyz, 0).shape) == (2, 0)
+        e = torch.empty((2, 0), dtype=torch.int32, device=DEV)
+        assert tuple(mod.gather_points(xyz.transpose(1, 2).contiguous(), e).shape) == (2, 3, 0)
+        g = mod.gather_points_grad(torch.empty((2, 3, 0), device=DEV), e, 500)
+        assert tuple(g.shape) == (2, 3, 500) and float(g.abs().sum()) == 0.0
+        bq = mod.ball_query(xyz[:, :0].contiguous(), xyz, 0.1, 4)
+        assert tuple(bq.shape) == (2, 0, 4)
+        d, i = mod.three_nn(xyz[:, :0].contiguous(), xyz)
+        assert tuple(d.shape) == (2, 0, 3) and tuple(i.shape) == (2, 0, 3)
+        with pytest.raises(RuntimeError):
+            mod.gather_points(xyz.transpose(1, 2).contiguous(), torch.zeros((3, 4), dtype=torch.int32, device=DEV))   # batch mismatch
+    # offset-batched FPS with an EMPTY middle segment: both modules give the same indices
+    pts = torch.cat([xyz[0], xyz[1]]).contiguous()
+    offset = torch.tensor([500, 500, 1000], dtype=torch.int32, device=DEV)       # segment 1 holds no points
+    new_offset = torch.tensor([40, 40, 90], dtype=torch.int32, device=DEV)
+    outs = []
+    for mod in (py_pops, pops):
+        idx = torch.zeros(90, dtype=torch.int32, device=DEV)
+        tmp = torch.full((1000,), 1e10, device=DEV)
+        mod.furthestsampling_cuda(3, 500, pts, offset, new_offset, tmp, idx)
+        outs.append(idx)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and int(outs[1][:40].max()) < 500 and int(outs[1][40:].min()) >= 500
