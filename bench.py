@@ -33,6 +33,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# One GPU: the replay leg launches its graphs in the runtime's fast mode (graph packet capture left ON: 0.5 ms of host time per
+# launch instead of 7-20 ms), which graph_step accepts only for graphs of kernel nodes alone -- it inspects what it captured
+# and this file records the node counts (and falls back to the eager step if a graph is refused).  An exported
+# GEOT_GRAPH_LAUNCH / DEBUG_CLR_GRAPH_PACKET_CAPTURE wins.  (sa / ntm --graph capture without that inspection: safe mode.)
+if (os.environ.get("WORLD_SIZE", "1") == "1" and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ
+        and not ("--graph" in sys.argv and any(w in sys.argv for w in ("sa", "ntm")))):
+    os.environ.setdefault("GEOT_GRAPH_LAUNCH", "fast")
 import geot_amd  # noqa: E402,F401  (before torch touches the GPU: it pins the HIP runtime's graph switch, geot_amd/__init__.py)
 
 N_POINTS = 24000
@@ -522,12 +529,14 @@ def main():
     # model / fixmatch on one GPU: the iteration can be issued EAGERLY (one kernel launch at a time from the host) or REPLAYED
     # from two single-stream hipGraphs (geot_amd/graph_step.py: M = forward, losses, backward, AdamW over static buffers on
     # the current stream; P = the batch-only work of the NEXT batch on a side stream beside it; same kernels, same bits:
-    # tests/test_graph_step_gpu.py).  Both are timed in every run and both are in the JSON; `value` is the PRIMARY mode:
-    # the replay where the eager step is host-bound (<= 2 clouds in the training forward: 18 ms flat eagerly, 10-13 ms
-    # replayed), the eager step otherwise (4-8 clouds: GPU-bound either way, the replay 1-5 % behind because its look-ahead
-    # graph starts with the forward).  --graph / --no-graph force the primary mode (--no-graph also skips the replay leg).
+    # tests/test_graph_step_gpu.py).  Both are timed in every run and both are in the JSON; `value` is the PRIMARY mode, fixed
+    # here and not picked after the fact: the replay where it was measured ahead -- the FixMatch+NTM iteration (30.4 against
+    # 31.1 ms: its ~1500 launches keep the eager host on the critical path) and the supervised step at <= 2 clouds (the eager
+    # step is host-bound at 17-18 ms; 10-13 ms replayed) -- the eager step otherwise (4-8 clouds: GPU-bound either way, the
+    # replay 1-7 % behind because its look-ahead graph starts beside the forward's widest GEMMs, profiles/r04_fps_beside.txt).
+    # --graph / --no-graph force the primary mode (--no-graph also skips the replay leg).
     can_replay = workload in ("model", "fixmatch") and world == 1 and not args.no_graph
-    use_graph = can_replay and (args.graph or (fps_clouds if workload == "fixmatch" else B) <= 2)
+    use_graph = can_replay and (args.graph or workload == "fixmatch" or B <= 2)
     eager_step = step
     graphed = replay_step = None
     if can_replay:
@@ -540,12 +549,18 @@ def main():
             if workload == "model":
                 return graphed(cur[0], cur[1], cur[2], next_pos=nxt[0] if lookahead else None)
             return graphed(cur[0], cur[1], next_batches=nxt if lookahead else None)["loss"]
+    replay_refused = None
     if use_graph:
-        step = replay_step
-        for _ in range(graphed.warmup + 1):     # eager over the static buffers, then the capture + first replay
-            step()
-        assert graphed.captured
-        graph_note = "; the iteration replayed from two single-stream hipGraphs (static buffers, batch copied in per step)"
+        try:
+            for _ in range(graphed.warmup + 1):     # eager over the static buffers, then the capture + first replay
+                replay_step()
+            assert graphed.captured
+            step = replay_step
+            graph_note = "; the iteration replayed from two single-stream hipGraphs (static buffers, batch copied in per step)"
+        except RuntimeError as e:                   # fast launch mode and a graph that is not kernel-only: eager, and say so
+            if "only kernel nodes" not in str(e):
+                raise
+            replay_refused, use_graph, can_replay = str(e), False, False
     if args.graph and not can_replay:
         assert workload in ("sa", "ntm"), "--graph: sa / ntm capture one step here; model / fixmatch have the replay of graph_step.py"
         from geot_amd import streams
@@ -622,9 +637,15 @@ def main():
                 u()
             undo = []
             other = replay_step
-            for _ in range(graphed.warmup + 2):  # eager over the static buffers, capture, first replays
-                other()
-            assert graphed.captured
+            try:
+                for _ in range(graphed.warmup + 2):  # eager over the static buffers, capture, first replays
+                    other()
+                assert graphed.captured
+            except RuntimeError as e:
+                if "only kernel nodes" not in str(e):
+                    raise
+                replay_refused, other = str(e), None
+    if can_replay and other is not None:
         t_e, out_e = timed_steps(other, k_e, dev, rehearsal)
         assert torch.isfinite(out_e).all()
         other_leg = {"ms_per_step": 1e3 * t_e / k_e, "clouds_per_s": clouds_per_step * k_e / t_e,
@@ -818,10 +839,20 @@ def main():
                                     "tests/test_graph_step_gpu.py); the eager leg of the same run is `eager`") if use_graph else
                                    ("primary mode = eager: N > 1 runs DistributedDataParallel, whose buckets and collectives are "
                                     "host logic" if world > 1 else
-                                    "primary mode = eager" + ("; the hipGraph replay of the same iterations is `replay` (primary at <= 2 "
-                                                              "clouds, where the eager step is host-bound)" if can_replay else " (--no-graph)"))}
+                                    "primary mode = eager" + ("; the hipGraph replay of the same iterations is `replay` (primary for "
+                                                              "the FixMatch iteration and at <= 2 clouds, where the eager "
+                                                              "step is host-bound)" if can_replay else " (--no-graph)"))}
         if other_leg is not None:
             result["eager" if use_graph else "replay"] = other_leg
+        if graphed is not None and graphed.node_types:
+            result["graph"]["launch_mode"] = geot_amd.GRAPH_LAUNCH if not geot_amd.graph_replay_is_safe() else "safe"
+            result["graph"]["nodes"] = graphed.node_types      # {"P": {"kernel": n}, "M": {...}}: hipGraphGetNodes on the captures
+            result["graph"]["launch_note"] = (
+                "fast = the runtime's graph packet capture left on (0.5 ms of host time per launch); correct only for graphs of "
+                "kernel nodes alone, which graph_step verifies per capture (`nodes`); safe = packet capture off "
+                "(DEBUG_CLR_GRAPH_PACKET_CAPTURE=0), any graph, 7-20 ms per launch (geot_amd/__init__.py)")
+        if replay_refused:
+            result["graph"]["replay_refused"] = replay_refused
         result["config"]["lookahead"] = ("the step is handed the next batch's coordinates (two batches alternate) and queues "
                                          "their sampling / grouping / index work beside its own backward"
                                          if lookahead else "off: all of a batch's work inside its own step")

@@ -129,6 +129,7 @@ PROTOTYPES.update({
     "geot_edgeconv_gn_max_grad_rix": [_c_int] * 6 + [_c_float] + [_P] * 15 + [ctypes.c_longlong, _c_void_p],
     "geot_edgeconv_rix_build": [_c_int] * 4 + [_P, _P, ctypes.c_longlong, _c_void_p],
 })
+PROTOTYPES["geot_rowsum_f64"] = [ctypes.c_longlong, _c_int, _P, _P, _c_void_p]
 # entry points that do not follow the "(..., stream) -> hipError_t" shape
 PLAIN = {
     "geot_sa_param_floats": ([_c_int, _c_int, ctypes.POINTER(_c_int)], _c_int),

@@ -817,6 +817,34 @@ GEOT_EXPORT int geot_colsum(int rows, int cols, const float *x, float *out, floa
     return hipGetLastError();
 }
 
+namespace geot {
+// out[r] = sum of the n floats of row r, accumulated in fp64 in a fixed order (a lane's strided share ascending, then a
+// fixed tree): one workgroup per row.  For the long, few-row sums whose torch form (aten::sum over 10^5 elements into a
+// handful of outputs) zeroes a semaphore buffer with hipMemsetAsync -- a memset NODE once captured, which ROCm 7.0's graph
+// packet capture does not keep ordered (geot_amd/graph_step.py): bias gradients of 1x1 convolutions over (B, C, N), the
+// per-channel sums of the FP stage's skip input.
+__global__ __launch_bounds__(256) void rowsum_f64_kernel(int n, const float *__restrict__ x, double *__restrict__ out)
+{
+    const float *row = x + (size_t)blockIdx.x * n;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)row[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+} // namespace geot
+
+GEOT_EXPORT int geot_rowsum_f64(long long rows, int n, const float *x, double *out, void *stream)
+{
+    if (rows < 0 || n < 0 || rows > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(geot::rowsum_f64_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, n, x, out);
+    return hipGetLastError();
+}
+
 GEOT_EXPORT int geot_segment_sum(long long rows, int n, const float *x, float *out, void *stream)
 {
     if (rows < 0 || n < 4 || n > 256 || (n & 3) || (((uintptr_t)x) & 15)) return hipErrorInvalidValue;

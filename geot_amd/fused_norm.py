@@ -457,7 +457,7 @@ class _FpStageClFn(Function):
         ctx.save_for_backward(y, idx, weight, skip, wbc, scale, shift, mean, rstd)
         ctx.cfg = (bool(relu), count, group, m, order, rix)
         # S2 of the skip-weight gradient (input data only); not under no_grad / for frozen weights
-        ctx.skip_sums = skip.sum((0, 2), dtype=torch.float64) if (cs and ctx.needs_input_grad[4]) else None
+        ctx.skip_sums = rowsum_f64(skip).sum(0) if (cs and ctx.needs_input_grad[4]) else None     # (B, cs) -> (cs,), fp64
         return z
 
     @staticmethod
@@ -513,6 +513,41 @@ def fp_stage_cl(bn, a_cl, idx, weight, skip, wb, relu=True, order=None, rix=None
     beta = bn.bias if bn.bias is not None else torch.zeros(c, device=dev)
     return _FpStageClFn.apply(a_cl.contiguous(), idx.contiguous(), weight.contiguous(),
                               None if skip is None else skip.contiguous().float(), wb, gamma, beta, bn, relu, order, rix)
+
+
+def rowsum_f64(x):
+    """x (..., n) contiguous float32 on the GPU -> fp64 sums over the last axis, shape x.shape[:-1]: one workgroup per row, fixed
+    order (geot_rowsum_f64).  For long rows and few of them, where torch's own reduction zeroes a semaphore buffer with
+    hipMemsetAsync (a memset node once captured: graph_step.py)."""
+    x = x.contiguous()
+    out = torch.empty(x.shape[:-1], dtype=torch.float64, device=x.device)
+    call("geot_rowsum_f64", x.device, out.numel(), x.shape[-1], ptr(x), ptr(out))
+    return out
+
+
+class _AddChannelBiasFn(Function):
+    """y (B, C, L) or (C, L) + bias (C) as one launch; the bias gradient = sums of the incoming gradient over (B, L) through
+    rowsum_f64."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        return y + bias.view(-1, 1)
+
+    @staticmethod
+    def backward(ctx, g):
+        gb = None
+        if ctx.needs_input_grad[1]:
+            gb = rowsum_f64(g)                          # fp64 row sums; (B, C): then the B rows, a small reduction
+            gb = (gb.sum(0) if g.dim() == 3 else gb).float()
+        return g, gb
+
+
+def add_channel_bias(y, bias):
+    """y (B, C, L) + bias.view(1, C, 1), or y (C, L) + bias.view(C, 1), for float32 GPU tensors; anything else: the torch
+    expression (whose bias gradient is an aten::sum -- for some shapes with a memset in front: see rowsum_f64)."""
+    if not (y.is_cuda and y.dtype == torch.float32 and bias.dtype == torch.float32 and y.dim() in (2, 3) and y.numel() > 0):
+        return y + bias.view(-1, 1)
+    return _AddChannelBiasFn.apply(y, bias)
 
 
 class _SegmentMaxFn(Function):

@@ -98,16 +98,20 @@ class _Graphed:
                 raise RuntimeError("graph_step: a DistributedDataParallel model is not captured (its gradient buckets and "
                                    "collectives are host logic); run N > 1 eagerly")
         import geot_amd
-        if not geot_amd.graph_replay_is_safe() and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
+        # (see geot_amd/__init__.py) packet capture off: anything replays; on: only graphs of kernel nodes do -- checked per graph
+        self.kernel_only = not geot_amd.graph_replay_is_safe()
+        if self.kernel_only and geot_amd.GRAPH_LAUNCH != "fast" and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
             raise RuntimeError(
                 "graph_step: %s must be 0 before the HIP runtime initialises (import geot_amd before the first torch.cuda "
-                "call, or export it): with graph packet capture on, eager launches between two replays corrupt the "
-                "graph's memset nodes -- wrong gradients, no error (geot_amd/__init__.py)" % geot_amd.GRAPH_PACKET_CAPTURE_ENV)
+                "call, or export it) -- or choose GEOT_GRAPH_LAUNCH=fast, under which only kernel-only graphs are accepted: "
+                "with graph packet capture on, eager launches between two replays corrupt a graph's memset / memcpy nodes "
+                "-- wrong gradients, no error (geot_amd/__init__.py)" % geot_amd.GRAPH_PACKET_CAPTURE_ENV)
         self.step = step
         self.warmup = int(warmup)
         self.calls = 0
         self.device = None
         self.graphs = {}          # "P" / "M" -> (CUDAGraph, static outputs)
+        self.node_types = {}      # "P" / "M" -> {"kernel": n, ...} of the captured graph
         self._eager_runs = {"P": 0, "M": 0}
         self.side = None          # the stream P replays on beside M
         self.pre = None           # P's product in M's input buffers
@@ -118,17 +122,25 @@ class _Graphed:
             for group in opt.param_groups:
                 group["capturable"] = True   # fused AdamW: the step counter is a device tensor already; same kernel
 
-    def _run(self, name, fn):
+    def _run(self, name, fn, pool_of=None):
         """fn() = a graph's body over the static buffers.  Eager for its first `warmup` executions, then captured once
-        and replayed on the current stream."""
+        (into the memory pool of graph `pool_of`, if given) and replayed on the current stream."""
         if name not in self.graphs:
-            if self._eager_runs[name] < self.warmup:
-                self._eager_runs[name] += 1
+            if self._eager_runs.get(name, 0) < self.warmup:
+                self._eager_runs[name] = self._eager_runs.get(name, 0) + 1
                 return fn()
             torch.cuda.synchronize(self.device)
-            graph = torch.cuda.CUDAGraph()
-            with streams.capture(graph, self.device):
+            graph = torch.cuda.CUDAGraph(keep_graph=True)         # (the hipGraph_t stays: node_types below)
+            pool = self.graphs[pool_of][0].pool() if pool_of is not None else None
+            with streams.capture(graph, self.device, pool=pool):
                 out = fn()
+            self.node_types[name] = kinds = streams.node_types(graph)
+            if self.kernel_only and set(kinds) - {"kernel"} and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
+                del graph
+                raise RuntimeError(
+                    "graph_step: graph %s holds %s; with graph packet capture on (GEOT_GRAPH_LAUNCH=fast) only kernel nodes "
+                    "replay correctly (geot_amd/__init__.py).  tools/lab/find_nonkernel_ops.py names the operators that "
+                    "issue hipMemsetAsync / hipMemcpyAsync; or run GEOT_GRAPH_LAUNCH=safe" % (name, kinds))
             self.graphs[name] = (graph, out)
         graph, out = self.graphs[name]
         graph.replay()
@@ -136,7 +148,7 @@ class _Graphed:
 
     @property
     def captured(self):
-        return "M" in self.graphs and "P" in self.graphs
+        return ("M" in self.graphs or "M2" in self.graphs) and "P" in self.graphs
 
     def _join_pending(self):
         """The current stream waits for the P of the previous call (its product, and its reads of P's static inputs)."""
@@ -163,6 +175,9 @@ class _Graphed:
                 tree_copy_(self.pre, self._pre_next)
         self._pre_next = None
         self._announced = None
+        mid = None
+        if isinstance(train, tuple):                 # (forward, backward): P starts between the two, beside the backward
+            mid = self._run("M1", train[0])
         if next_src is not None:
             load_next(False)
             self.side.wait_stream(main)              # behind the copies above (and behind M's previous replay)
@@ -170,7 +185,7 @@ class _Graphed:
                 self._pre_next = self._run("P", lookahead)
             self._pending = True
             self._announced = tuple((t, t._version) for t in next_src)
-        out = self._run("M", train)
+        out = self._run("M2", lambda: train[1](mid), pool_of="M1") if isinstance(train, tuple) else self._run("M", train)
         self.calls += 1
         return out
 
@@ -183,8 +198,13 @@ class GraphedSupervisedStep(_Graphed):
     """SupervisedStep.__call__ from hipGraphs (see the module docstring).  The returned loss is a static tensor the next
     call overwrites: clone it to keep it."""
 
-    def __init__(self, step, warmup=2):
+    def __init__(self, step, warmup=2, split=None):
+        """split: capture the iteration as two graphs, M1 = forward + loss and M2 = backward + AdamW (sharing a memory pool),
+        and start P between them -- beside the backward -- instead of beside the forward.  Same bits; measured no faster
+        (8 clouds: 32.81 against 32.73 ms -- what P costs M is its long FPS sharing 8 CUs with the persistent-grid GEMMs,
+        wherever it runs: profiles/r04_fps_beside.txt), so off unless asked for (GEOT_GRAPH_SPLIT=1)."""
         super().__init__(step, warmup)
+        self.split = (os.environ.get("GEOT_GRAPH_SPLIT", "0") == "1") if split is None else bool(split)
         self.x = None            # static (pos, cls, target)
         self.next_pos = None     # static coordinates P works on
 
@@ -210,6 +230,8 @@ class GraphedSupervisedStep(_Graphed):
 
         def train():
             return self.step.iteration(self.x[0], self.x[1], self.x[2], self.pre, None)[0]
+        if self.split:
+            train = (lambda: self.step.forward_loss(self.x[0], self.x[1], self.x[2], self.pre), self.step.backward_update)
         return self._iterate(announced_now, None if next_pos is None else (next_pos,), load_next, lookahead, train)
 
 

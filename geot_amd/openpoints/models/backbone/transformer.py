@@ -37,7 +37,7 @@ from .transformer_ops import (Group, fps, fps_downsample, graph_feature, get_gra
                               edgeconv_tail, edgeconv_tail_eligible, edgeconv_reverse_index)
 from .... import streams
 from ....ntm import sig_t_mean  # noqa: F401  (transformer.py:1099-1131 lives in ntm.py)
-from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm
+from ....fused_norm import bn_act, fp_front, fp_front_eligible, max_last, add_last_broadcast, thin_mm, add_channel_bias
 from ....fused_norm import (fp_front_cl, fp_front_cl_eligible, bn_act_cl, fp_stage_cl, pointwise_to_cl, pointwise_from_cl,
                             local_spatial_order, ReverseIndex)
 from ....fused_norm import linear as lean_linear, res_ln, res_ln_eligible, qkv_split, softmax_last
@@ -256,18 +256,20 @@ class Encoder(nn.Module):
         c1 = f0.shape[0]
         pooled = max_last(f0.view(c1, bs * g, n))                                       # (256, BG), + b1 below
         if b1 is not None:
-            pooled = pooled + b1.unsqueeze(1)
+            pooled = add_channel_bias(pooled, b1)
         c2 = self.second_conv[0]
         w = c2.weight.squeeze(-1)
         pre = c2.bias
         if b1 is not None:                                     # W_f (f0 + b1) = W_f f0 + W_f b1
             wb = torch.mv(w[:, c1:], b1)
-            pre = wb if pre is None else pre + wb
+            # (pre * 1.0: the two addends must not receive the SAME gradient tensor -- AccumulateGrad clones a shared one with a
+            # device-to-device memcpy, a memcpy node when the step is captured; x1.0 is exact)
+            pre = wb if pre is None else pre * 1.0 + wb
         h = add_last_broadcast(conv(c2, f0, w[:, c1:], bias=False).view(-1, bs * g, n), torch.mm(w[:, :c1], pooled))
         h0 = conv(self.second_conv[3], norm_act(self.second_conv, h.view(-1, L), pre), bias=False)  # (C_enc, L)
         out = max_last(h0.view(-1, bs * g, n))
         if b2 is not None:
-            out = out + b2.unsqueeze(1)
+            out = add_channel_bias(out, b2)
         return out.t().reshape(bs, g, self.encoder_channel)
 
     def forward(self, point_groups):
@@ -611,8 +613,15 @@ class PointTransformer_seg_T(nn.Module):
                 with torch.cuda.stream(side):
                     side.wait_event(grouped)
                     plan = self._index_plan(pts, center)
-        group_input_tokens = self.reduce_dim(self.encoder(neighborhood))
-        pos = self.pos_embed(center)
+        if self.dense != "reference":
+            # the three Linear layers in front of the blocks through fused_norm.linear: the same GEMMs, the bias gradients as
+            # fixed-order column sums (aten::sum over 4096 rows zeroes a semaphore buffer by memset: a memset node when captured)
+            tokens = self.encoder(neighborhood)
+            group_input_tokens = lean_linear(self.reduce_dim, tokens) if isinstance(self.reduce_dim, nn.Linear) else self.reduce_dim(tokens)
+            pos = lean_linear(self.pos_embed[2], self.pos_embed[1](lean_linear(self.pos_embed[0], center)))
+        else:
+            group_input_tokens = self.reduce_dim(self.encoder(neighborhood))
+            pos = self.pos_embed(center)
         inter_feats = self.blocks(group_input_tokens, pos)
         if self.at_blocks_backward is not None and inter_feats[-1].requires_grad:
             # look-ahead, timed: the training step's callback (it queues the next batch's coordinate-only work,

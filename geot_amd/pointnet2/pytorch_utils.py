@@ -24,7 +24,8 @@ def conv1x1(conv, x):
     shp = x.shape
     y = pointwise(conv.weight.view(conv.out_channels, -1), x.reshape(shp[0], shp[1], -1))
     if conv.bias is not None:
-        y = y + conv.bias.view(1, -1, 1)
+        from ..fused_norm import add_channel_bias        # (its bias gradient: one fixed-order kernel instead of aten::sum)
+        y = add_channel_bias(y, conv.bias)
     return y.view(shp[0], conv.out_channels, *shp[2:])
 
 

@@ -59,3 +59,35 @@ def capture(graph, device=None, pool=None):
         torch.cuda.Stream.record_event = orig
         kept, _KEPT = _KEPT, None
         del kept[:]
+
+
+# ---- what a captured graph is made of --------------------------------------------------------------------------------------
+NODE_TYPE_NAMES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "waitEvent", 7: "eventRecord",
+                   8: "extSemSignal", 9: "extSemWait", 10: "memAlloc", 11: "memFree", 12: "memcpyFromSymbol",
+                   13: "memcpyToSymbol"}            # hipGraphNodeType
+_hip = None
+
+
+def node_types(graph):
+    """{"kernel": n, "memset": n, ...} of a torch.cuda.CUDAGraph constructed with keep_graph=True (hipGraphGetNodes /
+    hipGraphNodeGetType on its hipGraph_t)."""
+    global _hip
+    import collections
+    import ctypes
+    import os
+    if _hip is None:
+        _hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    raw = ctypes.c_void_p(graph.raw_cuda_graph())
+    n = ctypes.c_size_t(0)
+    if _hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (ctypes.c_void_p * max(n.value, 1))()
+    if _hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    kinds = collections.Counter()
+    for nd in nodes[:n.value]:
+        t = ctypes.c_int(-1)
+        if _hip.hipGraphNodeGetType(ctypes.c_void_p(nd), ctypes.byref(t)) != 0:
+            raise RuntimeError("hipGraphNodeGetType failed")
+        kinds[NODE_TYPE_NAMES.get(t.value, str(t.value))] += 1
+    return dict(kinds)

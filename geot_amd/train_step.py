@@ -158,9 +158,23 @@ class SupervisedStep:
         inner = self.model.module if hasattr(self.model, "module") else self.model
         return inner.prefetch_geometry(pos, inline=True) if hasattr(inner, "prefetch_geometry") else None
 
+    def forward_loss(self, pos, cls, target, geometry=None):
+        """The first half of an iteration: the forward and the loss (with its autograd graph)."""
+        _mode(self.model, True)
+        logits = self.model(pos, pos.transpose(1, 2).contiguous(), cls, geometry=geometry)[0]
+        return self.criterion(logits, target)
+
+    def backward_update(self, loss):
+        """The second half: backward, clipping, the optimizer -> the detached loss."""
+        loss.backward()
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+        return loss.detach()
+
     def iteration(self, pos, cls, target, geometry=None, next_pos=None):
         """One iteration -> (detached loss, the geometry queued for next_pos or None)."""
-        _mode(self.model, True)
         inner = self.model.module if hasattr(self.model, "module") else self.model
         queued = [None]
         queue = None
@@ -170,18 +184,13 @@ class SupervisedStep:
         at_blocks = _lookahead_at_blocks(inner, "blocks")
         if queue is not None and at_blocks:
             inner.at_blocks_backward = queue          # runs inside the backward, when it reaches the transformer blocks
-        logits = self.model(pos, pos.transpose(1, 2).contiguous(), cls, geometry=geometry)[0]
-        loss = self.criterion(logits, target)
+        loss = self.forward_loss(pos, cls, target, geometry)
         if queue is not None and not at_blocks:
             queue()                                   # (GEOT_LOOKAHEAD_AT=forward: right behind the forward)
-        loss.backward()
+        loss = self.backward_update(loss)
         if at_blocks:
             inner.at_blocks_backward = None
-        if self.clip is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
-        self.optimizer.step()
-        self.optimizer.zero_grad(set_to_none=True)
-        return loss.detach(), queued[0]
+        return loss, queued[0]
 
 
 class FixMatchNTMStep:
@@ -332,7 +341,9 @@ class FixMatchNTMStep:
         _mode(self.T_predictor, True)
         data_u = dict(data_u, T=self.ema_t)
         pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
-        pred_l, pred_u_strong = pred_all[:bl], pred_all[bl:bl + bu]
+        # (split, not two slices: its backward is one concatenation kernel; a slice's backward copies the gradient into a zero
+        # tensor with a device-to-device memcpy -- a memcpy node when the iteration is captured)
+        pred_l, pred_u_strong = torch.split(pred_all, [bl, bu, pred_all.shape[0] - bl - bu])[:2]
         if after_forward is not None:
             after_forward()
         pred_u, logits_u_aug, label_u_aug = pseudo
@@ -357,7 +368,7 @@ class FixMatchNTMStep:
         loss.backward()
         if ema_in_place:
             with torch.no_grad():
-                self.ema_t.copy_(ema_next)       # behind everything that read the old one
+                torch.mul(ema_next, 1.0, out=self.ema_t)       # behind everything that read the old one (a kernel, not a memcpy node)
         if cfg["grad_norm_clip"] is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["grad_norm_clip"])
         self.optimizer.step()

@@ -236,6 +236,9 @@ int geot_bn_pool_grad(int b, int c, int groups, int n, const float *y, const flo
 /* out (rows) = the sum of every row, same shape rules: the gradient of a per-group term broadcast over the group's
  * points (Encoder, transformer.py:131-132: feature_global expanded over n) at streaming speed, fixed summation order. */
 int geot_segment_sum(long long rows, int n, const float *x, float *out, void *stream);
+/* out[r] (fp64) = sum of the n floats of row r, fixed order: the long few-row sums (1x1-conv bias gradients over (B, C, N),
+ * per-channel input sums) without the semaphore memset torch's reduction issues (a memset node under capture). */
+int geot_rowsum_f64(long long rows, int n, const float *x, double *out, void *stream);
 /* partial (rows, S, j) = per-slice sums of a[row][.] * b[jj][.] for a (rows, l), b (j, l), j <= 8, S =
  * geot_rowdot_small_slices(rows, l): the weight gradient of a 1x1 convolution with a handful of input channels
  * (Encoder first_conv, transformer.py:110: Conv1d(3, 128) over all points of all groups), one streaming pass. */

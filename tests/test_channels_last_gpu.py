@@ -410,3 +410,29 @@ def test_fixmatch_iterations_are_bit_reproducible():
                      + [trainer.ema_t.clone()]))
     assert torch.equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+
+
+@pytest.mark.parametrize("shape", [(8, 5, 24000), (256, 4096), (3, 17, 1), (1, 1, 100003), (6, 384, 0)])
+def test_rowsum_f64_and_the_bias_gradient_it_feeds(shape):
+    """geot_rowsum_f64 (one workgroup per row, fp64 accumulation, fixed order) against torch's fp64 sum; add_channel_bias's
+    forward is the torch expression bit for bit, its bias gradient the fp64 column sums rounded once -- closer to the fp64
+    truth than aten::sum's fp32 tree, and the same bits on every call."""
+    from geot_amd.fused_norm import rowsum_f64, add_channel_bias
+    torch.manual_seed(3)
+    x = torch.randn(*shape, device=DEV) * 3 + 0.5
+    if x.numel():
+        got = rowsum_f64(x)
+        want = x.double().sum(-1)
+        assert got.dtype == torch.float64 and got.shape == want.shape
+        assert torch.allclose(got, want, rtol=1e-13, atol=1e-10)
+        assert torch.equal(got, rowsum_f64(x))
+    c = shape[-2]
+    bias = torch.randn(c, device=DEV, requires_grad=True)
+    y = x.clone().requires_grad_(True)
+    out = add_channel_bias(y, bias)
+    assert torch.equal(out, y + bias.view(-1, 1))
+    g = torch.randn_like(out)
+    gy, gb = torch.autograd.grad(out, (y, bias), g)
+    assert torch.equal(gy, g)
+    lead = tuple(range(g.dim() - 2)) + (g.dim() - 1,)
+    assert torch.allclose(gb.double(), g.double().sum(lead), rtol=2e-7, atol=1e-30)

@@ -44,8 +44,8 @@ def _same(a, b):
     assert not bad, (len(bad), bad[:8])
 
 
-@pytest.mark.parametrize("look", [True, False])
-def test_supervised_step_from_a_graph_equals_eager(look):
+@pytest.mark.parametrize("look,split", [(True, False), (False, False), (True, True)])
+def test_supervised_step_from_a_graph_equals_eager(look, split):
     from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
     from geot_amd import train_step as ts, graph_step as gs
     batches = _sup_batches(2, 6000)
@@ -57,7 +57,7 @@ def test_supervised_step_from_a_graph_equals_eager(look):
         m = PointTransformer_seg_T(**SMALL).to(DEV)
         m.load_state_dict(init)
         step = ts.SupervisedStep(m)
-        call = gs.GraphedSupervisedStep(step, warmup=2) if mode == "graph" else step
+        call = gs.GraphedSupervisedStep(step, warmup=2, split=split) if mode == "graph" else step
         torch.manual_seed(7)
         losses = []
         for i, k in enumerate(order):
@@ -69,6 +69,8 @@ def test_supervised_step_from_a_graph_equals_eager(look):
         torch.cuda.synchronize()
         if mode == "graph":
             assert call.captured and call.calls == len(order)
+            assert sorted(call.node_types) == (["M1", "M2", "P"] if split else ["M", "P"])
+            assert all(set(v) == {"kernel"} for v in call.node_types.values()), call.node_types     # (see the fast-mode test)
         runs[mode] = (losses, _state(step))
     for i, (a, b) in enumerate(zip(*[runs[m][0] for m in ("eager", "graph")])):
         assert torch.equal(a, b), (i, float(a), float(b))
@@ -105,6 +107,7 @@ def test_fixmatch_iteration_from_a_graph_equals_eager(look):
         torch.cuda.synchronize()
         if mode == "graph":
             assert call.captured
+            assert len(call.node_types) == 2 and all(set(v) == {"kernel"} for v in call.node_types.values()), call.node_types
         runs[mode] = (out, _state(step))
     for i, (a, b) in enumerate(zip(runs["eager"][0], runs["graph"][0])):
         for k in a:
@@ -163,6 +166,23 @@ def test_replays_survive_eager_launches_between_them():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, want) and torch.equal(gb, want_gb)
+
+
+@pytest.mark.parametrize("which", ["supervised", "fixmatch"])
+def test_fast_launch_mode_kernel_only_graphs(which):
+    """GEOT_GRAPH_LAUNCH=fast: packet capture stays ON (a graph launch costs the host 0.5 ms instead of 7-20 ms); what makes
+    that safe is that the captured steps hold kernel nodes only -- verified per graph through hipGraphGetNodes -- and they
+    stay bit-equal to eager with 40 000 eager launches between replays (tests/_fast_graph_check.py, its own process: the
+    switch is read when HIP initialises)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    env["GEOT_GRAPH_LAUNCH"] = "fast"
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "_fast_graph_check.py"), which], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fast ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_a_learning_rate_schedule_reaches_the_replayed_step_through_a_tensor():
