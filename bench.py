@@ -531,12 +531,13 @@ def main():
     # the current stream; P = the batch-only work of the NEXT batch on a side stream beside it; same kernels, same bits:
     # tests/test_graph_step_gpu.py).  Both are timed in every run and both are in the JSON; `value` is the PRIMARY mode, fixed
     # here and not picked after the fact: the replay where it was measured ahead -- the FixMatch+NTM iteration (30.4 against
-    # 31.1 ms: its ~1500 launches keep the eager host on the critical path) and the supervised step at <= 2 clouds (the eager
-    # step is host-bound at 17-18 ms; 10-13 ms replayed) -- the eager step otherwise (4-8 clouds: GPU-bound either way, the
-    # replay 1-7 % behind because its look-ahead graph starts beside the forward's widest GEMMs, profiles/r04_fps_beside.txt).
+    # 31.1 ms: its ~1500 launches keep the eager host on the critical path) and the supervised step at <= 3 clouds (the eager
+    # step is host-bound at 17-19 ms; 10 / 13.5 / 18.6 ms replayed) -- the eager step otherwise (4-8 clouds: GPU-bound either
+    # way; the replay 2 % behind at 4 clouds, level at 8 -- and the dominant kernel's HIP events, which the roofline block
+    # needs from the timed region, can only be recorded on eager launches).
     # --graph / --no-graph force the primary mode (--no-graph also skips the replay leg).
     can_replay = workload in ("model", "fixmatch") and world == 1 and not args.no_graph
-    use_graph = can_replay and (args.graph or workload == "fixmatch" or B <= 2)
+    use_graph = can_replay and (args.graph or workload == "fixmatch" or B <= 3)
     eager_step = step
     graphed = replay_step = None
     if can_replay:
@@ -556,7 +557,7 @@ def main():
                 replay_step()
             assert graphed.captured
             step = replay_step
-            graph_note = "; the iteration replayed from two single-stream hipGraphs (static buffers, batch copied in per step)"
+            graph_note = "; the iteration replayed from single-stream hipGraphs (static buffers, batch copied in per step)"
         except RuntimeError as e:                   # fast launch mode and a graph that is not kernel-only: eager, and say so
             if "only kernel nodes" not in str(e):
                 raise
@@ -653,7 +654,7 @@ def main():
                      "host_cpu_ms_per_step": 1e3 * HOST_ISSUE["cpu_s"] / k_e, "steps": k_e,
                      "note": ("the same iterations, same model state continuing, launched kernel by kernel from the host"
                               if use_graph else
-                              "the same iterations, same model state continuing, replayed from two single-stream hipGraphs "
+                              "the same iterations, same model state continuing, replayed from single-stream hipGraphs "
                               "(geot_amd/graph_step.py)")}
     for u in undo:
         u()
@@ -840,7 +841,7 @@ def main():
                                    ("primary mode = eager: N > 1 runs DistributedDataParallel, whose buckets and collectives are "
                                     "host logic" if world > 1 else
                                     "primary mode = eager" + ("; the hipGraph replay of the same iterations is `replay` (primary for "
-                                                              "the FixMatch iteration and at <= 2 clouds, where the eager "
+                                                              "the FixMatch iteration and at <= 3 clouds, where the eager "
                                                               "step is host-bound)" if can_replay else " (--no-graph)"))}
         if other_leg is not None:
             result["eager" if use_graph else "replay"] = other_leg

@@ -199,12 +199,13 @@ class GraphedSupervisedStep(_Graphed):
     call overwrites: clone it to keep it."""
 
     def __init__(self, step, warmup=2, split=None):
-        """split: capture the iteration as two graphs, M1 = forward + loss and M2 = backward + AdamW (sharing a memory pool),
-        and start P between them -- beside the backward -- instead of beside the forward.  Same bits; measured no faster
-        (8 clouds: 32.81 against 32.73 ms -- what P costs M is its long FPS sharing 8 CUs with the persistent-grid GEMMs,
-        wherever it runs: profiles/r04_fps_beside.txt), so off unless asked for (GEOT_GRAPH_SPLIT=1)."""
+        """split: capture the iteration as two graphs sharing a memory pool -- M1 = forward, loss and the backward of the
+        head and the decoder, M2 = the backward of the transformer blocks and the patch encoder + AdamW (the model cuts its
+        autograd graph between the two: SupervisedStep.forward_backward_head) -- and start P between them: beside the
+        blocks' small GEMMs, where the eager step queues its look-ahead, instead of beside the forward.  Same bits.
+        Default: GEOT_GRAPH_SPLIT (1 / 0), else on."""
         super().__init__(step, warmup)
-        self.split = (os.environ.get("GEOT_GRAPH_SPLIT", "0") == "1") if split is None else bool(split)
+        self.split = (os.environ.get("GEOT_GRAPH_SPLIT", "1") != "0") if split is None else bool(split)
         self.x = None            # static (pos, cls, target)
         self.next_pos = None     # static coordinates P works on
 
@@ -231,7 +232,14 @@ class GraphedSupervisedStep(_Graphed):
         def train():
             return self.step.iteration(self.x[0], self.x[1], self.x[2], self.pre, None)[0]
         if self.split:
-            train = (lambda: self.step.forward_loss(self.x[0], self.x[1], self.x[2], self.pre), self.step.backward_update)
+            def head():
+                self._loss, rest = self.step.forward_backward_head(self.x[0], self.x[1], self.x[2], self.pre)
+                return rest
+
+            def rest_update(rest):
+                self.step.backward_rest_update(rest)
+                return self._loss
+            train = (head, rest_update)
         return self._iterate(announced_now, None if next_pos is None else (next_pos,), load_next, lookahead, train)
 
 

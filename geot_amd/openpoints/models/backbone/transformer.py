@@ -431,6 +431,8 @@ class PointTransformer_seg_T(nn.Module):
         self.overlap = overlap
         self._side = {}
         self.at_blocks_backward = None    # one-shot callback of the training step (set before forward, see _forward)
+        self.cut_at_blocks = False        # detach the decoder from the blocks for a two-phase backward (see _forward, take_cut)
+        self._cut = None
 
         self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
         self.encoder_dims = encoder_dims
@@ -476,6 +478,11 @@ class PointTransformer_seg_T(nn.Module):
             nn.init.xavier_uniform_(m.weight)
             if m.bias is not None:
                 nn.init.constant_(m.bias, 0)
+
+    def take_cut(self):
+        """(the blocks' outputs, their detached copies the decoder consumed) of the last forward under cut_at_blocks, once."""
+        cut, self._cut = self._cut, None
+        return cut
 
     def _side_stream(self, device):
         key = str(device)
@@ -634,6 +641,14 @@ class PointTransformer_seg_T(nn.Module):
                 cb()
                 return grad
             inter_feats[-1].register_hook(run_callback)
+        if self.cut_at_blocks and torch.is_grad_enabled() and inter_feats[-1].requires_grad:
+            # two-phase backward (graph_step's split capture): the decoder works on detached copies of the blocks' outputs;
+            # loss.backward() then stops there with the outputs' gradients, and take_cut() hands back what the second phase
+            # needs -- torch.autograd.backward(outputs, gradients).  The decoder's contribution reaches each output first in
+            # either form, so the sums are the same bits as in one backward.
+            cut_src = list(inter_feats)
+            inter_feats = [t.detach().requires_grad_(True) for t in cut_src]
+            self._cut = (cut_src, inter_feats)
         inter_feats = [self.norm(t).transpose(-1, -2).contiguous() for t in inter_feats]
         cls_label_one_hot = F.one_hot(cls_label, 2).transpose(1, 2).float().repeat(1, 1, N)
 

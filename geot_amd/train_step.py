@@ -173,6 +173,33 @@ class SupervisedStep:
         self.optimizer.zero_grad(set_to_none=True)
         return loss.detach()
 
+    def forward_backward_head(self, pos, cls, target, geometry=None):
+        """The iteration up to the point where the backward reaches the transformer blocks -- forward, loss, the backward of
+        the head and the decoder -- for a model that can cut its autograd graph there (cut_at_blocks / take_cut: the
+        segmentor); otherwise the whole backward.  -> (detached loss, what backward_rest_update needs)."""
+        inner = self.model.module if hasattr(self.model, "module") else self.model
+        can_cut = hasattr(inner, "take_cut")
+        if can_cut:
+            inner.cut_at_blocks = True
+        try:
+            loss = self.forward_loss(pos, cls, target, geometry)
+        finally:
+            if can_cut:
+                inner.cut_at_blocks = False
+        cut = inner.take_cut() if can_cut else None
+        loss.backward()
+        rest = None if cut is None else (cut[0], [d.grad for d in cut[1]])
+        return loss.detach(), rest
+
+    def backward_rest_update(self, rest):
+        """The rest of the backward (the blocks, the patch encoder), clipping, the optimizer."""
+        if rest is not None:
+            torch.autograd.backward(rest[0], rest[1])
+        if self.clip is not None:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=True)
+
     def iteration(self, pos, cls, target, geometry=None, next_pos=None):
         """One iteration -> (detached loss, the geometry queued for next_pos or None)."""
         inner = self.model.module if hasattr(self.model, "module") else self.model
