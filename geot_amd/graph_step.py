@@ -202,10 +202,14 @@ class GraphedSupervisedStep(_Graphed):
         """split: capture the iteration as two graphs sharing a memory pool -- M1 = forward, loss and the backward of the
         head and the decoder, M2 = the backward of the transformer blocks and the patch encoder + AdamW (the model cuts its
         autograd graph between the two: SupervisedStep.forward_backward_head) -- and start P between them: beside the
-        blocks' small GEMMs, where the eager step queues its look-ahead, instead of beside the forward.  Same bits.
-        Default: GEOT_GRAPH_SPLIT (1 / 0), else on."""
+        blocks' small GEMMs, where the eager step queues its look-ahead, instead of beside the forward.  Same bits.  It pays
+        when what follows the cut outlasts P (~6.3 ms whatever the batch: its FPS runs one cloud per CU): at 8 clouds the
+        replay goes from 0.45 ms behind the eager step to level, at 4 clouds 21.95 -> 21.08 ms, at 3 19.37 -> 18.59; at 1 / 2
+        clouds M2 is shorter than P and the step waits for it (10.1 -> 12.4, 13.6 -> 15.2 ms).  Default (None):
+        GEOT_GRAPH_SPLIT=1 / 0 if set, else split batches of at least 3 clouds."""
         super().__init__(step, warmup)
-        self.split = (os.environ.get("GEOT_GRAPH_SPLIT", "1") != "0") if split is None else bool(split)
+        env = os.environ.get("GEOT_GRAPH_SPLIT")
+        self.split = bool(split) if split is not None else (None if env is None else env == "1")
         self.x = None            # static (pos, cls, target)
         self.next_pos = None     # static coordinates P works on
 
@@ -214,6 +218,8 @@ class GraphedSupervisedStep(_Graphed):
             self.device = pos.device
             self.x = (pos.detach().clone().contiguous(), cls.detach().clone(), target.detach().clone())
             self.next_pos = torch.empty_like(self.x[0])
+            if self.split is None:
+                self.split = pos.shape[0] >= 3
         for dst, src, name in zip(self.x, (pos, cls, target), ("pos", "cls", "target")):
             _fits(dst, src, name)
         if next_pos is not None:
