@@ -47,6 +47,9 @@ from geot_amd import train_step as ts, graph_step as gs
 from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T, TOOTH_SEG_CFG
 from geot_amd.pointops.functions import pointops as pops
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+if os.environ.get("TUNED", "1") == "1":        # the GEMM selection bench.py runs with (geot_amd/tuning)
+    from geot_amd import tuning
+    tuning.enable()
 torch.manual_seed(0)
 m = PointTransformer_seg_T(**TOOTH_SEG_CFG).to(DEV)
 step = ts.SupervisedStep(m)

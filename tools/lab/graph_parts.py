@@ -10,6 +10,11 @@ from test_graph_step_gpu import _sup_batches, DEV
 from geot_amd import train_step as ts, graph_step as gs
 from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T, TOOTH_SEG_CFG
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+if os.environ.get("BLAS"):                      # BLAS=cublas (= rocBLAS) | cublaslt (= hipBLASLt), with TUNED=0
+    print("preferred blas:", torch.backends.cuda.preferred_blas_library(os.environ["BLAS"]))
+if os.environ.get("TUNED", "1") == "1":        # the GEMM selection bench.py runs with (geot_amd/tuning)
+    from geot_amd import tuning
+    print("TunableOp file:", tuning.enable())
 torch.manual_seed(0)
 m = PointTransformer_seg_T(**TOOTH_SEG_CFG).to(DEV)
 step = ts.SupervisedStep(m)
