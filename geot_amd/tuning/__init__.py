@@ -7,6 +7,14 @@ remembers the fastest; ``tunableop_gfx950.csv`` holds that choice for the shapes
 HIP, rocBLAS, hipBLASLt and ``gfx950``: on any other stack TunableOp ignores the file and the default solutions run).
 Same fp32 arithmetic, different tiling: 45.0 -> 41.0 ms per configs[2] step.
 
+"Fastest" is measured alone on the chip -- ``tunableop_gfx950_alone.csv`` -- and for most shapes that is a launch of exactly 256
+workgroups, one per CU, which waits for its slowest workgroup: beside the look-ahead's 8192-sample FPS (8 CUs, 4.7 ms) such a
+launch takes 50-85 % longer (profiles/r04_fps_beside.txt).  The default file therefore holds, for the 25 shapes of the second half
+of the 8-cloud supervised iteration (backward of the transformer blocks and the patch encoder: what the look-ahead runs beside),
+the solution that is fastest WITH such an FPS running on a side stream (tools/tune_lookahead_gemms.py; 21 of the 25 differ),
+and the `alone` choice for everything else: 32.4 -> 31.7 ms per step with look-ahead (34.8 -> 35.2 without it;
+profiles/r04_gemm_selection_beside_fps.txt).  GEOT_TUNABLEOP_FILE=<path> selects another file (A/B runs).
+
 ``enable()`` switches TunableOp on with these results and tuning OFF (no timing runs at start-up; unknown shapes use the
 library default); ``enable(tune=True, path=...)`` records a new file (minutes)."""
 import os
@@ -21,7 +29,7 @@ def enable(tune=False, path=None):
         import torch.cuda.tunable as tunable
     except ImportError:
         return None
-    path = path or DEFAULT
+    path = path or os.environ.get("GEOT_TUNABLEOP_FILE") or DEFAULT      # (the env: A/B runs against another selection)
     work = path
     if not tune:
         # TunableOp owns the file it is pointed at (it may rewrite it): every process works on a private copy, so N

@@ -40,6 +40,7 @@ if sys.argv[1] == "report":
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("GEOT_GRAPH_LAUNCH", "fast"); os.environ.setdefault("GEOT_GRAPH_SPLIT", "0")
+
 import geot_amd
 import torch
 from test_graph_step_gpu import _sup_batches, DEV
@@ -49,7 +50,7 @@ from geot_amd.pointops.functions import pointops as pops
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 if os.environ.get("TUNED", "1") == "1":        # the GEMM selection bench.py runs with (geot_amd/tuning)
     from geot_amd import tuning
-    tuning.enable()
+    tuning.enable(path=os.environ.get("TUNE_FILE"))
 torch.manual_seed(0)
 m = PointTransformer_seg_T(**TOOTH_SEG_CFG).to(DEV)
 step = ts.SupervisedStep(m)
@@ -65,16 +66,29 @@ with torch.cuda.stream(s2):
 torch.cuda.current_stream().wait_stream(s2); torch.cuda.synchronize()
 with torch.cuda.graph(gf):
     idx = pops.furthestsampling_uniform(xyz, B, 24000, 8192)
-M = call.graphs["M"][0]
 side = torch.cuda.Stream()
 torch.cuda.synchronize()
-for _ in range(6):
-    M.replay()
-torch.cuda.synchronize()
-for _ in range(6):
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        gf.replay()
-    M.replay()
-    torch.cuda.current_stream().wait_stream(side)
+if "M" in call.graphs:                     # unsplit: the FPS graph beside the whole of M
+    M = call.graphs["M"][0]
+    for _ in range(6):
+        M.replay()
+    torch.cuda.synchronize()
+    for _ in range(6):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gf.replay()
+        M.replay()
+        torch.cuda.current_stream().wait_stream(side)
+else:                                      # split (GEOT_GRAPH_SPLIT=1): the FPS graph starts behind M1, beside M2
+    M1, M2 = call.graphs["M1"][0], call.graphs["M2"][0]
+    for _ in range(6):
+        M1.replay(); M2.replay()
+    torch.cuda.synchronize()
+    for _ in range(6):
+        M1.replay()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gf.replay()
+        M2.replay()
+        torch.cuda.current_stream().wait_stream(side)
 torch.cuda.synchronize()

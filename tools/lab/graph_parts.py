@@ -14,7 +14,7 @@ if os.environ.get("BLAS"):                      # BLAS=cublas (= rocBLAS) | cubl
     print("preferred blas:", torch.backends.cuda.preferred_blas_library(os.environ["BLAS"]))
 if os.environ.get("TUNED", "1") == "1":        # the GEMM selection bench.py runs with (geot_amd/tuning)
     from geot_amd import tuning
-    print("TunableOp file:", tuning.enable())
+    print("TunableOp file:", tuning.enable(path=os.environ.get("TUNE_FILE")))
 torch.manual_seed(0)
 m = PointTransformer_seg_T(**TOOTH_SEG_CFG).to(DEV)
 step = ts.SupervisedStep(m)
