@@ -577,15 +577,17 @@ class PointTransformer_seg_T(nn.Module):
                 # FPS launch itself takes 5.6 instead of 4.7 ms, but nothing waits for it
                 pointops.fps_indices(pts, max(self.downsample_targets))
                 plan = self._index_plan(pts, group[1])
+            ready = streams.event()          # everything above is done: what a consumer OTHER than this model waits for
+            ready.record(side)               # (this model's own forward waits for its side stream; slice_geometry's user cannot)
         return {"pts": pts, "version": pts._version, "group": group, "grouped": grouped, "plan": plan,
-                "training": self.training, "fp_layout": self.fp_layout}
+                "training": self.training, "fp_layout": self.fp_layout, "ready": ready}
 
     def _forward(self, pts, x, cls_label, T, geometry=None):
         B, N, _ = pts.shape
         pts = pts.contiguous()
         side = self._side_stream(pts.device) if (self.overlap and pts.is_cuda and streams.may_fork(pts.device)) else None
         top = max(self.downsample_targets)
-        plan = None
+        plan = ready = None
         forked = False                    # has this forward queued work on the side stream (and must wait for it)?
         if (geometry is not None and geometry["training"] == self.training and geometry["fp_layout"] == self.fp_layout
                 and (geometry.get("static") or (side is not None and geometry["pts"] is pts and geometry["version"] == pts._version))):
@@ -595,6 +597,7 @@ class PointTransformer_seg_T(nn.Module):
             main = torch.cuda.current_stream(pts.device)
             if geometry.get("grouped") is not None:
                 main.wait_event(geometry["grouped"])
+            ready = geometry.get("ready")
             forked = not geometry.get("static")   # a queued geometry's plan is still on the side stream; a static one is memory
             neighborhood, center, idx = geometry["group"]
             plan = geometry["plan"]
@@ -660,6 +663,8 @@ class PointTransformer_seg_T(nn.Module):
             "the length of the cardinality and the features should be the same"
         if forked:
             main.wait_stream(side)
+            if ready is not None:         # a geometry queued by ANOTHER model (slice_geometry): its producer's stream, not ours
+                main.wait_event(ready)
         if plan is not None:
             center_pts, center_pts_trans = plan["center_pts"], plan["center_pts_trans"]
         else:
@@ -686,6 +691,40 @@ class PointTransformer_seg_T(nn.Module):
             logit = head[3](head[2](bn_act(head[1], head[0](f_l0), relu=False)))
         correction = self.T_linear(T) if T is not None else None
         return logit, correction, self.sigma, f_l0
+
+
+def slice_geometry(geometry, lo, hi):
+    """The geometry (prefetch_geometry's result) of clouds [lo, hi) of the batch `geometry` describes, for a model in EVAL
+    mode: every entry is per cloud -- sample ids, neighbour ids and Morton orders are cloud-local -- so the slices are exactly
+    what prefetch_geometry(pts[lo:hi]) of an eval-mode model would compute; the training-only entries (the reverse indices of
+    the gradients) are dropped.  FixMatch's frozen teacher sees the weak view, which is also the last third of the student's
+    batch: its geometry -- an 8192-sample FPS, Group, the index plan -- need not be computed twice."""
+    if geometry is None or geometry.get("plan") is None:
+        return None
+    pts = geometry["pts"]
+    b, n = pts.shape[0], pts.shape[1]
+    neighborhood, center, idx = geometry["group"]
+    flat = None if idx is None else (idx.view(b, -1)[lo:hi] - lo * n).reshape(-1)
+    plan = geometry["plan"]
+
+    def cut(t):
+        return None if t is None else t[lo:hi]
+
+    def fp(entry):                   # (idx, weight) or (idx, weight, Morton order, reverse index)
+        return tuple(cut(t) for t in entry[:3]) + ((None,) if len(entry) > 3 else ())
+
+    def graph(entry):                # ids, or (ids, reverse index) in training
+        return cut(entry[0] if isinstance(entry, tuple) else entry)
+    new_plan = {"center_pts": [cut(t) for t in plan["center_pts"]], "center_pts_trans": [cut(t) for t in plan["center_pts_trans"]],
+                "center_trans": cut(plan["center_trans"]), "fp2": fp(plan["fp2"]), "fp1": fp(plan["fp1"]), "fp0": fp(plan["fp0"]),
+                "dg2": tuple(graph(e) for e in plan["dg2"]), "dg1": tuple(graph(e) for e in plan["dg1"])}
+    out = {"pts": pts[lo:hi], "version": geometry["version"], "group": (neighborhood[lo:hi], center[lo:hi], flat),
+           "grouped": geometry.get("grouped"), "plan": new_plan, "training": False, "fp_layout": geometry["fp_layout"]}
+    if geometry.get("static"):
+        out["static"] = True
+    if geometry.get("ready") is not None:
+        out["ready"] = geometry["ready"]
+    return out
 
 
 TOOTH_SEG_CFG = dict(trans_dim=384, depth=12, num_heads=4, group_size=32, num_group=512, encoder_dims=256,

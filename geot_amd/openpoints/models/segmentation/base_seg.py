@@ -61,6 +61,20 @@ class WholePartSeg(nn.Module):
             g["src"] = tuple((t, t._version) for t in self._position_views(p0, u0, if_teacher, fixmatch))
         return g
 
+    @classmethod
+    def weak_view_geometry(cls, geometry, p0, u0):
+        """From the geometry of a fixmatch=True batch (labelled + strong + weak views of p0 / u0) the geometry a frozen,
+        eval-mode teacher's forward(u0, if_teacher=True) takes: the weak view's slice (slice_geometry) -- the same sampling,
+        grouping and index work, not done twice.  None when there is nothing to slice."""
+        from ..backbone.transformer import slice_geometry
+        if geometry is None:
+            return None
+        lo = p0["pos"].shape[0] + u0["pos_s"].shape[0]
+        g = slice_geometry(geometry, lo, lo + u0["pos_w"].shape[0])
+        if g is not None and not g.get("static"):
+            g["src"] = tuple((t, t._version) for t in cls._position_views(u0, if_teacher=True))
+        return g
+
     def forward(self, p0, f0=None, cls0=None, u0=None, if_teacher=False, fixmatch=False, geometry=None):
         if geometry is not None and not geometry.get("static"):
             # a geometry describes the tensors it was computed from and nothing else: the same objects, not edited since

@@ -243,6 +243,7 @@ class FixMatchNTMStep:
         self._teacher_stream = None
         # the frozen teacher's forward on its own stream beside the student's (same results; GEOT_TEACHER_STREAM=0: in line)
         self.overlap_teacher = os.environ.get("GEOT_TEACHER_STREAM", "1") != "0"
+        self.share_weak_geometry = os.environ.get("GEOT_SHARE_WEAK_GEOMETRY", "1") != "0"
 
     def optimizers(self):
         return [self.optimizer, self.T_optimizer]
@@ -272,6 +273,15 @@ class FixMatchNTMStep:
             logits_u_aug, label_u_aug = torch.max(pred_u, dim=1)
         return pred_u, logits_u_aug, label_u_aug
 
+    def _teacher_geometry(self, inner, geom_s, data, data_u, inline=False):
+        """The teacher's geometry: the weak view is the last third of the student's batch, so its sampling / grouping / index
+        work is a slice of the student's (WholePartSeg.weak_view_geometry; the teacher's own 8192-sample FPS was 4.7 ms on two
+        CUs beside the student's); computed on its own only when there is nothing to slice (GEOT_SHARE_WEAK_GEOMETRY=0: always)."""
+        g = None
+        if self.share_weak_geometry and hasattr(inner, "weak_view_geometry"):
+            g = inner.weak_view_geometry(geom_s, data, data_u)
+        return g if g is not None else self.model_t.prefetch_geometry(data_u, if_teacher=True, inline=inline)
+
     def lookahead_work(self, data, data_u):
         """Everything of an iteration that depends on its batches and on FROZEN state alone, on the CURRENT stream: the
         student's and the teacher's geometry, the teacher's forward -> pseudo labels (the teacher is never updated:
@@ -284,7 +294,7 @@ class FixMatchNTMStep:
         with torch.no_grad():
             geom_s = inner.prefetch_geometry(data, data_u, fixmatch=True, inline=True)
             _mode(self.model_t, False)
-            geom_t = self.model_t.prefetch_geometry(data_u, if_teacher=True, inline=True)
+            geom_t = self._teacher_geometry(inner, geom_s, data, data_u, inline=True)
             raw = data_u["raw_pos"].contiguous()
             nbr = self.threed_loss.neighbours(raw)
             order = ntm_mod.spatial_order(raw)
@@ -328,7 +338,8 @@ class FixMatchNTMStep:
 
             def queue():
                 _mode(self.model_t, False)
-                queued[0] = (inner.prefetch_geometry(nd, nu, fixmatch=True), self.model_t.prefetch_geometry(nu, if_teacher=True))
+                g_s = inner.prefetch_geometry(nd, nu, fixmatch=True)
+                queued[0] = (g_s, self._teacher_geometry(inner, g_s, nd, nu))
         at_blocks = _lookahead_at_blocks(inner.segmentor, "forward")
         if queue is not None and at_blocks:
             inner.segmentor.at_blocks_backward = queue      # runs when the student's backward reaches the transformer blocks

@@ -702,8 +702,18 @@ def test_fixmatch_look_ahead_changes_nothing_but_the_schedule():
                 a = step.model(d, u0=dict(u, T=step.ema_t), fixmatch=True, geometry=g_s)[0]
                 b = step.model(d, u0=dict(u, T=step.ema_t), fixmatch=True)[0]
                 step.model_t.eval()
+                # the teacher's geometry is the weak view's slice of the student's (slice_geometry), and the teacher takes it:
+                # no Group, no index plan of its own
+                assert g_t["pts"].data_ptr() == g_s["pts"][4:].data_ptr() and g_t["training"] is False
+                seg_t, calls = step.model_t.segmentor, []
+                plan0, group0 = seg_t._index_plan, seg_t.group_divider.forward
+                seg_t._index_plan = lambda *a, **k: (calls.append("plan"), plan0(*a, **k))[1]
+                seg_t.group_divider.forward = lambda *a, **k: (calls.append("group"), group0(*a, **k))[1]
                 ta = step.model_t(u, if_teacher=True, geometry=g_t)[0]
+                assert calls == [], calls
                 tb = step.model_t(u, if_teacher=True)[0]
+                assert sorted(calls) == ["group", "plan"]
+                seg_t._index_plan, seg_t.group_divider.forward = plan0, group0
             assert torch.equal(ta, tb)
             assert torch.equal(a, b)
             # an iteration on batches that were NOT announced ignores the geometry
