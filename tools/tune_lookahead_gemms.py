@@ -8,7 +8,10 @@ the second half of the supervised iteration -- the backward of the transformer b
 the look-ahead runs beside (SupervisedStep.backward_rest_update) -- WHILE such an FPS runs on a side stream, and writes the
 merged selection:  the `alone` entry for every other shape, the entry tuned under contention for these.
 
-    python tools/tune_lookahead_gemms.py out.csv [clouds=8]      (GPU box; ~5 min)
+    python tools/tune_lookahead_gemms.py out.csv [clouds=8]      (GPU box; ~1 min)
+    python tools/tune_lookahead_gemms.py out.csv fixmatch        the FixMatch+NTM iteration (2 + 2 clouds): replayed, its look-ahead
+                                                                 graph runs beside the STUDENT'S FORWARD -- those shapes are re-tuned
+The merge starts from GEOT_TUNE_BASE (default: the `alone` file), so two runs can be chained.
 """
 import os
 import sys
@@ -44,18 +47,42 @@ def entries(path):
 
 def main():
     out = sys.argv[1]
-    b = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    fixmatch = len(sys.argv) > 2 and sys.argv[2] == "fixmatch"
+    b = 6 if fixmatch else (int(sys.argv[2]) if len(sys.argv) > 2 else 8)
     dev = torch.device("cuda:0")
     xyz = make_batch(b, 24000)[0]
     pos = torch.from_numpy(xyz).to(dev)
-    cls = torch.zeros(b, 1, dtype=torch.long, device=dev)
-    target = torch.from_numpy(region_labels(xyz)).to(dev)
     work = tempfile.mkstemp(prefix="geot_tune_", suffix=".csv")[1]
     os.remove(work)                                   # an empty selection: every shape met while tuning is on gets tuned
     tuning.enable(tune=True, path=work)
     tunable.tuning_enable(False)
     torch.manual_seed(0)
-    step = ts.SupervisedStep(PointTransformer_seg_T(**TOOTH_SEG_CFG).to(dev))
+    if fixmatch:
+        import numpy as np
+        step = ts.build_fixmatch(dev, use_ddp=False)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+        lab, unl, strong = T(xyz[:2]), T(xyz[2:4]), T(xyz[2:4] * np.float32(1.04))
+        z = torch.zeros(2, 1, dtype=torch.long, device=dev)
+        data = {"pos": lab, "x": lab.transpose(1, 2).contiguous(), "cls": z, "y": T(region_labels(xyz[:2]))}
+        data_u = {"pos_w": unl, "x_w": unl.transpose(1, 2).contiguous(), "cls_w": z, "pos_s": strong,
+                  "x_s": strong.transpose(1, 2).contiguous(), "cls_s": z, "raw_pos": unl}
+
+        def iteration():
+            pre = step.lookahead_work(data, data_u)                         # selection off: nothing recorded
+            torch.cuda.synchronize()
+            tunable.tuning_enable(True)                                     # the student's forward is tuned beside the FPS ...
+            step.student_iteration(data, data_u, pre["geom_s"], pre["pseudo"], pre["knn"],
+                                   after_forward=lambda: tunable.tuning_enable(False))      # ... and nothing behind it
+    else:
+        cls = torch.zeros(b, 1, dtype=torch.long, device=dev)
+        target = torch.from_numpy(region_labels(xyz)).to(dev)
+        step = ts.SupervisedStep(PointTransformer_seg_T(**TOOTH_SEG_CFG).to(dev))
+
+        def iteration():
+            loss, rest = step.forward_backward_head(pos, cls, target)      # selection off: library defaults, nothing recorded
+            torch.cuda.synchronize()
+            tunable.tuning_enable(True)
+            step.backward_rest_update(rest)                                 # every shape in here is tuned beside the FPS
     flat = pos.reshape(-1, 3).contiguous()
     stop, launched = threading.Event(), [0]
 
@@ -71,10 +98,7 @@ def main():
     th.start()
     t0 = time.time()
     for i in range(2):
-        loss, rest = step.forward_backward_head(pos, cls, target)      # selection off: library defaults, nothing recorded
-        torch.cuda.synchronize()
-        tunable.tuning_enable(True)
-        step.backward_rest_update(rest)                                 # every shape in here is tuned beside the FPS
+        iteration()
         torch.cuda.synchronize()
         tunable.tuning_enable(False)
         print("iteration %d: %.0f s, %d FPS launches beside" % (i, time.time() - t0, launched[0]), flush=True)
@@ -83,7 +107,7 @@ def main():
     results = tunable.get_results()                   # ((op signature, parameters, solution, time), ...): this process's tuning
     del step
     torch.cuda.synchronize()
-    head, alone = entries(ALONE)
+    head, alone = entries(os.environ.get("GEOT_TUNE_BASE", ALONE))
     beside = {(r[0], r[1]): "%s,%s,%s,%s\n" % (r[0], r[1], r[2], r[3]) for r in results}
     if not beside:
         raise SystemExit("TunableOp wrote no results to %s" % work)
