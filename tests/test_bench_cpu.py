@@ -110,3 +110,31 @@ def test_recorded_gemm_selection_is_a_wellformed_tunableop_file():
     entries = [l.split(",") for l in lines if l.startswith("GemmTunableOp") or "TunableOp_float" in l.split(",")[0]]
     assert len(entries) > 50 and all(len(e) >= 3 for e in entries)
     assert all("float" in e[0] for e in entries)              # fp32 GEMMs only: the selection never changes precision
+
+
+def test_lookahead_gemm_selection_differs_from_the_alone_file_only_where_it_was_retuned():
+    """geot_amd/tuning: the default selection = the `alone` file (every shape's fastest solution alone on the chip) with the
+    shapes that run beside the look-ahead re-tuned under that contention (tools/tune_lookahead_gemms.py): same validators, the
+    same shapes (+ at most a few new ones), a different solution for a few dozen 8-cloud shapes of the blocks' / encoder's
+    backward and for nothing else."""
+    import os
+    from geot_amd import tuning
+
+    def load(path):
+        head, rows = [], {}
+        for line in open(path).read().strip().splitlines():
+            p = line.split(",")
+            if p[0] == "Validator":
+                head.append(line)
+            else:
+                rows[(p[0], p[1])] = p[2]
+        return head, rows
+    alone_path = os.path.join(os.path.dirname(tuning.DEFAULT), "tunableop_gfx950_alone.csv")
+    h0, alone = load(alone_path)
+    h1, cur = load(tuning.DEFAULT)
+    assert h0 == h1
+    assert set(alone) <= set(cur) and len(set(cur) - set(alone)) <= 4
+    changed = [k for k in alone if alone[k] != cur[k]]
+    assert 10 <= len(changed) <= 40
+    # 8-cloud supervised shapes only: 4096 tokens (8 x 512 groups) or 131072 group points (8 x 512 x 32) in the parameters
+    assert all(any(tok in k[1].split("_") for tok in ("4096", "131072")) or "_B_32_" in k[1] for k in changed), changed
