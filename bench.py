@@ -736,6 +736,23 @@ def main():
                               "note": "sum of HIP-event durations around every C-ABI launch in 2 extra untimed steps; the "
                                       "8192-point FPS runs on a side stream beside the encoder, so shares are of GPU work, "
                                       "not of wall time"}
+        # the step's largest HBM-bound hand-written kernel: the point-major interpolation + BatchNorm gradient of the three FP
+        # stages (gather_rows_csr_bn_cl: rows of 4 C bytes; reads y and dz of the n unknown points, writes the m known ones)
+        gr_ms = att.get("geot_gather_rows_csr_bn_cl")
+        if gr_ms:
+            c_fp = 4 * TOOTH_SEG_CFG["trans_dim"]
+            tg = TOOTH_SEG_CFG["downsample_targets"]
+            stages = [(N_POINTS, tg[0]), (tg[0], TOOTH_SEG_CFG["num_group"]), (tg[1], TOOTH_SEG_CFG["num_group"])]   # (n, m) of prop0 / 1 / 2
+            gr_bytes = sum(4.0 * B * c_fp * (2 * n_ + m_) for n_, m_ in stages)
+            t3, s3 = pmc_traffic("gather_rows_csr_bn_cl_kernel", tag) if B == default_b else (None, None)
+            result["roofline_hbm"] = {
+                "kernel": "gather_rows_csr_bn_cl_kernel (3 launches per step: FP stages 24000<-8192, 8192<-512, 4096<-512 at C = %d)" % c_fp,
+                "bound": "hbm", "achieved": gr_bytes / (gr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gr_bytes / (gr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t3, "traffic_source": s3,
+                "algorithmic_bytes_per_launch": gr_bytes / 3, "avg_launch_ms": gr_ms / 3,
+                "note": "algorithmic bytes = 4 C B (2 n + m) per stage (y and dz rows in, gradient rows out; the index is < 1 %); "
+                        "HIP events around the three C-ABI launches of 2 extra eager steps (hot_path); traffic = PMC bytes per "
+                        "launch averaged over the three stages"}
         f_ms = att.get("geot_furthestsampling_offset", float("nan"))
         k_ms = att.get("geot_knn_sorted_ws", float("nan"))
         result["micro"] = {"fps_24000_to_8192_Mpoints_per_s": B * N_POINTS / (fps_ms * 1e-3) / 1e6,
