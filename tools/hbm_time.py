@@ -59,42 +59,45 @@ cases = {
     "correct_logits bwd": (lambda: call("geot_ntm_correct_grad_ws", xyz.device, B, N, C, 0.9, ptr(logits), ptr(insT), ptr(cm), ptr(gout),
                                         ptr(gl), ptr(gI), ptr(gE), ptr(ws_cor)), 4 * B * N * (17 * 3 + 2 * 289)),
 }
+NU, MK = int(os.environ.get("NU", N)), int(os.environ.get("MK", "8192"))   # point-major cases: NU unknown <- MK known points
 if CI >= 256 and CI % 4 == 0:
     # the point-major FP stage (csrc/channels_last.hip, profiles/DESIGN_r01_r03.md 4.11) at the same shape: 24000 <- 8192, CI channels
     from geot_amd import fused_norm as fnm
     lib = _lib.load()
     CS = 5
-    w3 = p2.fp_weights(p2.three_nn(xyz, known)[0])
-    a_cl = torch.randn(B, 8192, CI, device=DEV)
-    skip = torch.randn(B, CS, N, device=DEV)
+    unk, kn = xyz[:, :NU].contiguous(), xyz[:, :MK].contiguous()
+    d3, i3c = p2.three_nn(unk, kn)
+    w3 = p2.fp_weights(d3)
+    a_cl = torch.randn(B, MK, CI, device=DEV)
+    skip = torch.randn(B, CS, NU, device=DEV)
     wb = torch.randn(CI, CS, device=DEV)
-    order_u, order_k = fnm.local_spatial_order(xyz), fnm.local_spatial_order(known)
-    tiles = int(lib.geot_fp_front_cl_tiles(B, CI, N, CS))
-    y_cl = torch.empty(B, N, CI, device=DEV)
+    order_u, order_k = fnm.local_spatial_order(unk), fnm.local_spatial_order(kn)
+    tiles = int(lib.geot_fp_front_cl_tiles(B, CI, NU, CS))
+    y_cl = torch.empty(B, NU, CI, device=DEV)
     part = torch.empty(int(lib.geot_cl_stat_floats(tiles, CI)), device=DEV)
-    dz_cl = torch.randn(B, N, CI, device=DEV)
-    rix = fnm.ReverseIndex(i3, w3, 8192, order_k)
-    ga_cl = torch.empty(B, 8192, CI, device=DEV)
+    dz_cl = torch.randn(B, NU, CI, device=DEV)
+    rix = fnm.ReverseIndex(i3c, w3, MK, order_k)
+    ga_cl = torch.empty(B, MK, CI, device=DEV)
     sc, sh, mu, rs, c1, c2 = (torch.rand(CI, device=DEV) + 0.5 for _ in range(6))
     sh = sh - 1.0
-    tl = int(lib.geot_cl_tiles(1, B * N, CI))
+    tl = int(lib.geot_cl_tiles(1, B * NU, CI))
     pk = torch.empty(tl, 2 + 2 * CS, CI, device=DEV)
     z_cl = torch.empty_like(y_cl)
-    call("geot_fp_front_cl", xyz.device, B, CI, 8192, N, CS, ptr(a_cl), ptr(i3), ptr(w3), ptr(skip), ptr(wb), ptr(order_u), ptr(y_cl), ptr(part))
+    call("geot_fp_front_cl", xyz.device, B, CI, MK, NU, CS, ptr(a_cl), ptr(i3c), ptr(w3), ptr(skip), ptr(wb), ptr(order_u), ptr(y_cl), ptr(part))
     row = 4 * B * CI
     cases.update({
-        "fp_front_cl (Morton) C=%d" % CI: (lambda: call("geot_fp_front_cl", xyz.device, B, CI, 8192, N, CS, ptr(a_cl), ptr(i3),
+        "fp_front_cl (Morton) C=%d" % CI: (lambda: call("geot_fp_front_cl", xyz.device, B, CI, MK, NU, CS, ptr(a_cl), ptr(i3c),
                                                         ptr(w3), ptr(skip), ptr(wb), ptr(order_u), ptr(y_cl), ptr(part)),
-                                           row * (N + 8192) + 4 * B * CS * N + 24 * B * N),
-        "bn_apply_cl C=%d" % CI: (lambda: call("geot_bn_apply_cl", xyz.device, B * N, CI, 1, ptr(y_cl), ptr(sc), ptr(sh), ptr(z_cl)), 2 * row * N),
-        "bn_bwd_reduce_skip_cl C=%d" % CI: (lambda: call("geot_bn_bwd_reduce_skip_cl", xyz.device, B, N, CI, CS, 1, ptr(y_cl), ptr(dz_cl), ptr(sc),
-                                                         ptr(sh), ptr(mu), ptr(rs), ptr(skip), ptr(pk)), 2 * row * N),
-        "gather_rows_csr_cl C=%d" % CI: (lambda: call("geot_gather_rows_csr_cl", xyz.device, B, CI, N, 8192, 3, ptr(dz_cl),
-                                                      ptr(rix.ws), ptr(order_k), ptr(ga_cl)), row * (N + 8192)),
-        "gather_rows_csr_bn_cl C=%d" % CI: (lambda: call("geot_gather_rows_csr_bn_cl", xyz.device, B, CI, N, 8192, 3, 1,
+                                           row * (NU + MK) + 4 * B * CS * NU + 24 * B * NU),
+        "bn_apply_cl C=%d" % CI: (lambda: call("geot_bn_apply_cl", xyz.device, B * NU, CI, 1, ptr(y_cl), ptr(sc), ptr(sh), ptr(z_cl)), 2 * row * NU),
+        "bn_bwd_reduce_skip_cl C=%d" % CI: (lambda: call("geot_bn_bwd_reduce_skip_cl", xyz.device, B, NU, CI, CS, 1, ptr(y_cl), ptr(dz_cl), ptr(sc),
+                                                         ptr(sh), ptr(mu), ptr(rs), ptr(skip), ptr(pk)), 2 * row * NU),
+        "gather_rows_csr_cl C=%d" % CI: (lambda: call("geot_gather_rows_csr_cl", xyz.device, B, CI, NU, MK, 3, ptr(dz_cl),
+                                                      ptr(rix.ws), ptr(order_k), ptr(ga_cl)), row * (NU + MK)),
+        "gather_rows_csr_bn_cl C=%d" % CI: (lambda: call("geot_gather_rows_csr_bn_cl", xyz.device, B, CI, NU, MK, 3, 1,
                                                          ptr(y_cl), ptr(dz_cl), ptr(sc), ptr(sh), ptr(mu), ptr(rs), ptr(c1),
                                                          ptr(c2), ptr(rix.ws), ptr(order_k), ptr(ga_cl)),
-                                            row * (2 * N + 8192)),
+                                            row * (2 * NU + MK)),
     })
 only = os.environ.get("ONLY")
 with torch.no_grad():
