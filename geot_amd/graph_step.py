@@ -255,8 +255,12 @@ _P_KEYS = (("pos",), ("pos_s", "pos_w", "x_w", "cls_w", "raw_pos"))      # what 
 class GraphedFixMatchStep(_Graphed):
     """FixMatchNTMStep.__call__ from hipGraphs.  The returned losses are static tensors the next call overwrites."""
 
-    def __init__(self, step, warmup=2):
+    def __init__(self, step, warmup=2, split=None):
+        """split: as GraphedSupervisedStep -- M1 ends where the backward reaches the student's transformer blocks, P starts
+        there.  Same bits, but a loss here: P is 10 ms (the teacher's forward is in it) and does not fit beside M2 -- 29.0 ->
+        30.4 ms per iteration (bench.py --workload fixmatch, alternating).  Off unless split=True / GEOT_GRAPH_SPLIT=1."""
         super().__init__(step, warmup)
+        self.split = bool(split) if split is not None else os.environ.get("GEOT_GRAPH_SPLIT") == "1"
         self.data = self.data_u = None       # static batch dicts
         self.next = None                     # static inputs of P
 
@@ -289,5 +293,16 @@ class GraphedFixMatchStep(_Graphed):
         def train():
             pre = self.pre
             return step.student_iteration(self.data, self.data_u, pre["geom_s"], pre["pseudo"], pre["knn"], ema_in_place=True)
+        if self.split:
+            def head():
+                pre = self.pre
+                self._losses, rest = step.student_iteration(self.data, self.data_u, pre["geom_s"], pre["pseudo"], pre["knn"],
+                                                            ema_in_place=True, defer_rest=True)
+                return rest
+
+            def rest_update(rest):
+                rest()
+                return self._losses
+            train = (head, rest_update)
         next_src = None if next_batches is None else [b[k] for b, keys in zip(next_batches, _P_KEYS) for k in keys]
         return self._iterate(announced_now, next_src, load_next, lookahead, train)

@@ -364,21 +364,33 @@ class FixMatchNTMStep:
             inner.segmentor.at_blocks_backward = None
         return losses, queued[0]
 
-    def student_iteration(self, data, data_u, geom_s, pseudo, knn_graph, after_forward=None, ema_in_place=False):
+    def student_iteration(self, data, data_u, geom_s, pseudo, knn_graph, after_forward=None, ema_in_place=False,
+                          defer_rest=False):
         """Steps 2-5 of the iteration (train.py:478-602, 646-660): the student on labelled + strong + weak views, the class
         transition, the per-point matrices, the corrected logits, the losses, backward, both optimisers.
         pseudo = (pred_u, logits_u_aug, label_u_aug) of the teacher; knn_graph = (nbr, order) of raw_pos or a callable that
         returns them (called where they are first needed); after_forward(): called behind the student's forward (the eager
         iteration joins its teacher stream and queues its look-ahead there); ema_in_place: update ema_t IN its buffer
-        (a captured graph holds the buffer, not the attribute)."""
+        (a captured graph holds the buffer, not the attribute); defer_rest: stop where the backward reaches the student's
+        transformer blocks (the segmentor cuts its autograd graph there) and return (losses, rest) -- rest() runs the backward
+        of the blocks and the patch encoder, the EMA update and both optimisers (graph_step's split capture)."""
         cfg = self.cfg
+        seg = getattr(self.model.module if hasattr(self.model, "module") else self.model, "segmentor", None)
+        can_cut = defer_rest and hasattr(seg, "take_cut")
         bl, bu = data["pos"].shape[0], data_u["pos_w"].shape[0]
         n = data["pos"].shape[1]
         # 2. student on labelled + strong + weak (train.py:478-492)
         _mode(self.model, True)
         _mode(self.T_predictor, True)
         data_u = dict(data_u, T=self.ema_t)
-        pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
+        if can_cut:
+            seg.cut_at_blocks = True
+        try:
+            pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
+        finally:
+            if can_cut:
+                seg.cut_at_blocks = False
+        cut = seg.take_cut() if can_cut else None
         # (split, not two slices: its backward is one concatenation kernel; a slice's backward copies the gradient into a zero
         # tensor with a device-to-device memcpy -- a memcpy node when the iteration is captured)
         pred_l, pred_u_strong = torch.split(pred_all, [bl, bu, pred_all.shape[0] - bl - bu])[:2]
@@ -404,16 +416,25 @@ class FixMatchNTMStep:
         unsup_loss = unsup_loss * (cfg["unsupervised_loss_weight"] * (bu * n) / thresh_mask.sum())
         loss = sup_loss + unsup_loss + loss_3d
         loss.backward()
-        if ema_in_place:
-            with torch.no_grad():
-                torch.mul(ema_next, 1.0, out=self.ema_t)       # behind everything that read the old one (a kernel, not a memcpy node)
-        if cfg["grad_norm_clip"] is not None:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["grad_norm_clip"])
-        self.optimizer.step()
-        self.optimizer.zero_grad(set_to_none=True)
-        self.T_optimizer.step()
-        self.T_optimizer.zero_grad(set_to_none=True)
-        return {"loss": loss.detach(), "sup": sup_loss.detach(), "unsup": unsup_loss.detach(), "threed": loss_3d.detach()}
+        rest_in = None if cut is None else (cut[0], [d.grad for d in cut[1]])
+
+        def rest():
+            if rest_in is not None:
+                torch.autograd.backward(rest_in[0], rest_in[1])
+            if ema_in_place:
+                with torch.no_grad():
+                    torch.mul(ema_next, 1.0, out=self.ema_t)   # behind everything that read the old one (a kernel, not a memcpy node)
+            if cfg["grad_norm_clip"] is not None:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["grad_norm_clip"])
+            self.optimizer.step()
+            self.optimizer.zero_grad(set_to_none=True)
+            self.T_optimizer.step()
+            self.T_optimizer.zero_grad(set_to_none=True)
+        losses = {"loss": loss.detach(), "sup": sup_loss.detach(), "unsup": unsup_loss.detach(), "threed": loss_3d.detach()}
+        if defer_rest:
+            return losses, rest
+        rest()
+        return losses
 
 
 def _same_positions_impl(src, data, data_u):

@@ -88,8 +88,8 @@ def _fix_batch(seed, n=4096):
              "x_s": strong.transpose(1, 2).contiguous(), "cls_s": z, "raw_pos": unl})
 
 
-@pytest.mark.parametrize("look", [True, False])
-def test_fixmatch_iteration_from_a_graph_equals_eager(look):
+@pytest.mark.parametrize("look,split", [(True, False), (False, False), (True, True)])
+def test_fixmatch_iteration_from_a_graph_equals_eager(look, split):
     from geot_amd import train_step as ts, graph_step as gs
     cfg = dict(ts.NTM_CFG, threed_k=8)
     batches = [_fix_batch(3), _fix_batch(400)]
@@ -97,7 +97,7 @@ def test_fixmatch_iteration_from_a_graph_equals_eager(look):
     for mode in ("eager", "graph"):
         torch.manual_seed(5)
         step = ts.build_fixmatch(DEV, seg_cfg=SMALL, cfg=cfg, use_ddp=False)
-        call = gs.GraphedFixMatchStep(step, warmup=2) if mode == "graph" else step
+        call = gs.GraphedFixMatchStep(step, warmup=2, split=split) if mode == "graph" else step
         torch.manual_seed(11)
         out = []
         for i in range(6):
@@ -107,7 +107,7 @@ def test_fixmatch_iteration_from_a_graph_equals_eager(look):
         torch.cuda.synchronize()
         if mode == "graph":
             assert call.captured
-            assert len(call.node_types) == 2 and all(set(v) == {"kernel"} for v in call.node_types.values()), call.node_types
+            assert len(call.node_types) == (3 if split else 2) and all(set(v) == {"kernel"} for v in call.node_types.values()), call.node_types
         runs[mode] = (out, _state(step))
     for i, (a, b) in enumerate(zip(runs["eager"][0], runs["graph"][0])):
         for k in a:
