@@ -3,10 +3,14 @@ usage: graph_long_fixmatch.py <points> <iterations>"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import geot_amd
 import torch
 from test_graph_step_gpu import _fix_batch, DEV, _state
 from geot_amd import train_step as ts, graph_step as gs
 n, iters = int(sys.argv[1]), int(sys.argv[2])
+FLOOD = int(os.environ.get("FLOOD", "0"))      # eager launches between replays every 5th iteration (the packet-capture hazard)
+flood_buf = torch.randn(1 << 16, device=DEV)
+print("launch mode:", geot_amd.GRAPH_LAUNCH, "| packet capture off:", geot_amd.graph_replay_is_safe(), "| flood", FLOOD, flush=True)
 batches = [_fix_batch(3, n), _fix_batch(400, n), _fix_batch(900, n)]
 res = {}
 for mode in ("eager", "graph"):
@@ -22,6 +26,9 @@ for mode in ("eager", "graph"):
         out = call(cur[0], cur[1], next_batches=nxt)
         if i % 5 == 0 or i == iters - 1:
             losses.append((i, float(out["loss"]), float(out["threed"])))
+            if mode == "graph":
+                for _ in range(FLOOD):
+                    flood_buf.mul_(1.0)
     torch.cuda.synchronize()
     res[mode] = (losses, _state(step))
 bad = [(a, b) for a, b in zip(res["eager"][0], res["graph"][0]) if a != b]
