@@ -540,9 +540,14 @@ def main():
     use_graph = can_replay and (args.graph or workload == "fixmatch" or B <= 3)
     eager_step = step
     graphed = replay_step = None
+    replay_refused = None
     if can_replay:
         from geot_amd import graph_step as gs
-        graphed = (gs.GraphedSupervisedStep if workload == "model" else gs.GraphedFixMatchStep)(trainer)
+        try:
+            graphed = (gs.GraphedSupervisedStep if workload == "model" else gs.GraphedFixMatchStep)(trainer)
+        except RuntimeError as e:                   # e.g. packet capture left on by the environment without GEOT_GRAPH_LAUNCH=fast
+            replay_refused, use_graph, can_replay = "%s: %s" % (type(e).__name__, str(e)[:600]), False, False
+    if can_replay:
 
         def replay_step():
             cur, nxt = batches[turn[0] % 2], batches[(turn[0] + 1) % 2]
@@ -550,7 +555,6 @@ def main():
             if workload == "model":
                 return graphed(cur[0], cur[1], cur[2], next_pos=nxt[0] if lookahead else None)
             return graphed(cur[0], cur[1], next_batches=nxt if lookahead else None)["loss"]
-    replay_refused = None
     if use_graph:
         try:
             for _ in range(graphed.warmup + 1):     # eager over the static buffers, then the capture + first replay
@@ -558,11 +562,11 @@ def main():
             assert graphed.captured
             step = replay_step
             graph_note = "; the iteration replayed from single-stream hipGraphs (static buffers, batch copied in per step)"
-        except RuntimeError as e:                   # fast launch mode and a graph that is not kernel-only: eager, and say so
-            if "only kernel nodes" not in str(e):
-                raise
-            replay_refused, use_graph, can_replay = str(e), False, False
-    if args.graph and not can_replay:
+        except RuntimeError as e:                   # e.g. fast launch mode and a graph that is not kernel-only: eager, and say so
+            replay_refused, use_graph, can_replay = "%s: %s" % (type(e).__name__, str(e)[:600]), False, False
+            step = eager_step
+            torch.cuda.synchronize()
+    if args.graph and not can_replay and replay_refused is None:
         assert workload in ("sa", "ntm"), "--graph: sa / ntm capture one step here; model / fixmatch have the replay of graph_step.py"
         from geot_amd import streams
         side = torch.cuda.Stream(device=dev)
@@ -642,10 +646,9 @@ def main():
                 for _ in range(graphed.warmup + 2):  # eager over the static buffers, capture, first replays
                     other()
                 assert graphed.captured
-            except RuntimeError as e:
-                if "only kernel nodes" not in str(e):
-                    raise
-                replay_refused, other = str(e), None
+            except RuntimeError as e:            # the timed (eager) region is done: a failed replay leg is reported, not fatal
+                replay_refused, other = "%s: %s" % (type(e).__name__, str(e)[:600]), None
+                torch.cuda.synchronize()
     if can_replay and other is not None:
         t_e, out_e = timed_steps(other, k_e, dev, rehearsal)
         assert torch.isfinite(out_e).all()
@@ -859,7 +862,8 @@ def main():
                                     "host logic" if world > 1 else
                                     "primary mode = eager" + ("; the hipGraph replay of the same iterations is `replay` (primary for "
                                                               "the FixMatch iteration and at <= 3 clouds, where the eager "
-                                                              "step is host-bound)" if can_replay else " (--no-graph)"))}
+                                                              "step is host-bound)" if can_replay else
+                                                             (" (the replay was refused: `replay_refused`)" if replay_refused else " (--no-graph)")))}
         if other_leg is not None:
             result["eager" if use_graph else "replay"] = other_leg
         if graphed is not None and graphed.node_types:
