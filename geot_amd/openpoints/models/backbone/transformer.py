@@ -182,28 +182,48 @@ class TransformerEncoder_h(nn.Module):
         """The same blocks with every residual add fused into the LayerNorm behind it (fused_norm.res_ln): the
         position embedding and the previous block's MLP branch enter the next block's norm1 in one pass, the attention
         branch enters norm2 in one pass; a block's output is materialised only where it is extracted."""
-        def scale(blk, branch):
-            return blk.drop_path.scale(branch) if isinstance(blk.drop_path, DropPath) else None
-
+        factors = self._drop_path_factors(x)
         inter_feats = []
         pending = None                                 # (a1, mlp branch, drop-path factors) of the previous block
         for i, blk in enumerate(self.blocks):
+            f_att, f_mlp = factors[i]
             if pending is None:
                 a0, n1 = res_ln(x, None, None, pos, blk.norm1)
             else:
                 a0, n1 = res_ln(pending[0], pending[1], pending[2], pos, blk.norm1)
             att = blk.attn(n1)
-            a1, n2 = res_ln(a0, att, scale(blk, att), None, blk.norm2)
+            a1, n2 = res_ln(a0, att, f_att, None, blk.norm2)
             m = blk.mlp(n2)
             wanted = self.extract_layers is not None and i + 1 in self.extract_layers
             if wanted or i + 1 == len(self.blocks):
-                x = _residual(a1, m, blk.drop_path)
+                x = a1 + m if f_mlp is None else torch.addcmul(a1, m, f_mlp)
                 pending = None
                 if wanted:
                     inter_feats.append(x)
             else:
-                pending = (a1, m, scale(blk, m))
+                pending = (a1, m, f_mlp)
         return inter_feats if self.extract_layers is not None else x
+
+    def _drop_path_factors(self, x):
+        """[(attention branch's factor, MLP branch's factor)] per block: Bernoulli(keep) / keep per sample, (B, 1, 1), or None where
+        nothing is dropped (eval, rate 0) -- what DropPath.scale draws, but ALL of a forward's factors in one bernoulli launch and
+        one division instead of two tiny launches per branch (44 per forward at depth 12: 0.2 ms of launch latency on the main
+        stream).  Same distribution per (branch, sample); the random stream is consumed in another order than branch by branch,
+        which the reference-order path (Block.forward) keeps."""
+        probs = [blk.drop_path.drop_prob if isinstance(blk.drop_path, DropPath) else 0.0 for blk in self.blocks]
+        if not self.training or not any(probs):
+            return [(None, None)] * len(self.blocks)
+        live = [i for i, p in enumerate(probs) if p > 0.0]
+        keep = self.__dict__.get("_dp_keep")
+        if keep is None or keep.device != x.device or keep.shape[0] != 2 * len(live):
+            keep = torch.tensor([1.0 - probs[i] for i in live for _ in (0, 1)], dtype=torch.float32, device=x.device).view(-1, 1)
+            self.__dict__["_dp_keep"] = keep                       # (2 x live blocks, 1): built once per device, outside any capture
+        f = (torch.bernoulli(keep.expand(-1, x.shape[0])) / keep).to(x.dtype)     # (2 x live, B)
+        shape = (x.shape[0],) + (1,) * (x.dim() - 1)
+        out = [(None, None)] * len(self.blocks)
+        for j, i in enumerate(live):
+            out[i] = (f[2 * j].view(shape), f[2 * j + 1].view(shape))
+        return out
 
 
 class Encoder(nn.Module):
