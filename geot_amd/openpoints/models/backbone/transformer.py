@@ -280,12 +280,13 @@ class Encoder(nn.Module):
         c2 = self.second_conv[0]
         w = c2.weight.squeeze(-1)
         pre = c2.bias
+        w_g, w_f = torch.split(w, [c1, w.shape[1] - c1], dim=1)  # (pooled | per-point) columns: one split, one concatenation back
         if b1 is not None:                                     # W_f (f0 + b1) = W_f f0 + W_f b1
-            wb = torch.mv(w[:, c1:], b1)
+            wb = torch.mv(w_f, b1)
             # (pre * 1.0: the two addends must not receive the SAME gradient tensor -- AccumulateGrad clones a shared one with a
             # device-to-device memcpy, a memcpy node when the step is captured; x1.0 is exact)
             pre = wb if pre is None else pre * 1.0 + wb
-        h = add_last_broadcast(conv(c2, f0, w[:, c1:], bias=False).view(-1, bs * g, n), torch.mm(w[:, :c1], pooled))
+        h = add_last_broadcast(conv(c2, f0, w_f, bias=False).view(-1, bs * g, n), torch.mm(w_g, pooled))
         h0 = conv(self.second_conv[3], norm_act(self.second_conv, h.view(-1, L), pre), bias=False)  # (C_enc, L)
         out = max_last(h0.view(-1, bs * g, n))
         if b2 is not None:
@@ -341,7 +342,7 @@ class DGCNN_Propagation(nn.Module):
         else:
             c = x_q.shape[1]
             w = conv.weight.view(conv.out_channels, 2 * c)
-            w_d, w_q = w[:, :c], w[:, c:]
+            w_d, w_q = torch.split(w, [c, c], dim=1)                     # (one split: its backward is one concatenation)
             if idx is None:      # (the model hands in the ids it searched on its side stream, see _index_plan)
                 idx = _knn_idx(coor_q, coor_k, self.k)
             p = pointwise(w_d, x_k)                                      # (B, Cout, Nk)
@@ -372,6 +373,9 @@ def _fp_factored(fp, unknown, known, unknow_feats, known_feats, nn3=None, layout
     conv = first.conv
     c = known_feats.shape[1]
     w = conv.weight.view(conv.out_channels, -1)
+    # the two column blocks of the first convolution (known features | skip features) as ONE split: its backward is a single
+    # concatenation, where two slices cost two zero-fills, two copies and an add per step
+    w_known, w_skip = torch.split(w, [c, w.shape[1] - c], dim=1) if w.shape[1] > c else (w, None)
     order = rix = None
     if nn3 is None:
         dist2, idx = pt_utils._ext.three_nn(unknown.contiguous(), known.contiguous())
@@ -392,9 +396,9 @@ def _fp_factored(fp, unknown, known, unknow_feats, known_feats, nn3=None, layout
         # + BatchNorm sums, BatchNorm + ReLU, and the second stage's convolution reads (B, n, C) as a transposed operand
         if weight is None:
             weight = pt_utils._ext.fp_weights(dist2)
-        a_cl = pointwise_to_cl(w[:, :c], known_feats)
+        a_cl = pointwise_to_cl(w_known, known_feats)
         relu = any(isinstance(mod, nn.ReLU) for _, mod in first.named_children())
-        wb = None if unknow_feats is None else w[:, c:]
+        wb = None if unknow_feats is None else w_skip
         if os.environ.get("GEOT_FP_CL_FUSED", "1") != "0":   # one node; its backward never writes the BatchNorm's input gradient
             z_cl = fp_stage_cl(first.bn.bn, a_cl, idx, weight, unknow_feats, wb, relu, order, rix)
         else:
@@ -405,12 +409,12 @@ def _fp_factored(fp, unknown, known, unknow_feats, known_feats, nn3=None, layout
         if conv2.bias is not None:
             y2 = y2 + conv2.bias.view(1, -1, 1)
         return shared_mlp_nd(layers[1:], y2, first_conv_done=True)
-    a = pointwise(w[:, :c], known_feats)                                 # (B, Cout, m): GEMM on the known points
+    a = pointwise(w_known, known_feats)                                  # (B, Cout, m): GEMM on the known points
     if conv.bias is None and has_bn and post_act and fp_front_eligible(a, unknow_feats):
         # interpolation + skip channels + the BatchNorm sums in one kernel, then BatchNorm + ReLU in one pass
         if weight is None:
             weight = pt_utils._ext.fp_weights(dist2)
-        y, partial = fp_front(a, idx, weight, unknow_feats, None if unknow_feats is None else w[:, c:])
+        y, partial = fp_front(a, idx, weight, unknow_feats, None if unknow_feats is None else w_skip)
         relu = any(isinstance(mod, nn.ReLU) for _, mod in first.named_children())
         y = bn_act(first.bn.bn, y, relu=relu, partial=partial)
         for name, mod in first.named_children():
@@ -419,7 +423,7 @@ def _fp_factored(fp, unknown, known, unknow_feats, known_feats, nn3=None, layout
         return shared_mlp_nd(layers[1:], y)
     y = pt_utils.three_interpolate(a, idx, weight if weight is not None else pt_utils._ext.fp_weights(dist2))
     if unknow_feats is not None:
-        y = y + pointwise(w[:, c:], unknow_feats)
+        y = y + pointwise(w_skip, unknow_feats)
     if conv.bias is not None:
         y = y + conv.bias.view(1, -1, 1)
     return _rest_of_stage(first, layers, y)
