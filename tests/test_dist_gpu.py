@@ -249,3 +249,28 @@ def test_rccl_backend_runs_a_ddp_step_on_one_rank():
     backend, last, gathered, losses = res
     assert backend == "nccl" and last == float((1 << 20) - 1) and gathered == [0.0, 1.0, 2.0, 3.0]
     assert losses[True] == losses[False], losses
+
+
+@pytest.mark.parametrize("packet_capture_env", [None, "1"])
+def test_bench_one_gpu_line_has_both_modes_or_says_why_not(packet_capture_env):
+    """bench.py on one GPU, as a fresh child: the replay leg runs in the runtime's fast graph mode (kernel-only graphs, their
+    node counts in the JSON) next to the eager leg; with graph packet capture forced on by the environment and no
+    GEOT_GRAPH_LAUNCH=fast, graph_step refuses to capture -- the line must still come out, eager, with the reason."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DEBUG_CLR_GRAPH_PACKET_CAPTURE",
+                        "GEOT_GRAPH_LAUNCH")}
+    if packet_capture_env is not None:
+        env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = packet_capture_env
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--clouds", "2", "--steps", "3", "--warmup", "1",
+                        "--points", "8192", "--no-cpu-baseline", "--no-dense-reference"], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and np.isfinite(rec["ms_per_step"])
+    g = rec["graph"]
+    if packet_capture_env is None:
+        assert g["replayed"] is True and g["launch_mode"] == "fast" and "eager" in rec        # 2 clouds: the replay is primary
+        assert all(set(v) == {"kernel"} for v in g["nodes"].values()) and set(g["nodes"]) >= {"P"}
+        assert rec["host_issue_ms_per_step"] < rec["eager"]["host_issue_ms_per_step"]
+    else:
+        assert g["replayed"] is False and "replay_refused" in g and "replay" not in rec and "eager" not in rec
