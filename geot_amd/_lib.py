@@ -48,6 +48,7 @@ PROTOTYPES = {
                               ctypes.POINTER(_c_int), _c_int, _P, _P, _c_void_p],
 }
 PROTOTYPES.update({
+    "geot_gather_points_grad_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_group_points_grad_ws": [_c_int, _c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _c_void_p],
     "geot_three_interpolate_grad_ws": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
     "geot_three_interpolate_grad_out": [_c_int, _c_int, _c_int, _c_int, _P, _P, _P, _P, _P, _c_void_p],
@@ -136,6 +137,7 @@ PLAIN = {
     "geot_knn_grid_ws_bytes": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_knnquery_heap_ws_bytes": ([_c_int, _c_int, _c_int, _c_int], ctypes.c_longlong),
     "geot_grad_ws_needs_zero": ([_c_int, _c_int, _c_int, ctypes.c_longlong, _c_int], _c_int),
+    "geot_scatter_grad_ws_floats": ([_c_int, _c_int, _c_int, ctypes.c_longlong, _c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_sig_t_mean_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_threed_loss_ws_bytes": ([_c_int, _c_int, _c_int], ctypes.c_longlong),
     "geot_ntm_correct_ws_floats": ([_c_int, _c_int], ctypes.c_longlong),
@@ -159,7 +161,7 @@ PLAIN = {
     "geot_rowdot_small_slices": ([_c_int] * 2, _c_int),
     "geot_colsum_ws_floats": ([_c_int] * 2, ctypes.c_longlong),
 }
-ABI_VERSION = 6     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
+ABI_VERSION = 7     # include/geot_hip.h GEOT_ABI_VERSION this binding was written against
 
 _lib = None
 

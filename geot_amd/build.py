@@ -19,8 +19,8 @@ LIB = os.path.join(HERE, "libgeot_hip.so")
 VARIANTS = {"exact": (0, LIB), "fma": (1, os.path.join(HERE, "libgeot_hip_fma.so")),
             "fma_xy": (2, os.path.join(HERE, "libgeot_hip_fma_xy.so"))}
 
-SOURCES = ["fps.hip", "neighbors.hip", "knn_grid.hip", "gather_group.hip", "ntm.hip", "ntm_generic.hip", "sa_mlp.hip", "dataprep.hip", "edgeconv.hip", "bnrelu.hip", "channels_last.hip", "loss.hip", "layernorm.hip"]
-HEADERS = ["geot_common.h", "ntm_generic.h", os.path.join(ROOT, "include", "geot_hip.h")]
+SOURCES = ["fps.hip", "neighbors.hip", "knn_grid.hip", "gather_group.hip", "tile_scatter.hip", "ntm.hip", "ntm_generic.hip", "sa_mlp.hip", "dataprep.hip", "edgeconv.hip", "bnrelu.hip", "channels_last.hip", "loss.hip", "layernorm.hip"]
+HEADERS = ["geot_common.h", "ntm_generic.h", "tile_scatter.h", os.path.join(ROOT, "include", "geot_hip.h")]
 
 # -ffp-contract=off: squared distances must be un-contracted IEEE fp32 so that
 # integer outputs match the CPU oracle bit for bit.

@@ -17,6 +17,7 @@
 // cloud is 96 KB).
 #include "geot_common.h"
 #include "geot_hip.h"
+#include "tile_scatter.h"
 #include <cstdlib>
 
 namespace geot {
@@ -1597,6 +1598,18 @@ GEOT_EXPORT int geot_gather_points_grad(int b, int c, int n, int m, const float 
     return hipGetLastError();
 }
 
+// as geot_gather_points_grad without float atomics: workspace = geot_scatter_grad_ws_floats(b, c, n, m, 1, 0) floats
+GEOT_EXPORT int geot_gather_points_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                           float *grad_points, float *workspace, void *stream)
+{
+    if (b < 0 || c < 0 || n < 0 || m < 0 || !workspace) return hipErrorInvalidValue;
+    if (b == 0 || c == 0 || m == 0 || n == 0) return hipSuccess;
+    hipError_t e = scatter_via_tiles(b, c, n, m, 1, (size_t)c * m, grad_out, idx, nullptr, grad_points, workspace,
+                                     geot_scatter_grad_ws_floats(b, c, n, m, 1, 0), (hipStream_t)stream, false);
+    if (e != hipErrorNotSupported) return e;
+    return geot_gather_points_grad(b, c, n, m, grad_out, idx, grad_points, stream);
+}
+
 GEOT_EXPORT int geot_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
                                   const int *idx, float *out, void *stream)
 {
@@ -1697,7 +1710,17 @@ GEOT_EXPORT int geot_three_interpolate_grad(int b, int c, int n, int m, const fl
 // only uses it as scratch (reverse-index path) and any contents will do.
 GEOT_EXPORT int geot_grad_ws_needs_zero(int b, int c, int m, long long L, int nt)
 {
+    if (ts_ws_ints(b, c, m, L, nt, nt == 3) > 0) return 0;
     return csr_applies(b, c, m, L, nt, (long long)b * m * c) ? 0 : 1;
+}
+
+// floats of workspace the *_grad_ws / _grad_out / _grad_from entry points take for these sizes: b*m*c (the
+// channels-last accumulator of the fallback) or the sorted pair stream of csrc/tile_scatter.hip, whichever is larger
+GEOT_EXPORT long long geot_scatter_grad_ws_floats(int b, int c, int m, long long L, int nt, int weighted)
+{
+    if (b < 1 || c < 1 || m < 1) return 0;
+    const long long base = (long long)b * m * c, tiles = L > 0 && nt > 0 ? ts_ws_ints(b, c, m, L, nt, weighted != 0) : 0;
+    return base > tiles ? base : tiles;
 }
 
 static int three_interpolate_grad_launch(int b, int c, int n, int m, const float *grad_out, size_t grad_bstride,
@@ -1709,7 +1732,10 @@ static int three_interpolate_grad_launch(int b, int c, int n, int m, const float
     if (n == 0) return overwrite ? (int)zero_words(grad_points, (long long)b * c * m, s) : (int)hipSuccess;
     if (b > 65535) return hipErrorInvalidValue;
     {
-        hipError_t e = scatter_via_csr<3, true>(b, c, m, n, grad_bstride, grad_out, idx, weight, grad_points, workspace,
+        hipError_t e = scatter_via_tiles(b, c, m, n, 3, grad_bstride, grad_out, idx, weight, grad_points, workspace,
+                                         geot_scatter_grad_ws_floats(b, c, m, n, 3, 1), s, overwrite);
+        if (e != hipErrorNotSupported) return e;
+        e = scatter_via_csr<3, true>(b, c, m, n, grad_bstride, grad_out, idx, weight, grad_points, workspace,
                                                 (long long)b * m * c, s, overwrite);
         if (e != hipErrorNotSupported) return e;
     }
@@ -1891,7 +1917,10 @@ GEOT_EXPORT int geot_group_points_grad_ws(int b, int c, int n, int npoints, int 
     if (b == 0 || c == 0 || npns == 0 || n == 0) return hipSuccess;
     if (npns > 0x7fffffffLL || b > 65535) return hipErrorInvalidValue;
     {
-        hipError_t e = scatter_via_csr<1, false>(b, c, n, (int)npns, (size_t)c * npns, grad_out, idx, nullptr, grad_points, workspace,
+        hipError_t e = scatter_via_tiles(b, c, n, (int)npns, 1, (size_t)c * npns, grad_out, idx, nullptr, grad_points, workspace,
+                                         geot_scatter_grad_ws_floats(b, c, n, npns, 1, 0), (hipStream_t)stream, false);
+        if (e != hipErrorNotSupported) return e;
+        e = scatter_via_csr<1, false>(b, c, n, (int)npns, (size_t)c * npns, grad_out, idx, nullptr, grad_points, workspace,
                                                  (long long)b * n * c, (hipStream_t)stream);
         if (e != hipErrorNotSupported) return e;
     }
@@ -1937,7 +1966,10 @@ GEOT_EXPORT int geot_graph_feature_grad(int b, int c, int nq, int nk, int k, con
     else hipLaunchKernelGGL(graph_feature_grad_q_kernel<0>, gq, dim3(GG_THREADS), 0, s, c, nq, k, grad_out, grad_xq);
     const int L = nq * k;
     {
-        hipError_t e = scatter_via_csr<1, false>(b, c, nk, L, (size_t)2 * c * L, grad_out, idx, nullptr, grad_xk,
+        hipError_t e = scatter_via_tiles(b, c, nk, L, 1, (size_t)2 * c * L, grad_out, idx, nullptr, grad_xk, workspace,
+                                         geot_scatter_grad_ws_floats(b, c, nk, L, 1, 0), s, false);
+        if (e != hipErrorNotSupported) return e;
+        e = scatter_via_csr<1, false>(b, c, nk, L, (size_t)2 * c * L, grad_out, idx, nullptr, grad_xk,
                                                  workspace, (long long)b * nk * c, s);
         if (e != hipErrorNotSupported) return e;
     }

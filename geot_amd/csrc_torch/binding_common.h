@@ -2,6 +2,7 @@
 // Error behaviour as geot_amd/ext/_common.py: every violated precondition is a RuntimeError (TORCH_CHECK), never an
 // exit() (the reference's pointnet2_batch wrappers exit(-1), its pointops wrappers check nothing).
 #pragma once
+#include <algorithm>
 #include <torch/extension.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/core/DeviceGuard.h>
@@ -38,5 +39,14 @@ inline void same_device(std::initializer_list<const at::Tensor *> ts)
 inline void ok(int err, const char *what) { TORCH_CHECK(err == 0, what, ": ", geot_error_string(err)); }
 
 inline at::TensorOptions like(const at::Tensor &t, at::ScalarType dtype) { return at::device(t.device()).dtype(dtype); }
+
+// scratch of the atomic-free gradients (geot_scatter_grad_ws_floats); zero-filled only for the shapes that still
+// accumulate in it (geot_grad_ws_needs_zero)
+inline at::Tensor grad_ws(const at::Tensor &ref, int b, int c, int m, long long sources, int slots, int weighted)
+{
+    const long long floats = std::max<long long>(geot_scatter_grad_ws_floats(b, c, m, sources, slots, weighted), 1);
+    return geot_grad_ws_needs_zero(b, c, m, sources, slots) ? at::zeros({(int64_t)floats}, like(ref, at::kFloat))
+                                                            : at::empty({(int64_t)floats}, like(ref, at::kFloat));
+}
 
 } // namespace geot_binding

@@ -43,8 +43,9 @@ int gather_points_grad_wrapper(int b, int c, int n, int npoints, at::Tensor grad
                     grad_points.numel() == (int64_t)b * c * n,
                 "gather_grad size mismatch");
     c10::DeviceGuard guard(grad_out.device());
-    ok(geot_gather_points_grad(b, c, n, npoints, grad_out.data_ptr<float>(), idx.data_ptr<int>(), grad_points.data_ptr<float>(),
-                               stream_of(grad_out)),
+    at::Tensor ws = grad_ws(grad_out, b, c, n, npoints, 1, 0);
+    ok(geot_gather_points_grad_ws(b, c, n, npoints, grad_out.data_ptr<float>(), idx.data_ptr<int>(), grad_points.data_ptr<float>(),
+                                  ws.data_ptr<float>(), stream_of(grad_out)),
        "gather_points_grad_wrapper");
     return 1;
 }
@@ -91,14 +92,13 @@ int group_points_grad_wrapper(int b, int c, int n, int npoints, int nsample, at:
                     grad_points.numel() == (int64_t)b * c * n,
                 "group_grad size mismatch");
     c10::DeviceGuard guard(grad_out.device());
-    if (c < 16) {
+    if (c < 16 && geot_grad_ws_needs_zero(b, c, n, (long long)npoints * nsample, 1)) {
         ok(geot_group_points_grad(b, c, n, npoints, nsample, grad_out.data_ptr<float>(), idx.data_ptr<int>(),
                                   grad_points.data_ptr<float>(), stream_of(grad_out)),
            "group_points_grad_wrapper");
         return 1;
     }
-    const bool zero = geot_grad_ws_needs_zero(b, c, n, (long long)npoints * nsample, 1) != 0;
-    at::Tensor ws = zero ? at::zeros({b, n, c}, like(grad_out, at::kFloat)) : at::empty({b, n, c}, like(grad_out, at::kFloat));
+    at::Tensor ws = grad_ws(grad_out, b, c, n, (long long)npoints * nsample, 1, 0);
     ok(geot_group_points_grad_ws(b, c, n, npoints, nsample, grad_out.data_ptr<float>(), idx.data_ptr<int>(),
                                  grad_points.data_ptr<float>(), ws.data_ptr<float>(), stream_of(grad_out)),
        "group_points_grad_wrapper");
@@ -146,14 +146,13 @@ void three_interpolate_grad_wrapper(int b, int c, int n, int m, at::Tensor grad_
                     grad_points.numel() == (int64_t)b * c * m,
                 "three_interpolate_grad size mismatch");
     c10::DeviceGuard guard(grad_out.device());
-    if (c < 16) {
+    if (c < 16 && geot_grad_ws_needs_zero(b, c, m, (long long)n, 3)) {
         ok(geot_three_interpolate_grad(b, c, n, m, grad_out.data_ptr<float>(), idx.data_ptr<int>(), weight.data_ptr<float>(),
                                        grad_points.data_ptr<float>(), stream_of(grad_out)),
            "three_interpolate_grad_wrapper");
         return;
     }
-    const bool zero = geot_grad_ws_needs_zero(b, c, m, (long long)n, 3) != 0;
-    at::Tensor ws = zero ? at::zeros({b, m, c}, like(grad_out, at::kFloat)) : at::empty({b, m, c}, like(grad_out, at::kFloat));
+    at::Tensor ws = grad_ws(grad_out, b, c, m, (long long)n, 3, 1);
     ok(geot_three_interpolate_grad_ws(b, c, n, m, grad_out.data_ptr<float>(), idx.data_ptr<int>(), weight.data_ptr<float>(),
                                       grad_points.data_ptr<float>(), ws.data_ptr<float>(), stream_of(grad_out)),
        "three_interpolate_grad_wrapper");

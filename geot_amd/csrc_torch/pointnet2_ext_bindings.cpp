@@ -30,8 +30,9 @@ at::Tensor gather_points_grad(at::Tensor grad_out, at::Tensor idx, const int n)
     c10::DeviceGuard guard(grad_out.device());
     const int b = grad_out.size(0), c = grad_out.size(1), m = grad_out.size(2);
     at::Tensor out = at::zeros({b, c, n}, like(grad_out, at::kFloat));
-    ok(geot_gather_points_grad(b, c, n, m, grad_out.data_ptr<float>(), idx.data_ptr<int>(), out.data_ptr<float>(),
-                               stream_of(grad_out)),
+    at::Tensor ws = grad_ws(grad_out, b, c, n, m, 1, 0);
+    ok(geot_gather_points_grad_ws(b, c, n, m, grad_out.data_ptr<float>(), idx.data_ptr<int>(), out.data_ptr<float>(),
+                                  ws.data_ptr<float>(), stream_of(grad_out)),
        "gather_points_grad");
     return out;
 }
@@ -97,7 +98,7 @@ at::Tensor three_interpolate_grad(at::Tensor grad_out, at::Tensor idx, at::Tenso
     TORCH_CHECK(idx.size(0) == b && idx.size(1) == n && idx.size(2) == 3 && weight.sizes() == idx.sizes(),
                 "idx/weight must be (B, n, 3)");
     c10::DeviceGuard guard(grad_out.device());
-    if (c < 16) {     // too few channels for the reverse-index / channels-last paths: direct scatter into zeros
+    if (c < 16 && geot_grad_ws_needs_zero(b, c, m, n, 3)) {     // the atomic fallback with too few channels for its 256-B rows: direct scatter
         at::Tensor out = at::zeros({b, c, m}, like(grad_out, at::kFloat));
         ok(geot_three_interpolate_grad(b, c, n, m, grad_out.data_ptr<float>(), idx.data_ptr<int>(), weight.data_ptr<float>(),
                                        out.data_ptr<float>(), stream_of(grad_out)),
@@ -105,7 +106,7 @@ at::Tensor three_interpolate_grad(at::Tensor grad_out, at::Tensor idx, at::Tenso
         return out;
     }
     at::Tensor out = at::empty({b, c, m}, like(grad_out, at::kFloat));        // every element is written by the call
-    at::Tensor ws = at::empty({(int64_t)b * c * m}, like(grad_out, at::kFloat));
+    at::Tensor ws = grad_ws(grad_out, b, c, m, n, 3, 1);
     ok(geot_three_interpolate_grad_out(b, c, n, m, grad_out.data_ptr<float>(), idx.data_ptr<int>(), weight.data_ptr<float>(),
                                        out.data_ptr<float>(), ws.data_ptr<float>(), stream_of(grad_out)),
        "three_interpolate_grad");
@@ -154,14 +155,13 @@ at::Tensor group_points_grad(at::Tensor grad_out, at::Tensor idx, const int n)
     TORCH_CHECK(idx.size(0) == b && idx.size(1) == np && idx.size(2) == ns, "idx shape mismatch");
     c10::DeviceGuard guard(grad_out.device());
     at::Tensor out = at::zeros({b, c, n}, like(grad_out, at::kFloat));        // group_points.cpp:50-52
-    if (c < 16) {
+    if (c < 16 && geot_grad_ws_needs_zero(b, c, n, (long long)np * ns, 1)) {
         ok(geot_group_points_grad(b, c, n, np, ns, grad_out.data_ptr<float>(), idx.data_ptr<int>(), out.data_ptr<float>(),
                                   stream_of(grad_out)),
            "group_points_grad");
         return out;
     }
-    const bool zero = geot_grad_ws_needs_zero(b, c, n, (long long)np * ns, 1) != 0;
-    at::Tensor ws = zero ? at::zeros({b, n, c}, like(grad_out, at::kFloat)) : at::empty({b, n, c}, like(grad_out, at::kFloat));
+    at::Tensor ws = grad_ws(grad_out, b, c, n, (long long)np * ns, 1, 0);
     ok(geot_group_points_grad_ws(b, c, n, np, ns, grad_out.data_ptr<float>(), idx.data_ptr<int>(), out.data_ptr<float>(),
                                  ws.data_ptr<float>(), stream_of(grad_out)),
        "group_points_grad");

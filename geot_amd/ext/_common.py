@@ -144,9 +144,19 @@ def ball_workspace(dev, b, n, m, radius, nsample):
     return ws.data_ptr(), nbytes, ws
 
 
-def grad_workspace(dev, b, c, m, n_sources, slots):
-    """(B, m, C) float scratch for the *_grad_ws entry points: zero-filled only when the kernel accumulates
-    in it (channels-last scatter); the reverse-index path just needs the room."""
-    need_zero = _lib.load().geot_grad_ws_needs_zero(int(b), int(c), int(m), int(n_sources), int(slots))
+def grad_needs_atomics(b, c, m, n_sources, slots):
+    """True for the shapes the atomic-free gradient forms do not take (the *_grad_ws calls then accumulate with float
+    atomics in a zero-filled channels-last workspace; with fewer than 16 channels the direct scatter is the better one)."""
+    return bool(_lib.load().geot_grad_ws_needs_zero(int(b), int(c), int(m), int(n_sources), int(slots)))
+
+
+def grad_workspace(dev, b, c, m, n_sources, slots, weighted=None):
+    """Float scratch for the *_grad_ws entry points (geot_scatter_grad_ws_floats): the sorted pair stream of
+    csrc/tile_scatter.hip, or -- for shapes it does not take -- the (B, m, C) channels-last accumulator, zero-filled
+    only then."""
+    lib = _lib.load()
+    weighted = (slots == 3) if weighted is None else weighted
+    floats = int(lib.geot_scatter_grad_ws_floats(int(b), int(c), int(m), int(n_sources), int(slots), int(bool(weighted))))
+    need_zero = lib.geot_grad_ws_needs_zero(int(b), int(c), int(m), int(n_sources), int(slots))
     alloc = torch.zeros if need_zero else torch.empty
-    return alloc((int(b), int(m), int(c)), dtype=torch.float32, device=dev)
+    return alloc(max(floats, 1), dtype=torch.float32, device=dev)

@@ -7,7 +7,8 @@ reference (which only checks ball_query and exit(-1)s) every call validates its
 tensors and raises RuntimeError.  Outputs may be uninitialised
 (torch.cuda.FloatTensor(...)); they are written in full.
 """
-from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace
+from ._common import (f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace,
+                      grad_needs_atomics)
 
 
 def furthest_point_sampling_wrapper(b, n, m, points, temp, idx):
@@ -32,7 +33,8 @@ def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
     dev = same_device(grad_out, idx, grad_points)
     need(grad_out.numel() == b * c * npoints and idx.numel() == b * npoints and grad_points.numel() == b * c * n,
          "gather_grad size mismatch")
-    call("geot_gather_points_grad", dev, b, c, n, npoints, ptr(grad_out), ptr(idx), ptr(grad_points))
+    ws = grad_workspace(dev, b, c, n, npoints, 1)
+    call("geot_gather_points_grad_ws", dev, b, c, n, npoints, ptr(grad_out), ptr(idx), ptr(grad_points), ptr(ws))
     return 1
 
 
@@ -60,7 +62,7 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     dev = same_device(grad_out, idx, grad_points)
     need(grad_out.numel() == b * c * npoints * nsample and idx.numel() == b * npoints * nsample
          and grad_points.numel() == b * c * n, "group_grad size mismatch")
-    if c < 16:
+    if c < 16 and grad_needs_atomics(b, c, n, npoints * nsample, 1):
         call("geot_group_points_grad", dev, b, c, n, npoints, nsample, ptr(grad_out), ptr(idx), ptr(grad_points))
         return 1
     ws = grad_workspace(dev, b, c, n, npoints * nsample, 1)
@@ -91,7 +93,7 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     dev = same_device(grad_out, idx, weight, grad_points)
     need(grad_out.numel() == b * c * n and idx.numel() == b * n * 3 and weight.numel() == b * n * 3
          and grad_points.numel() == b * c * m, "three_interpolate_grad size mismatch")
-    if c < 16:
+    if c < 16 and grad_needs_atomics(b, c, m, n, 3):
         call("geot_three_interpolate_grad", dev, b, c, n, m, ptr(grad_out), ptr(idx), ptr(weight), ptr(grad_points))
         return
     ws = grad_workspace(dev, b, c, m, n, 3)

@@ -8,7 +8,8 @@ ball_query.cpp:22-24; group_points.cpp:25-27,50-52; interpolate.cpp:26-31,58-60,
 """
 import torch
 
-from ._common import f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace, check_index
+from ._common import (f32, i32, same_device, need, call, ptr, knn_workspace, ball_workspace, grad_workspace,
+                      grad_needs_atomics, check_index)
 
 
 def _fresh(shape, dtype, dev, source_len):
@@ -36,7 +37,8 @@ def gather_points_grad(grad_out, idx, n):
     b, c, m = grad_out.shape
     need(tuple(idx.shape) == (b, m), "idx shape mismatch")
     out = torch.zeros((b, c, int(n)), dtype=torch.float32, device=dev)
-    call("geot_gather_points_grad", dev, b, c, int(n), m, ptr(grad_out), ptr(idx), ptr(out))
+    ws = grad_workspace(dev, b, c, int(n), m, 1)
+    call("geot_gather_points_grad_ws", dev, b, c, int(n), m, ptr(grad_out), ptr(idx), ptr(out), ptr(ws))
     return out
 
 
@@ -82,12 +84,12 @@ def three_interpolate_grad(grad_out, idx, weight, m):
     dev = same_device(grad_out, idx, weight)
     b, c, n = grad_out.shape
     need(tuple(idx.shape) == (b, n, 3) and tuple(weight.shape) == (b, n, 3), "idx/weight must be (B, n, 3)")
-    if c < 16:   # too few channels to fill a wave's 256-B atomic row: direct scatter
+    if c < 16 and grad_needs_atomics(b, c, int(m), n, 3):   # too few channels to fill a wave's 256-B atomic row: direct scatter
         out = torch.zeros((b, c, int(m)), dtype=torch.float32, device=dev)
         call("geot_three_interpolate_grad", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out))
         return out
     out = torch.empty((b, c, int(m)), dtype=torch.float32, device=dev)      # every element is written by the call
-    ws = torch.empty(b * c * int(m), dtype=torch.float32, device=dev)
+    ws = grad_workspace(dev, b, c, int(m), n, 3)
     call("geot_three_interpolate_grad_out", dev, b, c, n, int(m), ptr(grad_out), ptr(idx), ptr(weight), ptr(out),
          ptr(ws))
     return out
@@ -161,7 +163,7 @@ def group_points_grad(grad_out, idx, n):
     b, c, npoints, nsample = grad_out.shape
     need(tuple(idx.shape) == (b, npoints, nsample), "idx shape mismatch")
     out = torch.zeros((b, c, int(n)), dtype=torch.float32, device=dev)
-    if c < 16:
+    if c < 16 and grad_needs_atomics(b, c, int(n), npoints * nsample, 1):
         call("geot_group_points_grad", dev, b, c, int(n), npoints, nsample, ptr(grad_out), ptr(idx), ptr(out))
         return out
     ws = grad_workspace(dev, b, c, int(n), grad_out.shape[2] * grad_out.shape[3], 1)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GEOT_ABI_VERSION 6
+#define GEOT_ABI_VERSION 7
 #define GEOT_NTM_MAX_C 32   /* largest class count of the geot_ntm_* entry points */
 
 /* ABI version / diagnostics. */
@@ -67,6 +67,10 @@ int geot_gather_points(int b, int c, int n, int m, const float *points, const in
                        void *stream);
 int geot_gather_points_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
                             float *grad_points, void *stream);
+/* The same gradient without float atomics (one writer per element, bit-reproducible): see geot_group_points_grad_ws.
+ * workspace: geot_scatter_grad_ws_floats(b, c, n, m, 1, 0) floats of scratch. */
+int geot_gather_points_grad_ws(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                               float *grad_points, float *workspace, void *stream);
 
 /* ---- ball query -------------------------------------------------------------
  * pointnet2/_ext_src/src/ball_query_gpu.cu:49-57 query_ball_point_kernel_wrapper
@@ -88,10 +92,15 @@ int geot_group_points(int b, int c, int n, int npoints, int nsample, const float
 int geot_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                            const int *idx, float *grad_points, void *stream);
 
-/* Same result as geot_group_points_grad / geot_three_interpolate_grad (up to fp32 summation order),
- * several times faster: accumulates in a channels-last workspace where every atomic wave-instruction
- * is one contiguous 256-B row, then transposes into grad_points.  workspace: b*n*c (group) or b*m*c
- * (interpolate) floats, ZERO-FILLED by the caller. */
+/* Same result as geot_group_points_grad / geot_three_interpolate_grad (up to fp32 summation order) WITHOUT float
+ * atomics (geot_amd/csrc/tile_scatter.hip): the pairs of every tile of sources are sorted by target once per call, a
+ * workgroup keeps the sums of (batch, 4 channels) x all targets in LDS and streams grad_out through it -- grad_out is
+ * read once, every output element has one writer and one summation order: bit-reproducible, 3-4x faster.
+ * workspace: geot_scatter_grad_ws_floats(b, c, targets, sources, slots, weighted) floats; contents irrelevant unless
+ * geot_grad_ws_needs_zero says 1 (shapes the sorted form does not take -- more than 32768 targets per cloud -- fall
+ * back to a channels-last atomic accumulation in the workspace, which must then arrive zero-filled). */
+long long geot_scatter_grad_ws_floats(int b, int c, int m_targets, long long n_sources, int slots_per_source,
+                                      int weighted);
 int geot_group_points_grad_ws(int b, int c, int n, int npoints, int nsample, const float *grad_out,
                               const int *idx, float *grad_points, float *workspace, void *stream);
 /* 0 when the *_grad_ws entry points only use their workspace as scratch for these sizes (gradient as a

@@ -131,10 +131,18 @@ def test_host_only_planning_entry_points(monkeypatch):
     assert lib.geot_ntm_threed_graph_bytes(2, 1000, 32) > 4 * (2 * 1000 * (2 * 64 + 4 * 32))
     assert lib.geot_ntm_threed_loss_ws_bytes(2, 1000, 32) > 0 and lib.geot_ntm_sig_t_mean_ws_floats(8, 24000) > 0
     assert lib.geot_ntm_correct_ws_floats(8, 24000) % 289 == 0
-    # gradients: reverse-index path when the source rows fit LDS and the workspace is big enough
+    # gradients: the sorted-pair-stream form (csrc/tile_scatter.hip) wherever a CU's LDS holds the targets' sums
     assert lib.geot_grad_ws_needs_zero(8, 384, 8192, 24000, 3) == 0
-    assert lib.geot_grad_ws_needs_zero(8, 64, 24000, 6000 * 32, 1) == 1      # 768 KB rows: channels-last scatter
-    assert lib.geot_grad_ws_needs_zero(1, 16, 8192, 24000, 3) == 1           # workspace too small for the index
+    assert lib.geot_grad_ws_needs_zero(8, 64, 24000, 6000 * 32, 1) == 0
+    assert lib.geot_grad_ws_needs_zero(1, 3, 8, 3000, 3) == 0
+    assert lib.geot_grad_ws_needs_zero(1, 16, 100000, 200000, 3) == 1        # 100 k targets, long rows: channels-last atomic accumulation
+    ws = lib.geot_scatter_grad_ws_floats(8, 384, 8192, 24000, 3, 1)
+    assert ws >= 8 * 384 * 8192 and lib.geot_scatter_grad_ws_floats(8, 4, 8192, 24000, 3, 1) >= 2 * 8 * 24000 * 3
+    assert lib.geot_scatter_grad_ws_floats(1, 16, 100000, 200000, 3, 1) == 16 * 100000
+    monkeypatch.setenv("GEOT_GATHER_IMPL", "csr")
+    assert lib.geot_grad_ws_needs_zero(8, 64, 24000, 6000 * 32, 1) == 1      # the older forms: 768 KB rows do not fit LDS
+    assert lib.geot_grad_ws_needs_zero(1, 16, 8192, 24000, 3) == 1           # workspace too small for their index
+    monkeypatch.delenv("GEOT_GATHER_IMPL")
     assert lib.geot_sa_param_floats(3, 3, (__import__("ctypes").c_int * 3)(64, 64, 128)) == 6 * 64 + 64 + 64 * 64 + 64 + 64 * 128 + 128
 
 
