@@ -1060,6 +1060,18 @@ static bool csr_applies(int b, int c, int m, long long L, int nt, long long ws_f
            (long long)b * rix_plan(c, L).Q * m <= 0x7ffffff0LL;
 }
 
+// Few targets with long lists (the FP modules that interpolate from the 512 group centres: 24-48 pairs per target):
+// whole rows of grad_out fit LDS (Q = 1), one lane group per target walks its list -- one writer per element, fixed order,
+// and 2x faster there than the sorted pair stream of tile_scatter.hip, which pays for a segmented sum per chunk when most
+// pairs of a tile share their target (profiles/r05_tile_scatter.txt).  The pair stream takes everything else.
+static bool csr_preferred(int b, int c, int m, long long L, int nt)
+{
+    const char *env = getenv("GEOT_GATHER_IMPL");
+    if (env && env[0]) return env[0] != 't' && env[0] != 'p';       // forced: tiles / plain -> no; csr / sell / atomic -> as before
+    return L >= 1 && m >= 1 && rix_plan(c, L).Q == 1 && (double)L * nt >= 12.0 * m &&
+           csr_applies(b, c, m, L, nt, rix_ws_ints(b, c, m, L, nt));
+}
+
 // returns hipErrorNotSupported when this path does not apply (caller falls back)
 template <int NT, bool WEIGHTED>
 static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride, const float *grad_out,
@@ -1604,9 +1616,15 @@ GEOT_EXPORT int geot_gather_points_grad_ws(int b, int c, int n, int m, const flo
 {
     if (b < 0 || c < 0 || n < 0 || m < 0 || !workspace) return hipErrorInvalidValue;
     if (b == 0 || c == 0 || m == 0 || n == 0) return hipSuccess;
-    hipError_t e = scatter_via_tiles(b, c, n, m, 1, (size_t)c * m, grad_out, idx, nullptr, grad_points, workspace,
-                                     geot_scatter_grad_ws_floats(b, c, n, m, 1, 0), (hipStream_t)stream, false);
+    const long long wsf = geot_scatter_grad_ws_floats(b, c, n, m, 1, 0);
+    hipError_t e = csr_preferred(b, c, n, m, 1) ? hipErrorNotSupported
+                                                : scatter_via_tiles(b, c, n, m, 1, (size_t)c * m, grad_out, idx, nullptr, grad_points, workspace,
+                                                                    wsf, (hipStream_t)stream, false);
     if (e != hipErrorNotSupported) return e;
+    if (b <= 65535) {
+        e = scatter_via_csr<1, false>(b, c, n, m, (size_t)c * m, grad_out, idx, nullptr, grad_points, workspace, wsf, (hipStream_t)stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     return geot_gather_points_grad(b, c, n, m, grad_out, idx, grad_points, stream);
 }
 
@@ -1710,8 +1728,8 @@ GEOT_EXPORT int geot_three_interpolate_grad(int b, int c, int n, int m, const fl
 // only uses it as scratch (reverse-index path) and any contents will do.
 GEOT_EXPORT int geot_grad_ws_needs_zero(int b, int c, int m, long long L, int nt)
 {
-    if (ts_ws_ints(b, c, m, L, nt, nt == 3) > 0) return 0;
-    return csr_applies(b, c, m, L, nt, (long long)b * m * c) ? 0 : 1;
+    if (!csr_preferred(b, c, m, L, nt) && ts_ws_ints(b, c, m, L, nt, nt == 3) > 0) return 0;
+    return csr_applies(b, c, m, L, nt, geot_scatter_grad_ws_floats(b, c, m, L, nt, nt == 3)) ? 0 : 1;
 }
 
 // floats of workspace the *_grad_ws / _grad_out / _grad_from entry points take for these sizes: b*m*c (the
@@ -1720,7 +1738,9 @@ GEOT_EXPORT long long geot_scatter_grad_ws_floats(int b, int c, int m, long long
 {
     if (b < 1 || c < 1 || m < 1) return 0;
     const long long base = (long long)b * m * c, tiles = L > 0 && nt > 0 ? ts_ws_ints(b, c, m, L, nt, weighted != 0) : 0;
-    return base > tiles ? base : tiles;
+    const long long rows = L > 0 && nt > 0 && L <= TLDS_FLOATS && rix_plan(c, L).Q == 1 && (double)L * nt >= 12.0 * m
+                               ? rix_ws_ints(b, c, m, L, nt) : 0;           // the whole-rows gather (csr_preferred)
+    return base > tiles ? (base > rows ? base : rows) : (tiles > rows ? tiles : rows);
 }
 
 static int three_interpolate_grad_launch(int b, int c, int n, int m, const float *grad_out, size_t grad_bstride,
@@ -1732,11 +1752,13 @@ static int three_interpolate_grad_launch(int b, int c, int n, int m, const float
     if (n == 0) return overwrite ? (int)zero_words(grad_points, (long long)b * c * m, s) : (int)hipSuccess;
     if (b > 65535) return hipErrorInvalidValue;
     {
-        hipError_t e = scatter_via_tiles(b, c, m, n, 3, grad_bstride, grad_out, idx, weight, grad_points, workspace,
-                                         geot_scatter_grad_ws_floats(b, c, m, n, 3, 1), s, overwrite);
+        const long long wsf = geot_scatter_grad_ws_floats(b, c, m, n, 3, 1);
+        hipError_t e = csr_preferred(b, c, m, n, 3) ? hipErrorNotSupported
+                                                    : scatter_via_tiles(b, c, m, n, 3, grad_bstride, grad_out, idx, weight, grad_points,
+                                                                        workspace, wsf, s, overwrite);
         if (e != hipErrorNotSupported) return e;
         e = scatter_via_csr<3, true>(b, c, m, n, grad_bstride, grad_out, idx, weight, grad_points, workspace,
-                                                (long long)b * m * c, s, overwrite);
+                                                wsf, s, overwrite);
         if (e != hipErrorNotSupported) return e;
     }
     if (overwrite) {   // the channels-last scatter accumulates in the workspace and adds into grad_points
@@ -1917,11 +1939,13 @@ GEOT_EXPORT int geot_group_points_grad_ws(int b, int c, int n, int npoints, int 
     if (b == 0 || c == 0 || npns == 0 || n == 0) return hipSuccess;
     if (npns > 0x7fffffffLL || b > 65535) return hipErrorInvalidValue;
     {
-        hipError_t e = scatter_via_tiles(b, c, n, (int)npns, 1, (size_t)c * npns, grad_out, idx, nullptr, grad_points, workspace,
-                                         geot_scatter_grad_ws_floats(b, c, n, npns, 1, 0), (hipStream_t)stream, false);
+        const long long wsf = geot_scatter_grad_ws_floats(b, c, n, npns, 1, 0);
+        hipError_t e = csr_preferred(b, c, n, npns, 1) ? hipErrorNotSupported
+                                                       : scatter_via_tiles(b, c, n, (int)npns, 1, (size_t)c * npns, grad_out, idx, nullptr,
+                                                                           grad_points, workspace, wsf, (hipStream_t)stream, false);
         if (e != hipErrorNotSupported) return e;
         e = scatter_via_csr<1, false>(b, c, n, (int)npns, (size_t)c * npns, grad_out, idx, nullptr, grad_points, workspace,
-                                                 (long long)b * n * c, (hipStream_t)stream);
+                                                 wsf, (hipStream_t)stream);
         if (e != hipErrorNotSupported) return e;
     }
     dim3 g1((unsigned)((npns + SC_TILE - 1) / SC_TILE), (c + SC_TILE - 1) / SC_TILE, b);
@@ -1966,11 +1990,13 @@ GEOT_EXPORT int geot_graph_feature_grad(int b, int c, int nq, int nk, int k, con
     else hipLaunchKernelGGL(graph_feature_grad_q_kernel<0>, gq, dim3(GG_THREADS), 0, s, c, nq, k, grad_out, grad_xq);
     const int L = nq * k;
     {
-        hipError_t e = scatter_via_tiles(b, c, nk, L, 1, (size_t)2 * c * L, grad_out, idx, nullptr, grad_xk, workspace,
-                                         geot_scatter_grad_ws_floats(b, c, nk, L, 1, 0), s, false);
+        const long long wsf = geot_scatter_grad_ws_floats(b, c, nk, L, 1, 0);
+        hipError_t e = csr_preferred(b, c, nk, L, 1) ? hipErrorNotSupported
+                                                     : scatter_via_tiles(b, c, nk, L, 1, (size_t)2 * c * L, grad_out, idx, nullptr, grad_xk,
+                                                                         workspace, wsf, s, false);
         if (e != hipErrorNotSupported) return e;
         e = scatter_via_csr<1, false>(b, c, nk, L, (size_t)2 * c * L, grad_out, idx, nullptr, grad_xk,
-                                                 workspace, (long long)b * nk * c, s);
+                                                 workspace, wsf, s);
         if (e != hipErrorNotSupported) return e;
     }
     dim3 g1((L + SC_TILE - 1) / SC_TILE, (c + SC_TILE - 1) / SC_TILE, b);

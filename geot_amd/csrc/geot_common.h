@@ -256,9 +256,10 @@ static inline hipError_t zero_words(void *dst, long long words, hipStream_t s)
 // (2b) The reverse indices (CSR by target) are first filled through atomically handed-out ranks, so the order of a
 // target's entries differs from run to run -- and with it the fp32 summation order of every gather over them.  The
 // entry-parallel helper below gives every pair its position in the ascending-pair-id order of its list (a count over
-// the list, L2-resident), so the final lists -- and the gathers -- are bit-reproducible.  Lists longer than
-// RIX_SORT_MAX (degenerate hubs) keep the arbitrary order: still correct, only not reproducible.
-constexpr int RIX_SORT_MAX = 4096;
+// the list, L2-resident), so the final lists -- and the gathers -- are bit-reproducible.  Hub lists are counted in full
+// too (every pair of the list is its own thread: a 30 000-entry list costs each of them 30 000 L2-resident reads, ~0.1 ms
+// once per call); only beyond RIX_SORT_MAX entries does a list keep the arbitrary order: correct, not reproducible.
+constexpr int RIX_SORT_MAX = 1 << 22;
 __device__ __forceinline__ int rix_sorted_position(const int *__restrict__ tmp, int a, int z, int mine, int fallback)
 {
     if (z - a > RIX_SORT_MAX) return fallback;

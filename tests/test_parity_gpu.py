@@ -283,7 +283,9 @@ def test_three_interpolate_grad_out_overwrites_uninitialised_buffers(ext, oracle
     w = rng.random((b, n, 3)).astype(np.float32)
     go = rng.standard_normal((b, c, n)).astype(np.float32)
     out = torch.full((b, c, m), float("nan"), device=DEV)
-    ws = torch.full((b * c * m,), float("nan"), device=DEV)
+    from geot_amd import _lib
+    ws_floats = max(int(_lib.load().geot_scatter_grad_ws_floats(b, c, m, n, 3, 1)), b * c * m, 1)      # ABI 7: the call's own query
+    ws = torch.full((ws_floats,), float("nan"), device=DEV)
     d_go, d_idx, d_w = dev(go), dev(idx), dev(w)          # named: the raw pointers below do not keep them alive
     call("geot_three_interpolate_grad_out", out.device, b, c, n, m, ptr(d_go), ptr(d_idx), ptr(d_w), ptr(out), ptr(ws))
     want = oracle.three_interpolate_grad(go, idx, w, m) if n else np.zeros((b, c, m), np.float32)

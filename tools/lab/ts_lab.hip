@@ -9,6 +9,7 @@
 #include <random>
 #include <algorithm>
 #define TS_NSTAMP 8
+#ifndef TS_NO_STAMPS
 __device__ unsigned long long ts_stamp_buf[2][TS_NSTAMP];
 #define TS_STAMP_DECL unsigned long long ts_t0 = __builtin_amdgcn_s_memtime(); unsigned long long ts_acc[TS_NSTAMP] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define TS_STAMP(slot)                                                         \
@@ -20,6 +21,9 @@ __device__ unsigned long long ts_stamp_buf[2][TS_NSTAMP];
 #define TS_STAMP_FLUSH                                                                                                  \
     if ((threadIdx.x == 0 || threadIdx.x == 7 * 64) && blockIdx.x < 64)                                                 \
         for (int i = 0; i < TS_NSTAMP; ++i) atomicAdd(&ts_stamp_buf[threadIdx.x ? 1 : 0][i], ts_acc[i]);
+#else
+__device__ unsigned long long ts_stamp_buf[2][TS_NSTAMP];
+#endif
 #include "../../geot_amd/csrc/tile_scatter.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -62,9 +66,10 @@ int main(int argc, char **argv)
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = 4.0 * b * c * ((double)L + m) + 8.0 * b * L * nt;
     printf("b %d c %d L %d m %d nt %d: %.1f us per call, %.2f TB/s algorithmic\n", b, c, L, m, nt, ms / iters * 1e3, bytes / (ms / iters * 1e-3) / 1e12);
+#ifndef TS_NO_STAMPS
     unsigned long long st[2][TS_NSTAMP];
     CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(ts_stamp_buf), sizeof(st)));
-    const char *names[TS_NSTAMP] = {"prologue", "stage(store+load)", "barrier", "walk:entries+rows", "walk:plain chunks", "walk:sorted run", "walk:overflow", "epilogue"};
+    const char *names[TS_NSTAMP] = {"prologue", "stage(store+load)", "barrier", "stage A (rows of p+1)", "stage B (sums of p)", "-", "-", "epilogue"};
     const int wgs = std::min(64, (c + p.ch - 1) / p.ch) * b;   // blockIdx.x < 64 of every batch
     for (int wv = 0; wv < 2; ++wv) {
         unsigned long long tot = 0;
@@ -74,6 +79,7 @@ int main(int argc, char **argv)
             printf("   %-20s %10.1f  %5.1f %%\n", names[i], (double)st[wv][i] / iters / wgs, 100.0 * st[wv][i] / (double)tot);
         printf("   total %.1f ticks = %.1f us per workgroup\n", (double)tot / iters / wgs, (double)tot / iters / wgs / 100.0);
     }
+#endif
     // check against a double scatter-add on the host (first batch, first 8 channels)
     std::vector<float> out((size_t)b * c * m);
     CK(hipMemcpy(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost));
