@@ -36,9 +36,8 @@ if ROOT not in sys.path:
 # One GPU: the replay leg launches its graphs in the runtime's fast mode (graph packet capture left ON: 0.5 ms of host time per
 # launch instead of 7-20 ms), which graph_step accepts only for graphs of kernel nodes alone -- it inspects what it captured
 # and this file records the node counts (and falls back to the eager step if a graph is refused).  An exported
-# GEOT_GRAPH_LAUNCH / DEBUG_CLR_GRAPH_PACKET_CAPTURE wins.  (sa / ntm --graph capture without that inspection: safe mode.)
-if (os.environ.get("WORLD_SIZE", "1") == "1" and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ
-        and not ("--graph" in sys.argv and any(w in sys.argv for w in ("sa", "ntm")))):
+# GEOT_GRAPH_LAUNCH / DEBUG_CLR_GRAPH_PACKET_CAPTURE wins.  (The sa / ntm --graph capture below is inspected the same way.)
+if os.environ.get("WORLD_SIZE", "1") == "1" and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ:
     os.environ.setdefault("GEOT_GRAPH_LAUNCH", "fast")
 import geot_amd  # noqa: E402,F401  (before torch touches the GPU: it pins the HIP runtime's graph switch, geot_amd/__init__.py)
 
@@ -384,6 +383,11 @@ def main():
     from geot_amd.synth import make_batch, region_labels
     if rank == 0:
         hip_build.build()          # mtime-incremental; a stale git-ignored .so must not be loaded as-is
+        try:                       # the compiled torch bindings too, here and not lazily in every rank (same in-tree output files)
+            from geot_amd import build_torch_ext
+            build_torch_ext.build()
+        except Exception as e:     # noqa: BLE001 -- no compiler: every rank binds through ctypes
+            sys.stderr.write("bench.py: the compiled torch bindings did not build (%s); ctypes serves\n" % str(e)[:200])
     dist_utils.barrier()
     _lib.load()
 
@@ -576,9 +580,13 @@ def main():
                 eager_step()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize()
-        hip_graph = torch.cuda.CUDAGraph()
+        hip_graph = torch.cuda.CUDAGraph(keep_graph=True)
         with streams.capture(hip_graph, dev):
             graph_out = eager_step()
+        kinds = streams.node_types(hip_graph)
+        if not geot_amd.graph_replay_is_safe() and set(kinds) - {"kernel"}:
+            raise SystemExit("bench.py --graph: the captured step holds %s; only kernel nodes are known to replay correctly unless "
+                             "the launcher exported DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (geot_amd/__init__.py)" % kinds)
 
         def step():
             hip_graph.replay()
@@ -867,12 +875,15 @@ def main():
         if other_leg is not None:
             result["eager" if use_graph else "replay"] = other_leg
         if graphed is not None and graphed.node_types:
-            result["graph"]["launch_mode"] = geot_amd.GRAPH_LAUNCH if not geot_amd.graph_replay_is_safe() else "safe"
+            result["graph"]["launch_mode"] = ("safe" if geot_amd.graph_replay_is_safe() else
+                                              "fast" if geot_amd.GRAPH_LAUNCH == "fast" else "inspected")
             result["graph"]["nodes"] = graphed.node_types      # {"P": {"kernel": n}, "M": {...}}: hipGraphGetNodes on the captures
             result["graph"]["launch_note"] = (
                 "fast = the runtime's graph packet capture left on (0.5 ms of host time per launch); correct only for graphs of "
-                "kernel nodes alone, which graph_step verifies per capture (`nodes`); safe = packet capture off "
-                "(DEBUG_CLR_GRAPH_PACKET_CAPTURE=0), any graph, 7-20 ms per launch (geot_amd/__init__.py)")
+                "kernel nodes alone, which graph_step verifies per capture (`nodes`); safe = packet capture exported off by the "
+                "launcher (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0), any graph, 7-20 ms per launch; inspected = the switch is whatever "
+                "the environment left it and cannot be verified, so captures are held to kernel nodes as in fast mode "
+                "(geot_amd/__init__.py)")
         if replay_refused:
             result["graph"]["replay_refused"] = replay_refused
         result["config"]["lookahead"] = ("the step is handed the next batch's coordinates (two batches alternate) and queues "

@@ -14,32 +14,33 @@ import os as _os
 import sys as _sys
 
 
-def _hip_runtime_up():
-    t = _sys.modules.get("torch")
-    return bool(t is not None and hasattr(t, "cuda") and t.cuda.is_initialized())
-
-
 # hipGraph replays (geot_amd/graph_step.py) and the runtime's "graph packet capture" (on by default in ROCm 7.0): with it on,
 # the AQL packets of a graph's hipMemsetAsync / hipMemcpyAsync NODES keep pointing at kernel-argument slots of the device's
 # shared ring, and a few thousand eager launches between two replays recycle those slots -- the memsets then clear something
 # else, and every torch reduction that zeroes its semaphores that way returns garbage, silently
-# (profiles/r04_graph_capture_notes.txt has the reproducer).  Graphs of kernel nodes alone are not affected.  Two modes,
-# chosen by GEOT_GRAPH_LAUNCH before the HIP runtime initialises (the switch is read then):
-#   safe (default)  packet capture is turned OFF here, at import, unless the process has chosen a value itself; any graph
-#                   replays correctly, a launch costs the host 7-20 ms (the runtime re-encodes the graph's packets);
-#   fast            packet capture stays ON (0.5 ms per launch); graph_step then inspects every graph it captures
-#                   (hipGraphGetNodes) and REFUSES one that holds anything but kernel nodes.  The training steps of this
-#                   package capture kernel-only (tests/test_graph_step_gpu.py); code added around them may not.
-# graph_step refuses to capture when neither holds (HIP already initialised at import, or the variable overridden).
+# (profiles/r04_graph_capture_notes.txt has the reproducer).  Graphs of kernel nodes alone are not affected.
+# The HIP runtime reads the switch at ITS first call -- which can be earlier than any torch.cuda call this module could see
+# (torch.cuda.is_available() / device_count() before the import, or a preloaded tool such as rocprofv3) -- so a value this
+# module sets itself is a best effort, never a proof.  Hence three states:
+#   exported "0" by the launcher (the process environment had DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before this import):
+#                   packet capture is known to be off; any graph replays correctly (7-20 ms of host time per launch);
+#   GEOT_GRAPH_LAUNCH=safe (default), not exported: this module sets the variable to 0 now (in time when nothing has touched
+#                   HIP yet), but since that cannot be verified every captured graph is INSPECTED (hipGraphGetNodes) and one
+#                   that holds anything but kernel nodes is refused -- exactly as in fast mode;
+#   GEOT_GRAPH_LAUNCH=fast: packet capture stays ON (0.5 ms per launch); every captured graph is inspected, kernel-only accepted.
+# The training steps of this package capture kernel-only (tests/test_graph_step_gpu.py); code added around them may not --
+# then export the variable in the launcher.
 GRAPH_PACKET_CAPTURE_ENV = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
 GRAPH_LAUNCH = _os.environ.get("GEOT_GRAPH_LAUNCH", "safe")
 if GRAPH_LAUNCH not in ("safe", "fast"):
     raise ImportError("GEOT_GRAPH_LAUNCH must be 'safe' or 'fast', not %r" % GRAPH_LAUNCH)
-_GRAPH_ENV_SET_IN_TIME = not _hip_runtime_up()
-if _GRAPH_ENV_SET_IN_TIME and GRAPH_LAUNCH == "safe":
+_EXPORTED_BEFORE_IMPORT = _os.environ.get(GRAPH_PACKET_CAPTURE_ENV)
+if GRAPH_LAUNCH == "safe":
     _os.environ.setdefault(GRAPH_PACKET_CAPTURE_ENV, "0")
 
 
 def graph_replay_is_safe():
-    """True when hipGraph packet capture is off for this process (see above): any captured graph replays correctly."""
-    return _os.environ.get(GRAPH_PACKET_CAPTURE_ENV) == "0" and _GRAPH_ENV_SET_IN_TIME
+    """True only when the launcher exported DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (the process environment held it before this
+    import): hipGraph packet capture is then off for certain and any captured graph replays correctly.  Otherwise graph_step
+    (and bench.py's own captures) inspect every graph and accept kernel nodes only."""
+    return _EXPORTED_BEFORE_IMPORT == "0"

@@ -46,7 +46,26 @@ def _generate():
     gen = os.path.join(CSRC, "gen_dispatch.py")
     if (not os.path.exists(GENERATED)
             or os.path.getmtime(GENERATED) < max(os.path.getmtime(header), os.path.getmtime(gen))):
-        subprocess.check_call([sys.executable, gen, header, GENERATED], stdout=subprocess.DEVNULL)
+        tmp = "%s.%d.tmp" % (GENERATED, os.getpid())
+        subprocess.check_call([sys.executable, gen, header, tmp], stdout=subprocess.DEVNULL)
+        os.replace(tmp, GENERATED)
+
+
+class _BuildLock:
+    """One builder at a time per checkout (several ranks of one node import the package at once): an exclusive flock on a
+    file next to the outputs; the others wait, then find the outputs fresh."""
+
+    def __enter__(self):
+        import fcntl
+        self.fd = open(os.path.join(HERE, ".build_torch_ext.lock"), "w")
+        fcntl.flock(self.fd, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.fd, fcntl.LOCK_UN)
+        self.fd.close()
+        return False
 
 
 def _command(name, src):
@@ -59,7 +78,7 @@ def _command(name, src):
            "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI),
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + sysconfig.get_paths()["include"], "-I/opt/rocm/include"]
     cmd += ["-I" + p for p in inc]
-    cmd += [src, "-o", out_path(name), "-L" + tlib, "-L" + HERE, "-lgeot_hip", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
+    cmd += [src, "-o", "%s.%d.tmp" % (out_path(name), os.getpid()), "-L" + tlib, "-L" + HERE, "-lgeot_hip", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip",
             "-ltorch", "-ltorch_python", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + tlib]
     return cmd
 
@@ -67,26 +86,32 @@ def _command(name, src):
 def build(force=False, verbose=False, only=None):
     """Build every module that is older than its sources (all in parallel) -> path of _pointnet2_ext_cpp.so."""
     from . import build as hip_build
-    lib = hip_build.build()
-    _generate()
-    common = [os.path.join(ROOT, "include", "geot_hip.h"), os.path.join(CSRC, "binding_common.h"), lib]
-    jobs = []
-    for name, src in MODULES.items():
-        if only is not None and name not in only:
-            continue
-        out = out_path(name)
-        if force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in [src] + common):
-            cmd = _command(name, src)
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            jobs.append((name, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
-    failed = []
-    for name, proc in jobs:
-        _, err = proc.communicate()
-        if proc.returncode != 0:
-            failed.append("%s:\n%s" % (name, err[-4000:]))
-    if failed:
-        raise RuntimeError("building the torch extension modules failed:\n" + "\n".join(failed))
+    with _BuildLock():
+        lib = hip_build.build()
+        _generate()
+        common = [os.path.join(ROOT, "include", "geot_hip.h"), os.path.join(CSRC, "binding_common.h"), lib]
+        jobs = []
+        for name, src in MODULES.items():
+            if only is not None and name not in only:
+                continue
+            out = out_path(name)
+            if force or not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in [src] + common):
+                cmd = _command(name, src)
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                jobs.append((name, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+        failed = []
+        for name, proc in jobs:
+            _, err = proc.communicate()
+            tmp = "%s.%d.tmp" % (out_path(name), os.getpid())
+            if proc.returncode != 0:
+                failed.append("%s:\n%s" % (name, err[-4000:]))
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            else:
+                os.replace(tmp, out_path(name))      # readers never see a half-written module
+        if failed:
+            raise RuntimeError("building the torch extension modules failed:\n" + "\n".join(failed))
     return OUT
 
 

@@ -86,6 +86,9 @@ def dispatcher():
             except Exception as e:      # noqa: BLE001 -- no compiler / headers / matching library: ctypes serves
                 if BINDING == "cpp":
                     raise RuntimeError("GEOT_BINDING=cpp: the compiled dispatcher is unavailable: %s" % e)
+                import sys
+                sys.stderr.write("geot_amd: the compiled dispatcher is unavailable (%s: %s); launches go through ctypes\n"
+                                 % (type(e).__name__, str(e)[:300]))
                 _dispatch = False
     return _dispatch or None
 

@@ -98,14 +98,9 @@ class _Graphed:
                 raise RuntimeError("graph_step: a DistributedDataParallel model is not captured (its gradient buckets and "
                                    "collectives are host logic); run N > 1 eagerly")
         import geot_amd
-        # (see geot_amd/__init__.py) packet capture off: anything replays; on: only graphs of kernel nodes do -- checked per graph
+        # (see geot_amd/__init__.py) packet capture exported off by the launcher: anything replays; otherwise (fast mode, or the
+        # switch set by the package itself, which cannot be verified) only graphs of kernel nodes do -- checked per graph
         self.kernel_only = not geot_amd.graph_replay_is_safe()
-        if self.kernel_only and geot_amd.GRAPH_LAUNCH != "fast" and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
-            raise RuntimeError(
-                "graph_step: %s must be 0 before the HIP runtime initialises (import geot_amd before the first torch.cuda "
-                "call, or export it) -- or choose GEOT_GRAPH_LAUNCH=fast, under which only kernel-only graphs are accepted: "
-                "with graph packet capture on, eager launches between two replays corrupt a graph's memset / memcpy nodes "
-                "-- wrong gradients, no error (geot_amd/__init__.py)" % geot_amd.GRAPH_PACKET_CAPTURE_ENV)
         self.step = step
         self.warmup = int(warmup)
         self.calls = 0
@@ -121,6 +116,18 @@ class _Graphed:
         for opt in step.optimizers():
             for group in opt.param_groups:
                 group["capturable"] = True   # fused AdamW: the step counter is a device tensor already; same kernel
+        # a python-float lr is baked into the captured AdamW step: remember it and refuse a call that finds another value
+        # (a torch LR scheduler replaces group["lr"] every step -- the replay would silently train at the first one)
+        self._float_lrs = [(group, group["lr"]) for opt in step.optimizers() for group in opt.param_groups
+                           if not torch.is_tensor(group["lr"])]
+
+    def _check_lr(self):
+        for group, lr in self._float_lrs:
+            if not torch.is_tensor(group["lr"]) and group["lr"] != lr:
+                raise RuntimeError(
+                    "graph_step: a parameter group's lr changed from %r to %r, but a python float is baked into the captured "
+                    "AdamW step -- the replay would keep training at %r.  Make lr a float32 device tensor in the optimizer's "
+                    "parameter groups before wrapping the step and fill_ it between calls (module docstring)" % (lr, group["lr"], lr))
 
     def _run(self, name, fn, pool_of=None):
         """fn() = a graph's body over the static buffers.  Eager for its first `warmup` executions, then captured once
@@ -138,9 +145,11 @@ class _Graphed:
             if self.kernel_only and set(kinds) - {"kernel"} and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
                 del graph
                 raise RuntimeError(
-                    "graph_step: graph %s holds %s; with graph packet capture on (GEOT_GRAPH_LAUNCH=fast) only kernel nodes "
-                    "replay correctly (geot_amd/__init__.py).  tools/lab/find_nonkernel_ops.py names the operators that "
-                    "issue hipMemsetAsync / hipMemcpyAsync; or run GEOT_GRAPH_LAUNCH=safe" % (name, kinds))
+                    "graph_step: graph %s holds %s; unless the launcher exported %s=0 (before the HIP runtime initialises) only "
+                    "kernel nodes are known to replay correctly: with graph packet capture on, eager launches between two "
+                    "replays corrupt a graph's memset / memcpy nodes -- wrong gradients, no error (geot_amd/__init__.py).  "
+                    "tools/lab/find_nonkernel_ops.py names the operators that issue hipMemsetAsync / hipMemcpyAsync"
+                    % (name, kinds, geot_amd.GRAPH_PACKET_CAPTURE_ENV))
             self.graphs[name] = (graph, out)
         graph, out = self.graphs[name]
         graph.replay()
@@ -224,6 +233,7 @@ class GraphedSupervisedStep(_Graphed):
             _fits(dst, src, name)
         if next_pos is not None:
             _fits(self.next_pos, next_pos, "next_pos")
+        self._check_lr()
         announced_now = self._is_announced((pos,))
         self._join_pending()
         for dst, src in zip(self.x, (pos, cls, target)):
@@ -274,6 +284,7 @@ class GraphedFixMatchStep(_Graphed):
         for dst, src, what in ((self.data, data, "data"), (self.data_u, data_u, "data_u")):
             for k, v in dst.items():
                 _fits(v, src[k], "%s[%r]" % (what, k))
+        self._check_lr()
         announced_now = self._is_announced([b[k] for b, keys in zip((data, data_u), _P_KEYS) for k in keys])
         self._join_pending()
         for dst, src in ((self.data, data), (self.data_u, data_u)):

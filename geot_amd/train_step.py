@@ -405,7 +405,8 @@ class FixMatchNTMStep:
         ins_t = self.T_predictor(F.softmax(pred_u_strong, dim=1).detach(), self.cm)
         pred_u_strong_corr = ntm_mod.correct_logits(pred_u_strong, ins_t, ema_t_corr, cfg["lambma"])
         if not ema_in_place:
-            self.ema_t = ema_next.detach()
+            with torch.no_grad():      # in its buffer, never rebound: a captured replay (graph_step) holds this very tensor
+                self.ema_t.copy_(ema_next)
         # 5. losses (train.py:570-602)
         nbr, order = knn_graph() if callable(knn_graph) else knn_graph
         loss_3d = self.threed_loss(data_u["raw_pos"], label_u_aug, ins_t, nbr=nbr, order=order) * cfg["threed_loss_weight"]

@@ -115,6 +115,52 @@ def test_fixmatch_iteration_from_a_graph_equals_eager(look, split):
     _same(runs["eager"][1], runs["graph"][1])
 
 
+def test_fixmatch_eager_calls_between_replays_share_the_ema_buffer():
+    """An eager iteration on a step that a GraphedFixMatchStep wraps updates ema_t IN its buffer (the captured graph holds that
+    very tensor): replay, eager, replay equals three eager iterations -- bench.py runs exactly this sequence of legs."""
+    from geot_amd import train_step as ts, graph_step as gs
+    cfg = dict(ts.NTM_CFG, threed_k=8)
+    batches = [_fix_batch(3), _fix_batch(400)]
+    modes = ["g", "g", "g", "e", "g", "e", "g"]        # (the first two graphed calls are the eager warm-up over the static buffers)
+    runs = {}
+    for mode in ("eager", "mixed"):
+        torch.manual_seed(5)
+        step = ts.build_fixmatch(DEV, seg_cfg=SMALL, cfg=cfg, use_ddp=False)
+        graphed = gs.GraphedFixMatchStep(step, warmup=2) if mode == "mixed" else None
+        buf = step.ema_t
+        torch.manual_seed(11)
+        out = []
+        for i, how in enumerate(modes):
+            cur = batches[i % 2]
+            call = graphed if (graphed is not None and how == "g") else step
+            out.append({k: v.clone() for k, v in call(cur[0], cur[1]).items()})
+            assert step.ema_t is buf                     # never rebound
+        torch.cuda.synchronize()
+        runs[mode] = (out, _state(step))
+    for i, (a, b) in enumerate(zip(runs["eager"][0], runs["mixed"][0])):
+        for k in a:
+            assert torch.equal(a[k], b[k]), (i, k, float(a[k]), float(b[k]))
+    _same(runs["eager"][1], runs["mixed"][1])
+
+
+def test_a_changed_float_lr_is_refused():
+    """A python-float lr is baked into the captured AdamW step; a scheduler that replaces it must not go unnoticed."""
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd import train_step as ts, graph_step as gs
+    torch.manual_seed(0)
+    m = PointTransformer_seg_T(**SMALL).to(DEV)
+    step = ts.SupervisedStep(m)
+    call = gs.GraphedSupervisedStep(step, warmup=1)
+    a = _sup_batches(2, 6000)[0]
+    call(*a)
+    for opt in step.optimizers():
+        for group in opt.param_groups:
+            if not torch.is_tensor(group["lr"]):
+                group["lr"] = group["lr"] * 0.5
+    with pytest.raises(RuntimeError, match="lr changed"):
+        call(*a)
+
+
 def test_a_batch_of_another_shape_is_refused():
     from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
     from geot_amd import train_step as ts, graph_step as gs
