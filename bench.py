@@ -85,6 +85,9 @@ def parse():
                          "GPU: make the hipGraph replay (geot_amd/graph_step.py) the PRIMARY mode whatever the size (default: the "
                          "replay at <= 2 clouds in the training forward, the eager step above; the other mode is timed in the "
                          "same run and reported beside it)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default run (one GPU, workload model, default sizes): do NOT append the SetAbstraction forward (configs[1]) "
+                         "and the FixMatch+NTM iteration (configs[4]) as short legs under `also` in the one JSON line")
     ap.add_argument("--no-graph", action="store_true",
                     help="model / fixmatch: time the eager step only, no replay leg; N > 1 always runs eagerly "
                          "(DistributedDataParallel is host logic)")
@@ -123,6 +126,41 @@ def spawn_ranks(args):
             if p.poll() is None:
                 p.kill()
     return failed
+
+
+ALSO_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "data", "config", "roofline", "roofline_hbm",
+             "cpu_baseline", "saturated", "graph", "final_loss", "host_issue_ms_per_step")
+
+
+def also_legs(args, run=subprocess.run):
+    """The other single-GPU configurations of BASELINE.json as short legs of the default run, each a CHILD process of this
+    file (this process has initialised the GPU: it must not exec; a child is the permitted way) started after the primary
+    leg has finished its timing -- the parent only waits meanwhile.  Returns {"sa": {...}, "fixmatch": {...}}: the child's
+    own JSON line cut down to ALSO_KEYS, or {"error": ...} (a failing leg never fails the primary line)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GEOT_GRAPH_LAUNCH")}
+    legs = {"sa": ["--workload", "sa", "--steps", "20", "--warmup", "3", "--cpu-steps", "12"],
+            "fixmatch": ["--workload", "fixmatch", "--steps", str(max(4, min(args.steps, 10))), "--warmup", str(max(2, min(args.warmup, 3)))]}
+    out = {}
+    for name, extra in legs.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-also"] + extra
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        t0 = time.time()
+        try:
+            r = run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": "exit %d: %s" % (r.returncode, (r.stderr or r.stdout)[-400:])}
+                continue
+            rec = json.loads(lines[-1])
+            leg = {k: rec[k] for k in ALSO_KEYS if k in rec}
+            leg["wall_s"] = round(time.time() - t0, 1)
+            leg["command"] = "python bench.py " + " ".join(cmd[2:])
+            out[name] = leg
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+    return out
 
 
 def _finite(obj):
@@ -950,6 +988,11 @@ def main():
             result["cpu_baseline"] = cpu_baseline_model()
         elif workload == "fixmatch":
             result["cpu_baseline"] = cpu_baseline_fixmatch(bl, bu)
+    if (rank == 0 and world == 1 and workload == "model" and not args.no_also and args.clouds is None
+            and args.points == N_POINTS and not args.graph and not args.no_graph and args.dense is None):
+        # the driver's default invocation: configs[1] and configs[4] into the same record, after the primary leg's timing
+        torch.cuda.empty_cache()
+        result["also"] = also_legs(args)
     if rank == 0:
         print(json.dumps(_finite(result), allow_nan=False), flush=True)
     if world > 1:

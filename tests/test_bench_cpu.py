@@ -55,6 +55,47 @@ def test_spawn_ranks_sets_the_rendezvous_and_reports_the_worst_exit(tmp_path, mo
     assert time.time() - t0 < 30
 
 
+def test_also_legs_schema_and_failure_handling():
+    """The default one-GPU run appends configs[1] (SetAbstraction forward) and configs[4] (FixMatch+NTM iteration) under
+    `also`: each leg = the child's own JSON line cut down to the contract's fields; a failing child is recorded, not fatal."""
+    bench = _load_bench()
+    seen = []
+
+    class R:
+        def __init__(self, rc, out, err=""):
+            self.returncode, self.stdout, self.stderr = rc, out, err
+
+    def fake_run(cmd, env=None, **kw):
+        seen.append((cmd, env))
+        wl = cmd[cmd.index("--workload") + 1]
+        if wl == "fixmatch":
+            return R(3, "", "boom")
+        line = {"metric": "point-clouds/sec", "value": 281.0, "unit": "clouds/s", "steps": 20, "warmup": 3, "ms_per_step": 3.56,
+                "dtype": "f32", "data": "synthetic", "config": {"workload": "configs[1] ..."},
+                "roofline": {"bound": "mfma", "achieved": 1.0, "peak": 157.3, "unit": "TFLOP/s", "frac": 0.006, "traffic": None},
+                "cpu_baseline": {"value": 2.1, "unit": "clouds/s", "cores": 16, "kind": "port", "sample": "12 steps"},
+                "n_gpus": 1, "hot_path": {"dropped": True}}
+        return R(0, "noise\n" + json.dumps(line) + "\n")
+
+    class A:
+        steps, warmup, no_cpu_baseline = 20, 5, False
+    os.environ["RANK"] = "0"
+    try:
+        out = bench.also_legs(A, run=fake_run)
+    finally:
+        del os.environ["RANK"]
+    assert set(out) == {"sa", "fixmatch"}
+    sa = out["sa"]
+    for k in ("steps", "ms_per_step", "value", "roofline", "cpu_baseline", "config", "metric", "unit"):
+        assert k in sa, k
+    assert "hot_path" not in sa and sa["roofline"]["frac"] == 0.006 and sa["command"].startswith("python bench.py --gpus 1 --no-also")
+    assert out["fixmatch"]["error"].startswith("exit 3")
+    for cmd, env in seen:
+        assert "--no-also" in cmd and "RANK" not in env          # a child never recurses and never inherits a rendezvous
+    fm = [c for c, _ in seen if "fixmatch" in c][0]
+    assert fm[fm.index("--steps") + 1] == "10" and fm[fm.index("--warmup") + 1] == "3"
+
+
 def test_trace_window_summarises_only_the_steady_state(tmp_path):
     rows = ["Kind,Agent_Id,Queue_Id,Stream_Id,Thread_Id,Dispatch_Id,Kernel_Id,Kernel_Name,Correlation_Id,Start_Timestamp,End_Timestamp"]
     t = 0

@@ -262,7 +262,7 @@ def test_bench_one_gpu_line_has_both_modes_or_says_why_not(packet_capture_env):
     if packet_capture_env is not None:
         env["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = packet_capture_env
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--clouds", "2", "--steps", "3", "--warmup", "1",
-                        "--points", "8192", "--no-cpu-baseline", "--no-dense-reference"], env=env, capture_output=True, text=True,
+                        "--points", "8192", "--no-cpu-baseline", "--no-dense-reference", "--no-also"], env=env, capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
