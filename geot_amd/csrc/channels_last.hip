@@ -51,17 +51,7 @@ constexpr int CL_MAX_THREADS = 1024;
 // Workgroups per launch: every row costs the same, so the launch is ONE round of co-resident workgroups -- CUs x the
 // workgroups of cl_block(c4) threads a CU holds at <= 64 registers (8 waves per SIMD) -- each with one contiguous run of
 // rows (a second, partly filled round is a ~20 % tail at ~1.6 rounds: measured).  At least 16 rows per workgroup.
-static inline int cl_cus()
-{
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
-    return cus;
-}
+static inline int cl_cus() { return device_cus(); }     // per device (geot_common.h)
 static inline int cl_tiles_for(long long rows, int c)
 {
     const int waves = (c / 4 + 63) / 64;
@@ -491,9 +481,9 @@ static int fp_front_cl_blocks_of(int block)
 }
 static int fp_front_cl_tiles(long long rows, int c, int cs)
 {
-    static int cache[CL_MAX_SKIP + 1][CL_MAX_THREADS / 64 + 1];   // [cs][waves] -> workgroups per CU
+    static int cache[GEOT_DEV_SLOTS][CL_MAX_SKIP + 1][CL_MAX_THREADS / 64 + 1];   // [device][cs][waves] -> workgroups per CU
     const int block = cl_block(c / 4), waves = block / 64;
-    int &per_cu = cache[cs][waves];
+    int &per_cu = cache[device_slot()][cs][waves];
     if (!per_cu) {
         switch (cs) {
         case 0: per_cu = fp_front_cl_blocks_of<0>(block); break;

@@ -1876,15 +1876,9 @@ GEOT_EXPORT int geot_gather_rows_csr_cl(int b, int c, int L, int m, int nt, cons
     const RixLayout r = rix_layout(b, L, m, nt);
     if (r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL) return hipErrorInvalidValue;
     const int c4 = c / 4, slabs = gr_slabs(c4), waves = (c4 / slabs + 63) / 64;
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
-    }
-    static int per_cu_of[1024 / 64 + 1];                       // [waves] -> resident workgroups per CU
-    int &per_cu = per_cu_of[waves];
+    const int cus = device_cus();
+    static int per_cu_of[GEOT_DEV_SLOTS][1024 / 64 + 1];       // [device][waves] -> resident workgroups per CU
+    int &per_cu = per_cu_of[device_slot()][waves];
     if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_rows_csr_cl_kernel, waves * 64, 0) != hipSuccess || per_cu < 1))
         per_cu = 1;
     long long grid = (long long)cus * per_cu * gr_rounds(c4);  // rounds of co-resident workgroups, equal shares of the targets
@@ -1908,17 +1902,9 @@ GEOT_EXPORT int geot_gather_rows_csr_bn_cl(int b, int c, int L, int m, int nt, i
     const RixLayout r = rix_layout(b, L, m, nt);
     if (r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL) return hipErrorInvalidValue;
     const int c4 = c / 4, slabs = gr_slabs(c4), waves = (c4 / slabs + 63) / 64;
-    int cus = 256;
-    {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        static int cached = 0;
-        if (!cached && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            cached = prop.multiProcessorCount;
-        if (cached) cus = cached;
-    }
-    static int per_cu_of[1024 / 64 + 1];
-    int &per_cu = per_cu_of[waves];
+    const int cus = device_cus();
+    static int per_cu_of[GEOT_DEV_SLOTS][1024 / 64 + 1];
+    int &per_cu = per_cu_of[device_slot()][waves];
     if (!per_cu && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gather_rows_csr_bn_cl_kernel, waves * 64, 0) != hipSuccess || per_cu < 1))
         per_cu = 1;
     long long grid = (long long)cus * per_cu * gr_rounds(c4);

@@ -285,4 +285,14 @@ static inline int device_cus()
     return n;
 }
 
+// slot of the current device in the launchers' small per-device caches (occupancy per block size, ...): results of
+// hipOccupancy* / device properties are looked up once PER DEVICE, never shared across devices of a mixed node
+constexpr int GEOT_DEV_SLOTS = 16;
+static inline int device_slot()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev % GEOT_DEV_SLOTS;
+}
+
 } // namespace geot

@@ -143,6 +143,7 @@ class _Graphed:
                 out = fn()
             self.node_types[name] = kinds = streams.node_types(graph)
             if self.kernel_only and set(kinds) - {"kernel"} and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
+                import geot_amd
                 del graph
                 raise RuntimeError(
                     "graph_step: graph %s holds %s; unless the launcher exported %s=0 (before the HIP runtime initialises) only "

@@ -99,7 +99,9 @@ class PointnetSAModuleVotes(nn.Module):
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, inds: torch.Tensor = None):
         """xyz (B,N,3), features (B,C,N) -> (new_xyz (B,npoint,3), new_features (B,mlp[-1],npoint), inds)."""
         xyz_flipped = xyz.transpose(1, 2).contiguous()
-        if inds is None:
+        if self.npoint is None:
+            inds = None                     # GroupAll: nothing is sampled (the reference would hand None to its FPS here)
+        elif inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
             assert inds.shape[1] == self.npoint
