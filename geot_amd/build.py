@@ -52,9 +52,14 @@ def build(force=False, verbose=False, variant="exact"):
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    # lab sweeps (tools/lab/*.sh): GEOT_LAB_KERNELS=tools/lab/kernels takes a file from there when it exists -- the copies that
+    # still carry the knock-out / tuning switches the product sources no longer have
+    lab_dir = os.environ.get("GEOT_LAB_KERNELS")
     jobs = []
     for s in srcs:
         src = os.path.join(CSRC, s)
+        if lab_dir and os.path.exists(os.path.join(ROOT, lab_dir, s)):
+            src = os.path.join(ROOT, lab_dir, s)
         obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + hdrs):
             jobs.append([hipcc] + flags + ["-c", src, "-o", obj])

@@ -1,4 +1,5 @@
-"""FPS kernel lab (developer tool): builds fps.hip variants with -DGEOT_LAB_* switches,
+"""(Builds the LAB COPY tools/lab/kernels/fps.hip: the product source carries no knock-out switches since round 5.)
+FPS kernel lab (developer tool): builds fps.hip variants with -DGEOT_LAB_* switches,
 times them on the GPU and prints pruning statistics.  Not part of the product.
 
     python tools/fps_lab.py build     # here (no GPU needed)
@@ -30,7 +31,7 @@ def build():
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(ROOT, "geot_amd", "csrc")] + flags + \
-              [os.path.join(ROOT, "geot_amd", "csrc", "fps.hip"), "-o", out]
+              [os.path.join(ROOT, "tools", "lab", "kernels", "fps.hip"), "-o", out]
         subprocess.check_call(cmd)
         print("built", out)
 

@@ -1,4 +1,5 @@
-"""Gather-gradient lab (developer tool): builds gather_group.hip variants with -DGEOT_GG_LAB_* switches that remove
+"""(Builds the LAB COPY tools/lab/kernels/gather_group.hip: the product source carries no knock-out switches since round 5.)
+Gather-gradient lab (developer tool): builds gather_group.hip variants with -DGEOT_GG_LAB_* switches that remove
 one phase of the reverse-index gather at a time and times the prop0 interpolation gradient
 (B x 1536 x 24000 -> 8192).  Results of the variants are garbage by construction; only the timing matters.
 
@@ -39,7 +40,7 @@ def build():
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(ROOT, "geot_amd", "csrc")] + flags + \
-              [os.path.join(ROOT, "geot_amd", "csrc", "gather_group.hip"), "-o", out]
+              [os.path.join(ROOT, "tools", "lab", "kernels", "gather_group.hip"), "-o", out]
         subprocess.check_call(cmd)
         print("built", out)
 

@@ -13,7 +13,7 @@ if [ -n "${OLD_SRC:-}" ] && [ -s "$OLD_SRC" ]; then      # OLD_SRC: a copy of an
   cp "$NEW" geot_amd/csrc/edgeconv.hip
 fi
 for v in "" "-DGEOT_EC_LAB_LG=0" "-DGEOT_EC_LAB_TG=8" "-DGEOT_EC_LAB_E=8 -DGEOT_EC_LAB_TG=2" "-DGEOT_EC_LAB_NOWALK" "-DGEOT_EC_LAB_NOSTAGE" "-DGEOT_EC_LAB_NOLDSREAD" "-DGEOT_EC_LAB_NOREV"; do
-  GEOT_EXTRA_HIPCC_FLAGS="$v" python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
+  GEOT_LAB_KERNELS=tools/lab/kernels GEOT_EXTRA_HIPCC_FLAGS="$v" python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
   echo "== flags: ${v:-default (TG 4, E 4, lanes per target from the mean list length)}"; run
 done
 python -m geot_amd.build --force > /dev/null 2>&1

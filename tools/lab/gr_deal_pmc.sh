@@ -3,7 +3,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 for v in "-DGEOT_GR_LAB_SHARES" ""; do
   cd $GRAFT_REPO_ROOT
-  GEOT_EXTRA_HIPCC_FLAGS="$v" python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
+  GEOT_LAB_KERNELS=tools/lab/kernels GEOT_EXTRA_HIPCC_FLAGS="$v" python -m geot_amd.build --force > /dev/null 2>&1 || echo BUILD FAILED
   echo "== ${v:-default: targets dealt round-robin inside an XCD}"
   cd /tmp && export TMPDIR=/tmp
   for CTR in "FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do

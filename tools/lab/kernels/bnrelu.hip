@@ -190,6 +190,7 @@ __global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int 
     __shared__ float wb[CH][FP_MAX_SKIP];
     __shared__ float red[FP_THREADS / 64][CH][2];
     const int bi = blockIdx.z, c0 = blockIdx.y * CH, nch = min(CH, c - c0);
+#ifndef GEOT_FP_LAB_NOTABLE
     {
         const float *src = A + ((size_t)bi * c + c0) * m;
         const int count = nch * m;
@@ -201,6 +202,7 @@ __global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int 
             for (int e = threadIdx.x; e < count; e += FP_THREADS) fp_rows[e] = src[e];
         }
     }
+#endif
     if (threadIdx.x < CH * FP_MAX_SKIP) {
         const int l = threadIdx.x / FP_MAX_SKIP, k = threadIdx.x % FP_MAX_SKIP;
         wb[l][k] = (l < nch && k < cs) ? Wb[(size_t)(c0 + l) * cs + k] : 0.f;
@@ -234,7 +236,10 @@ __global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int 
             }
         }
     }
-    constexpr int U = 2;
+#ifndef GEOT_FP_LAB_U
+#define GEOT_FP_LAB_U 2
+#endif
+    constexpr int U = GEOT_FP_LAB_U;
     for (int eb = e0 + threadIdx.x; eb < e1; eb += U * FP_THREADS) {
         int ii[U][3];
         float ww[U][3], sk[U][FP_MAX_SKIP];
@@ -257,13 +262,21 @@ __global__ __launch_bounds__(FP_THREADS) void fp_front_kernel(int c, int m, int 
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int e = eb + u * FP_THREADS;
+#ifdef GEOT_FP_LAB_NOLDS
+                    float v = __int_as_float(ii[u][0]) * ww[u][0];
+                    v = v + __int_as_float(ii[u][1]) * ww[u][1];
+                    v = v + __int_as_float(ii[u][2]) * ww[u][2];
+#else
                     float v = R[ii[u][0]] * ww[u][0];
                     v = v + R[ii[u][1]] * ww[u][1];
                     v = v + R[ii[u][2]] * ww[u][2];           // ((p0 w0 + p1 w1) + p2 w2): three_interpolate's order
+#endif
 #pragma unroll
                     for (int k = 0; k < FP_MAX_SKIP; ++k) v = fmaf(wb[l][k], sk[u][k], v);
                     if (e < e1) {
+#ifndef GEOT_FP_LAB_NOSTORE
                         y[((size_t)bi * c + c0 + l) * n + e] = v;
+#endif
                         const float d = v - piv[l];
                         s[l] += d;
                         ss[l] = fmaf(d, d, ss[l]);

@@ -27,11 +27,21 @@ namespace geot {
 
 typedef float cl_f4 __attribute__((ext_vector_type(4)));
 // Row stores: the rows these kernels write are not read again before the whole tensor has gone by, so they should not
-// take L2 capacity from the rows being gathered: non-temporal (plain, sc1 and sc0 sc1 stores measured no better; the lab copy
-// tools/lab/kernels/channels_last.hip keeps the switch).
+// take L2 capacity from the rows being gathered.  GEOT_CL_LAB_STORE (lab): 0 nt, 1 plain, 2 sc1, 3 sc0 sc1.
+#ifndef GEOT_CL_LAB_STORE
+#define GEOT_CL_LAB_STORE 0
+#endif
 __device__ __forceinline__ void cl_store(cl_f4 v, cl_f4 *p)
 {
+#if GEOT_CL_LAB_STORE == 1
+    *p = v;
+#elif GEOT_CL_LAB_STORE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#elif GEOT_CL_LAB_STORE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+#else
     __builtin_nontemporal_store(v, p);
+#endif
 }
 #define CL_LD(p) __builtin_nontemporal_load(p)
 #define CL_ST(v, p) cl_store(v, p)
@@ -59,7 +69,13 @@ static inline int cl_block(int c4) { return (c4 + 63) & ~63; }
 // weights, skip values, output row) is staged in LDS by the whole workgroup in one coalesced pass, then every row costs
 // 3 uniform LDS reads, 3 row loads (scalar base + lane offset), ~24 packed-fp32 operations and one row store.
 constexpr int CL_STAGE = 128;
-constexpr int CL_FP_U = 2, CL_FP_STAGES = 2;   // rows per group, groups in flight + 1
+#ifndef GEOT_CL_LAB_U
+#define GEOT_CL_LAB_U 2
+#endif
+#ifndef GEOT_CL_LAB_STAGES
+#define GEOT_CL_LAB_STAGES 2
+#endif
+constexpr int CL_FP_U = GEOT_CL_LAB_U, CL_FP_STAGES = GEOT_CL_LAB_STAGES;   // rows per group, groups in flight + 1
 
 template <int U>
 __device__ __forceinline__ void fp_front_cl_load(int i, int c4, int q, const cl_f4 *__restrict__ a, const int (*s_row)[3],

@@ -405,7 +405,13 @@ __global__ __launch_bounds__(256) void edge_rix_place_kernel(long long total, lo
 //   the walk's three dependent round trips overlap the row loads.
 // A target's sum has a fixed order (its lanes' shares ascending, then an xor butterfly over the lanes): reproducible; with
 // lg = 0 it is the ascending order of the plain walk.
-constexpr int EC_TG = 4, EC_E = 4, EC_SU = 4;
+#ifndef GEOT_EC_LAB_TG
+#define GEOT_EC_LAB_TG 4
+#endif
+#ifndef GEOT_EC_LAB_E
+#define GEOT_EC_LAB_E 4
+#endif
+constexpr int EC_TG = GEOT_EC_LAB_TG, EC_E = GEOT_EC_LAB_E, EC_SU = 4;
 
 template <bool K4, int CH>
 __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
@@ -443,7 +449,11 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
 #pragma unroll
         for (int t = 0; t < EC_TG; ++t) {
 #pragma unroll
+#ifdef GEOT_EC_LAB_NOREV
+            for (int e = 0; e < EC_E; ++e) pid[t][e] = (a0[t] + (e << lg)) & 8191;
+#else
             for (int e = 0; e < EC_E; ++e) pid[t][e] = rev[max(min(a0[t] + (e << lg), a1[t] - 1), 0)];
+#endif
         }
     };
     if (n1 > n0) request(slot);
@@ -462,7 +472,11 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
         if (l < nch) {
             const float gm = gamma[c0 + l], bt = beta[c0 + l], us = -s2[l] * rstd[l];
             const size_t base = ((size_t)bi * c + c0 + l) * nq;
+#ifdef GEOT_EC_LAB_NOSTAGE
+            for (int i0 = threadIdx.x; i0 < min(nq, 1024); i0 += EC_SU * EC_THREADS) {
+#else
             for (int i0 = threadIdx.x; i0 < nq; i0 += EC_SU * EC_THREADS) {
+#endif
                 float ys[EC_SU], go[EC_SU], qq[EC_SU];
                 uint8_t jj[EC_SU];
 #pragma unroll
@@ -490,6 +504,10 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
     if (n1 <= n0) return;
     while (true) {
         float acc[EC_TG][CH];
+#ifdef GEOT_EC_LAB_NOWALK
+#pragma unroll
+        for (int t = 0; t < EC_TG; ++t) { a1[t] = a0[t]; }
+#endif
 #pragma unroll
         for (int t = 0; t < EC_TG; ++t) {
 #pragma unroll
@@ -502,8 +520,12 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
 #pragma unroll
                 for (int l = 0; l < CH; ++l) {
                     if (l < nch) {
+#ifdef GEOT_EC_LAB_NOLDSREAD
+                        const float v = __int_as_float(i + j + l);
+#else
                         const float2 au = AU[(size_t)l * nq + i];
                         const float v = (J[(size_t)l * nq + i] == (uint8_t)j ? au.x : 0.f) + au.y;
+#endif
                         acc[t][l] = in ? acc[t][l] + v : acc[t][l];
                     }
                 }
@@ -512,13 +534,21 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
 #pragma unroll
         for (int t = 0; t < EC_TG; ++t) {
             for (int e = a0[t] + (EC_E << lg); e < a1[t]; e += step) {          // the tail of a long share
+#ifdef GEOT_EC_LAB_NOREV
+                const int p = e & 8191;
+#else
                 const int p = rev[e];
+#endif
                 const int i = K4 ? (p >> 2) : (p / k), j = K4 ? (p & 3) : (p - i * k);
 #pragma unroll
                 for (int l = 0; l < CH; ++l) {
                     if (l < nch) {
+#ifdef GEOT_EC_LAB_NOLDSREAD
+                        acc[t][l] += __int_as_float(i + j + l);
+#else
                         const float2 au = AU[(size_t)l * nq + i];
                         acc[t][l] += (J[(size_t)l * nq + i] == (uint8_t)j ? au.x : 0.f) + au.y;
+#endif
                     }
                 }
             }
@@ -548,26 +578,36 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
 // channels per forward workgroup: rows of P within 64 KB of LDS so that two workgroups share a CU (one's staging under the
 // other's streaming) and at most 4 (measured at 8 clouds, Nk = 512 / 4096 / 8192: 8 channels = 131 KB, one workgroup per
 // CU, 492 us per step; <= 4: 466; <= 2: 448 -- profiles/r03_edge_sweep.txt); longer rows take what the CU's LDS holds
+#ifndef GEOT_EC_LAB_FCH
+#define GEOT_EC_LAB_FCH 4
+#endif
 static int ec_fwd_ch(int nk)
 {
     int fit = 64 * 1024 / ((int)sizeof(float) * nk);
     if (fit < 1) fit = EC_LDS_BYTES / ((int)sizeof(float) * nk);
-    if (fit > 4) fit = 4;
+    if (fit > GEOT_EC_LAB_FCH) fit = GEOT_EC_LAB_FCH;
     return fit >= 8 ? 8 : (fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0)));
 }
+#ifndef GEOT_EC_LAB_CH
+#define GEOT_EC_LAB_CH 4
+#endif
 static int ec_bwd_ch(int nq)
 {
     int fit = EC_LDS_BYTES / (9 * nq);
-    if (fit > 4) fit = 4;
+    if (fit > GEOT_EC_LAB_CH) fit = GEOT_EC_LAB_CH;
     return fit >= 4 ? 4 : (fit >= 2 ? 2 : (fit >= 1 ? 1 : 0));
 }
 // lanes per target in the dP walk (log2): a lane's share of the mean list is about EC_E pairs
 static int ec_lanes_log2(int nq, int nk, int k)
 {
+#ifdef GEOT_EC_LAB_LG
+    return GEOT_EC_LAB_LG;
+#else
     const long long mean_len = ((long long)nq * k + nk - 1) / nk;
     int lg = 0;
     while (lg < 3 && (long long)(3 * EC_E) << lg < mean_len) ++lg;      // measured: a mean of 8 is best left to one lane
     return lg;
+#endif
 }
 static int ec_slices(int b, int c, int ch, int n)
 {

@@ -188,6 +188,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(
 //  kernel (and to the reference): skipping is only ever a proven no-op.
 // ===========================================================================
 // ---- developer lab hooks (tools/fps_lab.py builds variants with -DGEOT_LAB_*) ----------
+#if defined(GEOT_LAB_STATS) || defined(GEOT_LAB_STAMPS)
+__device__ unsigned long long geot_fps_dbg[8];
+#endif
 constexpr int FP_CELLS = 4096;
 constexpr int FP_MAX_N = 768 * 32;
 
@@ -508,8 +511,21 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
     // committed samples of the current round: lane u holds sample u (read back with v_readlane)
     float qxv = P[0], qyv = P[1], qzv = P[2];
     int Tn = 1, par = 0;
+#ifdef GEOT_LAB_STAMPS
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, t0, t1, rounds = 0;
+    unsigned long long w0 = __builtin_readcyclecounter(), wredo = 0, nredo = 0;
+    __shared__ unsigned int lab_max;
+    if (tid == 0) lab_max = 0;
+#define GEOT_STAMP(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
+#else
 #define GEOT_STAMP(acc) do {} while (0)
+#endif
+#ifdef GEOT_LAB_STATS
+#define GEOT_APPLY_STAT(mask) \
+    if (lane == 0) { atomicAdd(&geot_fps_dbg[0], (unsigned long long)__popcll(mask)); atomicAdd(&geot_fps_dbg[1], 1ull); }
+#else
 #define GEOT_APPLY_STAT(mask)
+#endif
     // one committed sample: box test by lanes (= slots), then update of the surviving slots
 #define GEOT_APPLY(AX, AY, AZ, REDO)                                                                   \
     do {                                                                                               \
@@ -539,6 +555,9 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
     int j = 1, phase = 0, ua = 0, ub = 1;
     bool redo_acc = false, early = false, done = false;
     for (;;) {
+#ifdef GEOT_LAB_STAMPS
+        t0 = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
         for (int u = ua; u < ub; ++u) {
             const float ax = read_lane(qxv, u), ay = read_lane(qyv, u), az = read_lane(qzv, u);
@@ -547,6 +566,9 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
         if (done) break;
         if (phase == 0) {
             GEOT_STAMP(tA);
+#ifdef GEOT_LAB_STAMPS
+            ++rounds;
+#endif
             // -- this wave's candidate + runner-up bound: recomputed only when its slot was touched
             if (!cand_ok || redo_acc) {
                 cand_ok = true;
@@ -585,6 +607,13 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
                 if (ckey == KEY_NONE) cM = -1;
                 else cV2 = max(max(m2, ins), -1);
             }
+#ifdef GEOT_LAB_STAMPS
+            {
+                unsigned long long work = __builtin_readcyclecounter() - w0;
+                if (redo_acc) { wredo += work; ++nredo; }
+                if (lane == 0) atomicMax(&lab_max, (unsigned int)work);
+            }
+#endif
             redo_acc = false;
             GEOT_STAMP(tB);
             if (lane == 0) {
@@ -689,6 +718,9 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
             const FpsEntry2 *cq = &srt[ln < TMAX ? ln : 0]; // lane u <- sample u (stale beyond Tn: unused)
             qxv = cq->x; qyv = cq->y; qzv = cq->z;
             Tn = __builtin_amdgcn_readfirstlane(res_tn);
+#ifdef GEOT_LAB_STATS
+            if (tid == 0) { atomicAdd(&geot_fps_dbg[2], (unsigned long long)Tn); atomicAdd(&geot_fps_dbg[3], 1ull); }
+#endif
             j += Tn;
             // The reference's temp buffer ends as "min-distance to samples 0..m-2": the last pick of the
             // whole run is never applied.
@@ -697,10 +729,22 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
             ub = done ? Tn - 1 : Tn;
             phase = 0;
             GEOT_STAMP(tD);
+#ifdef GEOT_LAB_STAMPS
+            if (tid == 0) { tE += lab_max; lab_max = 0; } // lab_max was final at barrier 1; next atomics come after this
+            w0 = __builtin_readcyclecounter();
+#endif
         }
     }
 #undef GEOT_APPLY
 #undef GEOT_APPLY_STAT
+#ifdef GEOT_LAB_STAMPS
+    if (lane == 0) {
+        atomicAdd(&geot_fps_dbg[0], tA); atomicAdd(&geot_fps_dbg[1], tB); atomicAdd(&geot_fps_dbg[2], tC);
+        atomicAdd(&geot_fps_dbg[3], tD); atomicAdd(&geot_fps_dbg[4], tE); atomicAdd(&geot_fps_dbg[5], (unsigned long long)(m - 1));
+        atomicAdd(&geot_fps_dbg[7], (wredo << 24) | nredo); // lab only: both fit (cycles < 2^40, rounds < 2^24)
+        if (tid == 0) atomicAdd(&geot_fps_dbg[6], rounds);
+    }
+#endif
 #undef GEOT_STAMP
     } else {
     // This wave's candidate, wave-uniform, carried across rounds.  Min-distances only ever
@@ -710,10 +754,18 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
     float cx = 0.f, cy = 0.f, cz = 0.f;
     bool cand_ok = false;
 
+#ifdef GEOT_LAB_STAMPS
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, tE = 0, t0, t1;
+#define GEOT_STAMP(acc) do { t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1; } while (0)
+#else
 #define GEOT_STAMP(acc) do {} while (0)
+#endif
     float qx = P[0], qy = P[1], qz = P[2];
     int r3 = 1; // j % 3
     for (int j = 1; j < m; ++j) {
+#ifdef GEOT_LAB_STAMPS
+        t0 = __builtin_readcyclecounter();
+#endif
         // -- which of my wave's slots can the new sample change?
         float dx = fmaxf(fmaxf(bx0 - qx, qx - bx1), 0.f);
         float dy = fmaxf(fmaxf(by0 - qy, qy - by1), 0.f);
@@ -721,6 +773,14 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
         float lb2 = dx * dx + dy * dy + dz * dz;
         bool act = !(lb2 > __int_as_float(smax) * 1.00001f);
         unsigned long long mask = __ballot(act);
+#ifdef GEOT_LAB_STATS
+        if (lane == 0) {
+            atomicAdd(&geot_fps_dbg[0], (unsigned long long)__popcll(mask));
+            atomicAdd(&geot_fps_dbg[1], 1ull);
+            if (mask) atomicAdd(&geot_fps_dbg[2], 1ull);
+            if (!cand_ok || (cslot >= 0 && ((mask >> cslot) & 1ull))) atomicAdd(&geot_fps_dbg[3], 1ull);
+        }
+#endif
         const bool redo = !cand_ok || (cslot >= 0 && ((mask >> cslot) & 1ull));
         GEOT_STAMP(tA);
         while (mask) {
@@ -790,6 +850,12 @@ __global__ __launch_bounds__(NT) void fps_pruned_kernel(
         if (tid == 0) out[j] = base + (int)old;
         GEOT_STAMP(tE);
     }
+#ifdef GEOT_LAB_STAMPS
+    if (lane == 0) {
+        atomicAdd(&geot_fps_dbg[0], tA); atomicAdd(&geot_fps_dbg[1], tB); atomicAdd(&geot_fps_dbg[2], tC);
+        atomicAdd(&geot_fps_dbg[3], tD); atomicAdd(&geot_fps_dbg[4], tE); atomicAdd(&geot_fps_dbg[5], (unsigned long long)(m - 1));
+    }
+#endif
     }
 #pragma unroll 1
     for (int i = 0; i < PPT; ++i) {
@@ -858,6 +924,17 @@ static int ref_log2_block(int work, int cap)
 
 } // namespace geot
 
+#if defined(GEOT_LAB_STATS) || defined(GEOT_LAB_STAMPS)
+GEOT_EXPORT int geot_lab_read_stats(unsigned long long *out8, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(geot::geot_fps_dbg), 8 * sizeof(unsigned long long));
+    if (e == hipSuccess && reset) {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(geot::geot_fps_dbg), z, sizeof(z));
+    }
+    return e;
+}
+#endif
 
 GEOT_EXPORT int geot_furthest_point_sampling(int b, int n, int m, const float *xyz, float *temp,
                                              int *idxs, int block_cap, int skip_origin, void *stream)

@@ -681,9 +681,14 @@ __global__ __launch_bounds__(TLDS_THREADS, MINB) void table_gather_csr_parts_ker
     for (int part = 0; part < Q; ++part) {
         const int p0 = part * partlen, plen = min(partlen, L - p0);
         if (part) __syncthreads(); // the previous part's rows have been read by everyone
+#ifndef GEOT_GG_LAB_NOSTAGE
         for (int l = 0; l < nch; ++l)
             tlds_load_rows(tlds_rows + (size_t)l * partlen, grad_out + (size_t)bi * src_bstride + (size_t)(c0 + l) * L + p0, plen);
+#endif
         __syncthreads();
+#ifdef GEOT_GG_LAB_NOWALK
+        continue;
+#endif
         const int *offp = off + ((size_t)bi * Q + part) * m;
 #pragma unroll
         for (int g = 0; g < TPT; g += TP) {
@@ -704,8 +709,13 @@ __global__ __launch_bounds__(TLDS_THREADS, MINB) void table_gather_csr_parts_ker
                     for (int u = 0; u < RU; ++u) {
                         const int q = a[p] + it + u;
                         const bool in = q < z[p];
+#ifdef GEOT_GG_LAB_NOIDX
+                        e[p][u] = in ? (q & 4095) : 0;
+                        w[p][u] = in ? 1.f : 0.f;
+#else
                         e[p][u] = in ? rev[q] : 0;
                         w[p][u] = in ? (WEIGHTED ? revw[q] : 1.f) : 0.f;
+#endif
                     }
 #pragma unroll
                 for (int p = 0; p < TP; ++p)
@@ -714,7 +724,11 @@ __global__ __launch_bounds__(TLDS_THREADS, MINB) void table_gather_csr_parts_ker
                         if (l < nch) {
 #pragma unroll
                             for (int u = 0; u < RU; ++u)
+#ifdef GEOT_GG_LAB_NOLDSREAD
+                                acc[g + p][l] = fmaf(w[p][u], __int_as_float(e[p][u]), acc[g + p][l]);
+#else
                                 acc[g + p][l] = fmaf(w[p][u], tlds_rows[(size_t)l * partlen + e[p][u]], acc[g + p][l]);
+#endif
                         }
                     }
             }
@@ -865,6 +879,7 @@ __global__ __launch_bounds__(SELL_THREADS) void table_gather_sell_kernel(
         const int bq = bi * Q + part, p0 = part * partlen, plen = min(partlen, L - p0);
         if (part) __syncthreads();                       // the exchange of the previous part has been read
         // stage CH rows of this part interleaved: rows4[e] = (g[c0][e], g[c0+1][e], g[c0+2][e], g[c0+3][e])
+#ifndef GEOT_SELL_LAB_NOSTAGE
         {
             const float *g0 = grad_out + (size_t)bi * src_bstride + (size_t)c0 * L + p0;
             if (nch == CH && (L & 3) == 0 && (p0 & 3) == 0 && (((uintptr_t)g0) & 15) == 0) {
@@ -893,6 +908,7 @@ __global__ __launch_bounds__(SELL_THREADS) void table_gather_sell_kernel(
                 }
             }
         }
+#endif
         __syncthreads();
         // Walk this wave's TPT tasks (task = wave + 16 s: the sorted order puts the long tasks first, so every wave gets a
         // mix): wave-uniform trip counts, one coalesced 8-byte load and one 16-byte LDS read per entry.
@@ -908,6 +924,9 @@ __global__ __launch_bounds__(SELL_THREADS) void table_gather_sell_kernel(
             if (task < sv.ntask) {
                 const int base = sv.tbase[(size_t)bq * sv.ntask + task];
                 int len = sv.tlen[(size_t)bq * sv.ntask + task];
+#ifdef GEOT_SELL_LAB_NOWALK
+                len = 0;
+#endif
                 const uint2 *q = ent + base + lane;
                 int k = 0;
                 for (; k + 4 <= len; k += 4) {           // 4 independent 8-byte loads + 4 LDS reads in flight
@@ -1187,7 +1206,10 @@ static hipError_t scatter_via_csr(int b, int c, int m, int L, size_t src_bstride
 // 4.  One writer per output row, pairs in ascending pair order: bit-reproducible.  (csrc/channels_last.hip: the forward.)
 typedef float cl_f4 __attribute__((ext_vector_type(4)));
 constexpr int GR_CAP = 512;          // pairs staged per pass
-constexpr int GR_U = 8;   // row loads in flight per half of the software pipeline
+#ifndef GEOT_GR_LAB_U
+#define GEOT_GR_LAB_U 8
+#endif
+constexpr int GR_U = GEOT_GR_LAB_U;   // row loads in flight per half of the software pipeline
 constexpr unsigned GR_LAST = 0x80000000u;
 
 // placement for the point-major walk: pair x of target rank k goes to its slot (ascending pair id within the list) as
@@ -1234,9 +1256,16 @@ __global__ __launch_bounds__(256) void invert_order_kernel(long long total, int 
 // keeps its order: results are bit-identical to the contiguous form.  List lengths vary (0 ... 30), but a workgroup's
 // share is every nwg-th list of thousands: the sums differ by a few per cent.
 // GR_SB target slots at a time: lengths -> LDS, one-wave scan, then chunks of GR_CAP pairs are staged by binary search.
+#ifdef GEOT_GR_LAB_SHARES
+constexpr bool GR_DEAL = false;     // lab: contiguous shares of the pair stream (the first form)
+#else
 constexpr bool GR_DEAL = true;
+#endif
 constexpr int GR_SB = 512;
-constexpr int GR_GT = 2;   // consecutive targets a workgroup takes at a time
+#ifndef GEOT_GR_LAB_GT
+#define GEOT_GR_LAB_GT 2
+#endif
+constexpr int GR_GT = GEOT_GR_LAB_GT;   // consecutive targets a workgroup takes at a time
 struct GrDeal {
     int tb, te, nwg, w, nloc;       // the XCD's target range, workgroups sharing it, this one's rank, its target slots
     __device__ __forceinline__ int target(int u) const { return tb + ((u / GR_GT) * nwg + w) * GR_GT + u % GR_GT; }
@@ -1407,7 +1436,10 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_cl_kernel(int c4, int T,
 // is linear in (g, y - mean, 1), so a target's sum  sum_p w_p gy_p  =  k0 G + A Y - k0 c1 W  with  G = sum w g,
 // Y = sum w (y - mean), W = sum w, A = -k0 rstd c2: three running sums per list, the constants applied once per target.
 // gy is never written or read (1.18 GB each way at 8 x 24000 x 1536) and the bn_bwd_apply pass disappears.
-constexpr int GRB_U = 4;    // pairs (2 row loads each) in flight per half of the software pipeline
+#ifndef GEOT_GRB_LAB_U
+#define GEOT_GRB_LAB_U 4
+#endif
+constexpr int GRB_U = GEOT_GRB_LAB_U;    // pairs (2 row loads each) in flight per half of the software pipeline
 __global__ __launch_bounds__(1024) void gather_rows_csr_bn_cl_kernel(
     int c4, int T, int P, int relu, const cl_f4 *__restrict__ y, const cl_f4 *__restrict__ dz, const cl_f4 *__restrict__ scale,
     const cl_f4 *__restrict__ shift, const cl_f4 *__restrict__ mean, const cl_f4 *__restrict__ rstd, const cl_f4 *__restrict__ c1,

@@ -167,8 +167,14 @@ struct SigMfma {
 // waves per SIMD (229 registers, 77 KB of LDS per block).  512-thread blocks -- two column tiles per wave at most, the row
 // phase in two passes -- measured SLOWER: 222 us at one block per CU (244 registers), 445 us held to 128 registers for two
 // blocks per CU (181 spilled).  profiles/r03_sig_sweep.txt.
-constexpr int SIG_BWD_THREADS = 256;
-constexpr int SIG_BWD_WPS = 2;
+#ifndef GEOT_SIG_LAB_BWD_THREADS
+#define GEOT_SIG_LAB_BWD_THREADS 256
+#endif
+constexpr int SIG_BWD_THREADS = GEOT_SIG_LAB_BWD_THREADS;
+#ifndef GEOT_SIG_LAB_BWD_WPS
+#define GEOT_SIG_LAB_BWD_WPS 2
+#endif
+constexpr int SIG_BWD_WPS = GEOT_SIG_LAB_BWD_WPS;
 
 // GV float4 per thread of the gradient tile that starts at float4 index base4: loads unconditional, index clamped to the
 // last whole float4 of the buffer (a clamped value is never used)
@@ -241,6 +247,9 @@ __global__ __launch_bounds__(NT, BACKWARD ? SIG_BWD_WPS : 4) void sig_t_mean_mfm
     if (BACKWARD) {
         const long long first = (long long)blockIdx.x * SM_PTS;
         have_pre = first + SM_PTS <= total_pts;
+#ifdef GEOT_SIG_LAB_NOPREFETCH
+        have_pre = false;
+#endif
         fetch(have_pre ? first : 0);
     }
     __syncthreads();
@@ -279,7 +288,11 @@ __global__ __launch_bounds__(NT, BACKWARD ? SIG_BWD_WPS : 4) void sig_t_mean_mfm
         if (BACKWARD) {
             const long long next = (long long)i0 + (long long)gridDim.x * SM_PTS;
             have_pre = next + SM_PTS <= total_pts;
+#ifdef GEOT_SIG_LAB_NOPREFETCH
+            have_pre = false;
+#else
             fetch(have_pre ? next : 0);                   // stays in flight until the top of the next tile
+#endif
             if (wave == 0) {
 #pragma unroll
                 for (int ks = 0; ks < KP / 2; ++ks) At[r * ATS + 2 * ks + h] = a[ks];

@@ -57,6 +57,9 @@ __device__ __forceinline__ void sa_layer(const float *__restrict__ W, const floa
     }
     const float *arow = act + r * act_stride + h;
     const float *wrow = W + h * cp + r;
+#ifdef GEOT_SA_LAB_NOMFMA
+    kp = 2;
+#endif
     for (int k0 = 0; k0 < kp; k0 += 2) {
         float a = arow[k0];
 #pragma unroll
@@ -146,6 +149,9 @@ __device__ __forceinline__ void sa_pool_direct(const f32x16 (&acc)[NCT], float (
 template <int NP>
 __device__ __forceinline__ void sa_write_direct(const float (&o)[4], int g, int npoint, int c_out, float *__restrict__ out)
 {
+#ifdef GEOT_SA_LAB_NOOUT
+    if (g != 0) return;
+#endif
     const int lane = lane_id(), c = lane & 31, h = lane >> 5;
     const int bi = g / npoint, gi = g - bi * npoint;
     float *dst = out + ((size_t)bi * c_out + h * 32 + c) * npoint + gi;
@@ -165,6 +171,20 @@ __device__ __forceinline__ void sa_run_layer(const SaDesc &d, int l, const float
 {
     f32x16 acc[NCT];
     sa_layer<NCT>(P + d.woff[l], P + d.boff[l], d.kp[l], d.cp[l], (d.relu_mask >> l) & 1, act, d.act_stride, acc);
+#if defined(GEOT_SA_LAB_NOSTORE) || defined(GEOT_SA_LAB_NOPOOL)
+    {   // lab (tools/sa_lab.py): keep the accumulators alive while a phase is removed
+        float keep = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) keep += acc[ct][0] + acc[ct][15];
+        if (keep == 12345.678f) pool[0] = keep;
+    }
+#endif
+#ifdef GEOT_SA_LAB_NOSTORE
+    if (l + 1 < d.nlayers) return;
+#endif
+#ifdef GEOT_SA_LAB_NOPOOL
+    if (l + 1 == d.nlayers) return;
+#endif
     if (l + 1 < d.nlayers) sa_store_act<NCT>(acc, act, d.act_stride);
     else if (direct) sa_pool_direct<NCT>(acc, o);
     else sa_pool<NCT>(acc, pool, d.cp[l], gpt);
@@ -204,6 +224,11 @@ __global__ __launch_bounds__(MAXW >= 8 ? 512 : SA_WAVES * 64) void sa_group_mlp_
         // output column then land next to each other in the SAME L2 within a few tiles and leave it as whole lines
         // (interleaving the groups over workgroups scattered every line over all eight L2s: partial-sector writes)
         auto load = [&](SaRow &R, int g) {
+#ifdef GEOT_SA_LAB_NOGATHER
+            for (int x = 0; x < 3; ++x) { R.p[x] = 0.01f * r; R.q[x] = 0.f; }
+            for (int j = 0; j < 4; ++j) R.f[j] = 0.02f * g;
+            return;
+#endif
             const int bi = g / npoint;
             const int a = idx[(size_t)g * 32 + r];
             const float *pp = xyz + ((size_t)bi * n + a) * 3, *q = new_xyz + (size_t)g * 3;

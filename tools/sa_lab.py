@@ -1,4 +1,5 @@
-"""SA-body kernel lab (developer tool): builds sa_mlp.hip variants with -DGEOT_SA_LAB_* switches that remove one
+"""(Builds the LAB COPY tools/lab/kernels/sa_mlp.hip: the product source carries no knock-out switches since round 5.)
+SA-body kernel lab (developer tool): builds sa_mlp.hip variants with -DGEOT_SA_LAB_* switches that remove one
 phase at a time (gather / epilogue stores / MFMA k-loop) and times them, to see where the non-MFMA half of the
 launch goes.  Results of the variants are garbage by construction; only the timing matters.
 
@@ -34,7 +35,7 @@ def build():
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
                "-ffp-contract=off", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
                "-I" + os.path.join(ROOT, "geot_amd", "csrc")] + flags + \
-              [os.path.join(ROOT, "geot_amd", "csrc", "sa_mlp.hip"), "-o", out]
+              [os.path.join(ROOT, "tools", "lab", "kernels", "sa_mlp.hip"), "-o", out]
         subprocess.check_call(cmd)
         print("built", out)
 
