@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 # launch instead of 7-20 ms), which graph_step accepts only for graphs of kernel nodes alone -- it inspects what it captured
 # and this file records the node counts (and falls back to the eager step if a graph is refused).  An exported
 # GEOT_GRAPH_LAUNCH / DEBUG_CLR_GRAPH_PACKET_CAPTURE wins.  (The sa / ntm --graph capture below is inspected the same way.)
-if os.environ.get("WORLD_SIZE", "1") == "1" and "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ:
+if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" not in os.environ:      # (N > 1 too: the data-parallel step replays from graphs over RCCL)
     os.environ.setdefault("GEOT_GRAPH_LAUNCH", "fast")
 import geot_amd  # noqa: E402,F401  (before torch touches the GPU: it pins the HIP runtime's graph switch, geot_amd/__init__.py)
 
@@ -447,6 +447,11 @@ def main():
     fps_clouds = B
     ddp_modules = []
     parallelism = "independent clouds per rank, no collective"
+    # N > 1: the step replayed from hipGraphs (no host on the critical path) needs its collectives captured -- RCCL only, and
+    # never in the one-GPU rehearsal over gloo.  GEOT_BENCH_DP_GRAPH=0: the eager DistributedDataParallel step as primary.
+    dp_graph = (world > 1 and not rehearsal and workload in ("model", "fixmatch") and not args.no_graph
+                and os.environ.get("GEOT_BENCH_DP_GRAPH", "1") != "0")
+    trainer_g = None
 
     if workload == "model":
         from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T, TOOTH_SEG_CFG
@@ -483,6 +488,13 @@ def main():
             cur, nxt = batches[turn[0] % 2], batches[(turn[0] + 1) % 2]
             turn[0] += 1
             return trainer(cur[0], cur[1], cur[2], next_pos=nxt[0] if lookahead else None)
+        if dp_graph:
+            # N > 1 without the host: the same model on the bare SyncBatchNorm-converted module with ONE flat gradient
+            # all-reduce between backward and optimizer (train_step.sync_only / GradSync) -- the form a hipGraph can hold
+            model_g = PointTransformer_seg_T(**TOOTH_SEG_CFG, dense=args.dense).to(dev)
+            model_g.load_state_dict(model.state_dict())
+            net_g = ts.sync_only(model_g)
+            trainer_g = ts.SupervisedStep(net_g, grad_sync=ts.GradSync([net_g], torch.distributed.group.WORLD))
     elif workload == "fixmatch":
         from geot_amd import train_step as ts
         torch.manual_seed(1609)
@@ -490,6 +502,9 @@ def main():
                                     group=torch.distributed.group.WORLD if world > 1 else None)
         if world > 1:
             ddp_modules = [trainer.model, trainer.T_predictor]
+        if dp_graph:
+            torch.manual_seed(1609)         # (the same initial weights as `trainer`)
+            trainer_g = ts.build_fixmatch(dev, graph_sync=True, group=torch.distributed.group.WORLD)
         from geot_amd.pointops.functions import pointops as pops
         patch_owner, patch_name = pops, "furthestsampling_uniform"      # the student's 8192-sample FPS: its largest kernel
         from geot_amd.openpoints.models.backbone.transformer import TOOTH_SEG_CFG
@@ -578,17 +593,28 @@ def main():
     # way; the replay 2 % behind at 4 clouds, level at 8 -- and the dominant kernel's HIP events, which the roofline block
     # needs from the timed region, can only be recorded on eager launches).
     # --graph / --no-graph force the primary mode (--no-graph also skips the replay leg).
-    can_replay = workload in ("model", "fixmatch") and world == 1 and not args.no_graph
-    use_graph = can_replay and (args.graph or workload == "fixmatch" or B <= 3)
+    can_replay = workload in ("model", "fixmatch") and (world == 1 or dp_graph) and not args.no_graph
+    # N > 1: the replay is the primary mode whenever it captures (on every rank: `agree`) -- an eager rank needs ~1.5 host cores
+    # continuously, eight of them share one host
+    use_graph = can_replay and (args.graph or workload == "fixmatch" or B <= 3 or world > 1)
     eager_step = step
     graphed = replay_step = None
     replay_refused = None
+
+    def agree(ok):
+        flag = torch.tensor([1.0 if ok else 0.0], device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        return bool(flag.item() > 0.5)
     if can_replay:
         from geot_amd import graph_step as gs
         try:
-            graphed = (gs.GraphedSupervisedStep if workload == "model" else gs.GraphedFixMatchStep)(trainer)
+            graphed = (gs.GraphedSupervisedStep if workload == "model" else gs.GraphedFixMatchStep)(
+                trainer_g if world > 1 else trainer, agree=agree if world > 1 else None)
         except RuntimeError as e:                   # e.g. packet capture left on by the environment without GEOT_GRAPH_LAUNCH=fast
             replay_refused, use_graph, can_replay = "%s: %s" % (type(e).__name__, str(e)[:600]), False, False
+        if world > 1 and not agree(graphed is not None):      # one verdict for all ranks, before any of them replays
+            replay_refused = replay_refused or "another rank could not construct its replay"
+            graphed, use_graph, can_replay = None, False, False
     if can_replay:
 
         def replay_step():
@@ -702,7 +728,9 @@ def main():
                      "host_issue_ms_per_step": 1e3 * HOST_ISSUE["s"] / k_e,
                      "host_cpu_ms_per_step": 1e3 * HOST_ISSUE["cpu_s"] / k_e, "steps": k_e,
                      "note": ("the same iterations, same model state continuing, launched kernel by kernel from the host"
-                              if use_graph else
+                              if use_graph and world == 1 else
+                              "the eager DistributedDataParallel step (25-MB buckets overlapped with the backward) on the same "
+                              "batches, its own copy of the model" if use_graph else
                               "the same iterations, same model state continuing, replayed from single-stream hipGraphs "
                               "(geot_amd/graph_step.py)")}
     for u in undo:

@@ -26,8 +26,10 @@ A learning-rate schedule reaches a captured AdamW step through memory: make `lr`
 parameter groups and fill_ it between calls (tests/test_graph_step_gpu.py); a python float is baked into the graph.
 Inputs are copied into static buffers before every replay; shapes are fixed by the first call (another shape is an error:
 build another wrapper).  The first `warmup` executions of each graph's body run eagerly over the same buffers, the next
-one captures.  DistributedDataParallel is not captured (gradient buckets and RCCL's collectives are host logic): N > 1
-runs the eager steps.
+one captures.  N > 1: DistributedDataParallel itself is not captured (its reducer is host logic); a step built on the bare
+SyncBatchNorm-converted modules with a gradient exchange of its own (train_step.sync_only / GradSync: one flat RCCL
+all-reduce between backward and optimizer, a kernel node) replays like the single-GPU one -- SyncBatchNorm's statistic
+all-reduces and the anchor all-gather of the class transition are captured where they stand.
 
 Mirrors the loop body of examples/segmentation/train.py:410-669; the reference never leaves eager mode.
 """
@@ -92,11 +94,25 @@ def _fits(dst, src, what):
 class _Graphed:
     """P / M bookkeeping shared by the two steps; subclasses supply the static buffers and the two bodies."""
 
-    def __init__(self, step, warmup=2):
+    def __init__(self, step, warmup=2, agree=None):
+        """agree(ok: bool) -> bool, for N > 1: called after every capture, BEFORE its first replay, with this rank's verdict;
+        returns the verdict of all ranks (e.g. an all-reduce MIN).  A capture one rank refuses is then refused by all of
+        them at the same point of the collective sequence -- the ranks fall back to the eager step together instead of
+        meeting each other with different collectives."""
+        self.agree = agree
         for net in (getattr(step, n, None) for n in ("model", "model_t", "T_predictor")):
             if isinstance(net, torch.nn.parallel.DistributedDataParallel):
-                raise RuntimeError("graph_step: a DistributedDataParallel model is not captured (its gradient buckets and "
-                                   "collectives are host logic); run N > 1 eagerly")
+                raise RuntimeError(
+                    "graph_step: a DistributedDataParallel model is not captured -- its reducer is host logic, and it keeps "
+                    "every parameter's AccumulateGrad node on the stream of its construction, which forks the captured "
+                    "backward (a crash in hipStreamEndCapture on this runtime).  For N > 1 hand the step the bare "
+                    "SyncBatchNorm-converted modules and a gradient exchange of its own: train_step.sync_only + GradSync "
+                    "(build_fixmatch(graph_sync=True)); over RCCL its one flat all-reduce is a kernel node of the graph")
+        if getattr(step, "grad_sync", None) is not None:
+            import torch.distributed as dist
+            if dist.get_backend(step.grad_sync.group) != "nccl":
+                raise RuntimeError("graph_step: the step's gradient exchange runs over the %r backend -- on the host, not "
+                                   "capturable; run N > 1 eagerly or over nccl (RCCL)" % dist.get_backend(step.grad_sync.group))
         import geot_amd
         # (see geot_amd/__init__.py) packet capture exported off by the launcher: anything replays; otherwise (fast mode, or the
         # switch set by the package itself, which cannot be verified) only graphs of kernel nodes do -- checked per graph
@@ -139,18 +155,28 @@ class _Graphed:
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph(keep_graph=True)         # (the hipGraph_t stays: node_types below)
             pool = self.graphs[pool_of][0].pool() if pool_of is not None else None
-            with streams.capture(graph, self.device, pool=pool):
-                out = fn()
-            self.node_types[name] = kinds = streams.node_types(graph)
-            if self.kernel_only and set(kinds) - {"kernel"} and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
-                import geot_amd
+            refusal = None
+            try:
+                with streams.capture(graph, self.device, pool=pool):
+                    out = fn()
+                self.node_types[name] = kinds = streams.node_types(graph)
+                if self.kernel_only and set(kinds) - {"kernel"} and os.environ.get("GEOT_GRAPH_UNSAFE") != "1":
+                    import geot_amd
+                    refusal = RuntimeError(
+                        "graph_step: graph %s holds %s; unless the launcher exported %s=0 (before the HIP runtime initialises) "
+                        "only kernel nodes are known to replay correctly: with graph packet capture on, eager launches between "
+                        "two replays corrupt a graph's memset / memcpy nodes -- wrong gradients, no error "
+                        "(geot_amd/__init__.py).  tools/lab/find_nonkernel_ops.py names the operators that issue "
+                        "hipMemsetAsync / hipMemcpyAsync" % (name, kinds, geot_amd.GRAPH_PACKET_CAPTURE_ENV))
+            except RuntimeError as e:
+                if self.agree is None:
+                    raise
+                refusal = e
+            if self.agree is not None and not self.agree(refusal is None) and refusal is None:
+                refusal = RuntimeError("graph_step: another rank refused its capture of graph %s; all ranks run eagerly" % name)
+            if refusal is not None:
                 del graph
-                raise RuntimeError(
-                    "graph_step: graph %s holds %s; unless the launcher exported %s=0 (before the HIP runtime initialises) only "
-                    "kernel nodes are known to replay correctly: with graph packet capture on, eager launches between two "
-                    "replays corrupt a graph's memset / memcpy nodes -- wrong gradients, no error (geot_amd/__init__.py).  "
-                    "tools/lab/find_nonkernel_ops.py names the operators that issue hipMemsetAsync / hipMemcpyAsync"
-                    % (name, kinds, geot_amd.GRAPH_PACKET_CAPTURE_ENV))
+                raise refusal
             self.graphs[name] = (graph, out)
         graph, out = self.graphs[name]
         graph.replay()
@@ -208,7 +234,7 @@ class GraphedSupervisedStep(_Graphed):
     """SupervisedStep.__call__ from hipGraphs (see the module docstring).  The returned loss is a static tensor the next
     call overwrites: clone it to keep it."""
 
-    def __init__(self, step, warmup=2, split=None):
+    def __init__(self, step, warmup=2, split=None, agree=None):
         """split: capture the iteration as two graphs sharing a memory pool -- M1 = forward, loss and the backward of the
         head and the decoder, M2 = the backward of the transformer blocks and the patch encoder + AdamW (the model cuts its
         autograd graph between the two: SupervisedStep.forward_backward_head) -- and start P between them: beside the
@@ -216,8 +242,8 @@ class GraphedSupervisedStep(_Graphed):
         when what follows the cut outlasts P (~6.3 ms whatever the batch: its FPS runs one cloud per CU): at 8 clouds the
         replay goes from 0.45 ms behind the eager step to level, at 4 clouds 21.95 -> 21.08 ms, at 3 19.37 -> 18.59; at 1 / 2
         clouds M2 is shorter than P and the step waits for it (10.1 -> 12.4, 13.6 -> 15.2 ms).  Default (None):
-        GEOT_GRAPH_SPLIT=1 / 0 if set, else split batches of at least 3 clouds."""
-        super().__init__(step, warmup)
+        GEOT_GRAPH_SPLIT=1 / 0 if set, else split batches of at least 3 clouds.  agree: see _Graphed."""
+        super().__init__(step, warmup, agree)
         env = os.environ.get("GEOT_GRAPH_SPLIT")
         self.split = bool(split) if split is not None else (None if env is None else env == "1")
         self.x = None            # static (pos, cls, target)
@@ -266,11 +292,11 @@ _P_KEYS = (("pos",), ("pos_s", "pos_w", "x_w", "cls_w", "raw_pos"))      # what 
 class GraphedFixMatchStep(_Graphed):
     """FixMatchNTMStep.__call__ from hipGraphs.  The returned losses are static tensors the next call overwrites."""
 
-    def __init__(self, step, warmup=2, split=None):
+    def __init__(self, step, warmup=2, split=None, agree=None):
         """split: as GraphedSupervisedStep -- M1 ends where the backward reaches the student's transformer blocks, P starts
         there.  Same bits, but a loss here: P is 10 ms (the teacher's forward is in it) and does not fit beside M2 -- 29.0 ->
         30.4 ms per iteration (bench.py --workload fixmatch, alternating).  Off unless split=True / GEOT_GRAPH_SPLIT=1."""
-        super().__init__(step, warmup)
+        super().__init__(step, warmup, agree)
         self.split = bool(split) if split is not None else os.environ.get("GEOT_GRAPH_SPLIT") == "1"
         self.data = self.data_u = None       # static batch dicts
         self.next = None                     # static inputs of P

@@ -177,9 +177,12 @@ def exchange_anchor_rows(v_star, class_T, group):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     pack = torch.cat([v_star.unsqueeze(1), class_T], dim=1).contiguous()
-    parts = [torch.empty_like(pack) for _ in range(world)]
-    dist.all_gather(parts, pack, group=group)
-    parts = torch.stack(parts)                                            # (W, C, 1 + C)
+    if world == 1:
+        parts = pack.unsqueeze(0)
+    else:       # ONE collective into one tensor (the list form copies W pieces out afterwards: memcpy nodes under a hipGraph capture)
+        flat = torch.empty((world * pack.shape[0], pack.shape[1]), dtype=pack.dtype, device=pack.device)
+        dist.all_gather_into_tensor(flat, pack, group=group)                # rank-major concatenation (the form gloo takes too)
+        parts = flat.view(world, pack.shape[0], pack.shape[1])              # (W, C, 1 + C)
     r_star = torch.argmax(parts[:, :, 0], dim=0)                          # first (= lowest) rank with the maximum
     cols = torch.arange(class_T.shape[0], device=class_T.device)
     return parts[r_star, cols, 1:]

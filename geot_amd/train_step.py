@@ -56,6 +56,67 @@ def ddp(module, device, sync_bn=True, unused=(), min_world=2, **kw):
     return nn.parallel.DistributedDataParallel(module, device_ids=ids, **kw)
 
 
+def sync_only(module, sync_bn=True, min_world=2):
+    """The data-parallel form of a module for a step that is REPLAYED FROM hipGraphs (geot_amd/graph_step.py): SyncBatchNorm
+    conversion as train.py:159-166 does it, but NO DistributedDataParallel wrapper -- the step exchanges its gradients itself
+    (GradSync).  Why not wrap and bypass: DDP's reducer keeps every parameter's AccumulateGrad node alive from its
+    construction on, on the stream that was current then; a backward captured on the capture stream hops to that stream and
+    back for each of them -- forks inside a capture, which this runtime answers with a crash in hipStreamEndCapture
+    (profiles/r04_graph_capture_notes.txt; reproduced with DDP in round 5)."""
+    import torch.distributed as dist
+    if sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world:
+        module = nn.SyncBatchNorm.convert_sync_batchnorm(module)
+    return module
+
+
+class GradSync:
+    """The data-parallel gradient exchange as ONE flat all-reduce, for a step that is replayed from a hipGraph
+    (geot_amd/graph_step.py): DistributedDataParallel's reducer is host logic (bucket hooks fired from the autograd engine)
+    and cannot be captured, an RCCL collective on the current stream can -- it is a kernel node.  The step holds the bare
+    (SyncBatchNorm-converted: sync_only) modules and calls this between the backward and the optimizer: every gradient that
+    exists is packed into one static fp32 buffer, divided by the world size (before the sum, as the reducer does), summed
+    over the ranks, and copied back.  108 MB at the segmentor's size: one collective instead of five 25-MB buckets; nothing
+    overlaps the backward -- the price of a host-free step (train.py:159-166 wraps the model; :646-669 is the loop this
+    replaces).  Construction broadcasts rank 0's parameters and buffers, as DDP's does."""
+
+    def __init__(self, modules, group=None, broadcast=True):
+        import torch.distributed as dist
+        modules = [m.module if hasattr(m, "module") else m for m in modules]
+        self.params = [p for m in modules for p in m.parameters() if p.requires_grad]
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.flat = None
+        self.views = None
+        self.collectives = 0
+        if broadcast and self.world > 1:
+            with torch.no_grad():
+                for m in modules:
+                    for t in list(m.parameters()) + list(m.buffers()):
+                        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+
+    def __call__(self):
+        import torch.distributed as dist
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
+        sizes = [g.numel() for g in grads]
+        if self.flat is None or self.flat.numel() != sum(sizes):
+            self.flat = torch.empty(sum(sizes), dtype=grads[0].dtype, device=grads[0].device)
+            self.views = list(torch.split(self.flat, sizes))
+        flat_grads = [g.reshape(-1) for g in grads]          # (gradients are contiguous: views, not copies)
+        torch._foreach_copy_(self.views, flat_grads)
+        if self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        dist.all_reduce(self.flat, group=self.group)
+        self.collectives += 1
+        torch._foreach_copy_(flat_grads, self.views)
+
+
+def _inner(module, bypass):
+    """The module a step calls: DDP's wrapped module when the step exchanges its gradients itself (GradSync)."""
+    return module.module if (bypass and hasattr(module, "module")) else module
+
+
 def parameter_groups(model, weight_decay=1e-4, skip_list=()):
     """The two AdamW parameter groups of the reference's optimizer factory (openpoints/optim/optim_factory.py:66-119
     get_parameter_groups, reached through build_optimizer_from_cfg :190-198 with its default filter_bias_and_bn=True,
@@ -129,15 +190,19 @@ def _lookahead_at_blocks(segmentor, default):
 
 
 class SupervisedStep:
-    def __init__(self, model, lr=1e-3, weight_decay=1e-4, grad_norm_clip=None):
+    def __init__(self, model, lr=1e-3, weight_decay=1e-4, grad_norm_clip=None, grad_sync=None):
         self.model = model
         self.criterion = Poly1FocalLoss()
         self.optimizer = make_optimizer(model, lr, weight_decay)
         self.clip = grad_norm_clip
         self._geometry = None          # coordinate-only work of the next batch, queued by the previous call
+        self.grad_sync = grad_sync     # a GradSync: the step exchanges its gradients itself (bare modules: sync_only)
 
     def optimizers(self):
         return [self.optimizer]
+
+    def sync_modules(self):
+        return [self.model]
 
     def __call__(self, pos, cls, target, next_pos=None):
         """pos (B,N,3) f32, cls (B,1) int64 jaw id, target (B,N) int64 -> detached loss.
@@ -161,12 +226,14 @@ class SupervisedStep:
     def forward_loss(self, pos, cls, target, geometry=None):
         """The first half of an iteration: the forward and the loss (with its autograd graph)."""
         _mode(self.model, True)
-        logits = self.model(pos, pos.transpose(1, 2).contiguous(), cls, geometry=geometry)[0]
+        logits = _inner(self.model, self.grad_sync is not None)(pos, pos.transpose(1, 2).contiguous(), cls, geometry=geometry)[0]
         return self.criterion(logits, target)
 
     def backward_update(self, loss):
         """The second half: backward, clipping, the optimizer -> the detached loss."""
         loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync()
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
         self.optimizer.step()
@@ -195,6 +262,8 @@ class SupervisedStep:
         """The rest of the backward (the blocks, the patch encoder), clipping, the optimizer."""
         if rest is not None:
             torch.autograd.backward(rest[0], rest[1])
+        if self.grad_sync is not None:
+            self.grad_sync()
         if self.clip is not None:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.clip)
         self.optimizer.step()
@@ -244,9 +313,13 @@ class FixMatchNTMStep:
         # the frozen teacher's forward on its own stream beside the student's (same results; GEOT_TEACHER_STREAM=0: in line)
         self.overlap_teacher = os.environ.get("GEOT_TEACHER_STREAM", "1") != "0"
         self.share_weak_geometry = os.environ.get("GEOT_SHARE_WEAK_GEOMETRY", "1") != "0"
+        self.grad_sync = None          # a GradSync: see SupervisedStep
 
     def optimizers(self):
         return [self.optimizer, self.T_optimizer]
+
+    def sync_modules(self):
+        return [self.model, self.T_predictor]
 
     def __call__(self, data, data_u, next_batches=None):
         """data: labelled batch {pos (B_l,N,3), x (B_l,3,N), cls (B_l,1), y (B_l,N)}; data_u: unlabelled batch
@@ -386,7 +459,7 @@ class FixMatchNTMStep:
         if can_cut:
             seg.cut_at_blocks = True
         try:
-            pred_all, _, sigma = self.model(data, u0=data_u, fixmatch=True, geometry=geom_s)
+            pred_all, _, sigma = _inner(self.model, self.grad_sync is not None)(data, u0=data_u, fixmatch=True, geometry=geom_s)
         finally:
             if can_cut:
                 seg.cut_at_blocks = False
@@ -402,7 +475,7 @@ class FixMatchNTMStep:
             pred_u, sigma, self.ema_t, cfg["geo_lambma"], cfg["ema_t_decay"], group=self.group,
             filter_outlier=cfg["filter_outlier"])
         # 4. per-point matrices + corrected strong logits (train.py:547-552)
-        ins_t = self.T_predictor(F.softmax(pred_u_strong, dim=1).detach(), self.cm)
+        ins_t = _inner(self.T_predictor, self.grad_sync is not None)(F.softmax(pred_u_strong, dim=1).detach(), self.cm)
         pred_u_strong_corr = ntm_mod.correct_logits(pred_u_strong, ins_t, ema_t_corr, cfg["lambma"])
         if not ema_in_place:
             with torch.no_grad():      # in its buffer, never rebound: a captured replay (graph_step) holds this very tensor
@@ -425,6 +498,8 @@ class FixMatchNTMStep:
             if ema_in_place:
                 with torch.no_grad():
                     torch.mul(ema_next, 1.0, out=self.ema_t)   # behind everything that read the old one (a kernel, not a memcpy node)
+            if self.grad_sync is not None:
+                self.grad_sync()
             if cfg["grad_norm_clip"] is not None:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg["grad_norm_clip"])
             self.optimizer.step()
@@ -443,16 +518,24 @@ def _same_positions_impl(src, data, data_u):
         and all(t._version == v for t, v in zip(src, src[3]))
 
 
-def build_fixmatch(device, seg_cfg=None, cfg=None, use_ddp=True, group=None):
+def build_fixmatch(device, seg_cfg=None, cfg=None, use_ddp=True, group=None, graph_sync=False, min_world=2):
     """Student, frozen teacher and T_predictor as train.py:154-226 builds them (random init: the pretrained
-    checkpoints are the authors' local files)."""
+    checkpoints are the authors' local files).  graph_sync: the data-parallel form for a replay from hipGraphs -- bare
+    SyncBatchNorm-converted modules + one flat gradient all-reduce (sync_only / GradSync) instead of DDP wrappers."""
     from .openpoints.models.backbone.transformer import TOOTH_SEG_CFG
     seg = dict(NAME="PointTransformer_seg_T", **(seg_cfg or TOOTH_SEG_CFG))
     student = WholePartSeg(segmentor_args=seg).to(device)
     teacher = WholePartSeg(segmentor_args=seg).to(device)
     teacher.load_state_dict(student.state_dict())
     t_pred = ntm_mod.Ins_T_mean(nclasses=(cfg or NTM_CFG).get("num_classes", 17)).to(device)
+    if graph_sync:
+        import torch.distributed as dist
+        student = sync_only(student, min_world=min_world)
+        step = FixMatchNTMStep(student, teacher, t_pred, cfg=cfg, group=group)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world:
+            step.grad_sync = GradSync([student, t_pred], group)
+        return step
     if use_ddp:
-        student = ddp(student, device, unused=UNUSED_FIXMATCH)
-        t_pred = ddp(t_pred, device, sync_bn=False)
+        student = ddp(student, device, unused=UNUSED_FIXMATCH, min_world=min_world)
+        t_pred = ddp(t_pred, device, sync_bn=False, min_world=min_world)
     return FixMatchNTMStep(student, teacher, t_pred, cfg=cfg, group=group)

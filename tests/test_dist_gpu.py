@@ -225,6 +225,113 @@ def _rccl_single_rank_worker(port, q):
     dist.destroy_process_group()
 
 
+def _rccl_graphed_ddp_worker(port, q, which):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.pop("DEBUG_CLR_GRAPH_PACKET_CAPTURE", None)
+    os.environ["GEOT_GRAPH_LAUNCH"] = "fast"              # captures are inspected: kernel nodes only
+    import geot_amd  # noqa: F401
+    import torch.distributed as dist
+    from geot_amd import train_step as ts, graph_step as gs
+    from geot_amd.synth import make_batch, region_labels
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    out = {}
+    try:
+        if which == "supervised":
+            from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+            torch.manual_seed(3)
+            init = PointTransformer_seg_T(**SMALL).state_dict()
+            batches = []
+            for start in (5, 60):
+                xyz = make_batch(3, N, start_index=start)[0]
+                batches.append((torch.from_numpy(xyz).to(dev), torch.zeros(3, 1, dtype=torch.long, device=dev),
+                                torch.from_numpy(region_labels(xyz)).to(dev)))
+            for mode in ("eager", "graph"):
+                m = PointTransformer_seg_T(**SMALL).to(dev)
+                m.load_state_dict(init)
+                if mode == "eager":       # train.py:159-166: SyncBatchNorm + DistributedDataParallel, bucketed all-reduce in the backward
+                    step = ts.SupervisedStep(ts.ddp(m, dev, unused=ts.UNUSED_SUPERVISED, min_world=1))
+                else:                     # the bare converted module + one flat all-reduce: what a hipGraph can hold
+                    net = ts.sync_only(m, min_world=1)
+                    step = ts.SupervisedStep(net, grad_sync=ts.GradSync([net], dist.group.WORLD))
+                call = gs.GraphedSupervisedStep(step, warmup=2) if mode == "graph" else step
+                torch.manual_seed(7)
+                losses = []
+                for i in range(6):                                   # 2 eager warm-ups over the static buffers, capture, 3 replays
+                    cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+                    losses.append(float(call(cur[0], cur[1], cur[2], next_pos=nxt[0])))
+                torch.cuda.synchronize()
+                state = {k: v.detach().float().cpu().numpy() for k, v in m.state_dict().items()}
+                out[mode] = {"losses": losses, "state": state}
+                if mode == "graph":
+                    out["nodes"] = call.node_types
+                    out["sync_calls"] = step.grad_sync.collectives
+                    out["captured"] = call.captured
+        else:
+            cfg = dict(ts.NTM_CFG, threed_k=8)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("_gs_tests", os.path.join(ROOT, "tests", "test_graph_step_gpu.py"))
+            gst = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(gst)
+            _fix_batch, SMALL_FIX = gst._fix_batch, gst.SMALL
+            batches = [_fix_batch(3), _fix_batch(400)]
+            for mode in ("eager", "graph"):
+                torch.manual_seed(5)
+                step = ts.build_fixmatch(dev, seg_cfg=SMALL_FIX, cfg=cfg, use_ddp=(mode == "eager"), graph_sync=(mode == "graph"),
+                                         group=dist.group.WORLD, min_world=1)
+                assert isinstance(step.model, torch.nn.parallel.DistributedDataParallel) == (mode == "eager")
+                call = gs.GraphedFixMatchStep(step, warmup=2) if mode == "graph" else step
+                torch.manual_seed(11)
+                losses = []
+                for i in range(5):
+                    cur, nxt = batches[i % 2], batches[(i + 1) % 2]
+                    losses.append({k: float(v) for k, v in call(cur[0], cur[1], next_batches=nxt).items()})
+                torch.cuda.synchronize()
+                out[mode] = {"losses": losses, "ema_t": step.ema_t.cpu().numpy()}
+                if mode == "graph":
+                    out["nodes"] = call.node_types
+                    out["sync_calls"] = step.grad_sync.collectives
+                    out["captured"] = call.captured
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["supervised", "fixmatch"])
+def test_ddp_step_replayed_from_graphs_over_rccl_equals_eager(which):
+    """N > 1 without the host: a DistributedDataParallel + SyncBatchNorm step over backend nccl (one rank: what this box
+    allows) against the same step on the bare SyncBatchNorm-converted modules replayed from hipGraphs -- train_step.GradSync
+    puts ONE flat gradient all-reduce between the backward and the optimizer, the captures hold kernel nodes only: the
+    losses and the parameters of the eager DDP step bit for bit over alternating batches (the reducer divides by the world size and sums: at one rank both are the
+    identity, so the two exchanges agree exactly).  examples/segmentation/train.py:159-166, 646-669."""
+    import torch.multiprocessing as mp
+    import queue
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_graphed_ddp_worker, args=(_free_port(), q, which))
+    p.start()
+    res = None
+    for _ in range(160):
+        try:
+            res = q.get(timeout=5)
+            break
+        except queue.Empty:
+            if p.exitcode not in (None, 0):
+                pytest.fail("the RCCL rank exited with %s" % p.exitcode)
+    p.join(timeout=120)
+    assert res is not None and p.exitcode == 0
+    assert res["captured"] and res["sync_calls"] >= 3
+    assert all(set(v) == {"kernel"} for v in res["nodes"].values()), res["nodes"]
+    assert res["eager"]["losses"] == res["graph"]["losses"], (res["eager"]["losses"], res["graph"]["losses"])
+    if which == "supervised":
+        for k, v in res["eager"]["state"].items():
+            np.testing.assert_array_equal(v, res["graph"]["state"][k], err_msg=k)
+    else:
+        np.testing.assert_array_equal(res["eager"]["ema_t"], res["graph"]["ema_t"])
+
+
 def test_rccl_backend_runs_a_ddp_step_on_one_rank():
     """The only RCCL execution a one-GPU box allows: a process group over backend "nccl" (= RCCL on ROCm) with ONE rank --
     all-reduce and all-gather go through the library, and DistributedDataParallel + SyncBatchNorm over it drive three
