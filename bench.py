@@ -245,6 +245,26 @@ def pmc_traffic(kernel, tag):
     return None, None
 
 
+def sq_share(kernel, tag):
+    """Executed-work figure of `kernel` from the committed SQ counter passes of this command (profiles/*<tag>*_sq_counters.json,
+    tools/profile_bench.sh): the share of the cycles its CUs were busy in which a vector instruction was issuing
+    (SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES), with its source.  Pruned updates are not in it: only instructions that ran."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s*_sq_counters.json" % tag)),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    for path in reversed(files):
+        with open(path) as f:
+            prof = json.load(f)
+        for name, rec in prof.get("kernels", {}).items():
+            if kernel in name and rec.get("valu_active_share_of_busy_cu_cycles") is not None:
+                return {"value": rec["valu_active_share_of_busy_cu_cycles"], "file": os.path.relpath(path, ROOT), "kernel": name,
+                        "valu_insts_per_wave_cycle": rec.get("valu_insts_per_wave_cycle"),
+                        "what": "SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES of the profiled launches: vector-issue share of the cycles "
+                                "the occupied CUs were busy (executed instructions only; pruned updates are not counted)"}
+    return None
+
+
 def affinity_cores(cap=16):
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     return min(cap, n)
@@ -758,12 +778,12 @@ def main():
         "kernel": "fps_pruned_kernel", "bound": "valu", "achieved": fps_tf, "peak": FP32_VECTOR_PEAK_TFLOPS,
         "unit": "TFLOP/s", "frac": fps_tf / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": source,
         "avg_launch_ms": fps_ms, "alone_launch_ms": fps_alone_ms, "cus_used": fps_clouds,
-        # the same rate against the peak of the CUs the launch can occupy (one workgroup per cloud): context for `frac`, which
-        # divides by all 256 CUs and is capped at clouds / 256 whatever the kernel does
-        "frac_of_occupied_cus": fps_tf / (FP32_VECTOR_PEAK_TFLOPS * min(fps_clouds, 256) / 256.0) if fps_clouds else None,
+        # `frac` divides by all 256 CUs and is capped at clouds / 256 whatever the kernel does (one workgroup per cloud); what the
+        # occupied CUs actually execute comes from the committed SQ counter pass: vector-issue share of their busy cycles
+        "valu_issue_share_of_occupied_cus": sq_share("fps_pruned_kernel<768, 32, false", tag if workload != "model" else "bench_model"),
         "note": "FPS is fp32-VALU / round-latency bound, not HBM or MFMA bound; algorithmic flop = clouds*N*(m-1) updates "
-                "* 10 (what the reference executes); the pruned kernel skips most of them exactly; one workgroup "
-                "(one CU of 256) per cloud; avg_launch_ms is the launch as it ran inside the step (side stream, sharing its CUs "
+                "* 10 (what the reference executes); the pruned kernel skips most of them exactly (so `frac` is not utilisation: "
+                "see valu_issue_share_of_occupied_cus); one workgroup (one CU of 256) per cloud; avg_launch_ms is the launch as it ran inside the step (side stream, sharing its CUs "
                 "with the main stream's GEMMs) -- under the default hipGraph replay taken on the eager leg of the same run, "
                 "where HIP events can bracket one launch; alone_launch_ms the same launch with the chip to itself"}
     result = {

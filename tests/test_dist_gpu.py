@@ -55,7 +55,7 @@ def test_bench_two_rank_rehearsal_emits_an_auditable_line(workload):
     assert comm["gradient_allreduce_mb_per_step"] > 100            # 27 M fp32 parameters
     assert np.isfinite(comm["exposed_allreduce_ms"]) and comm["ms_per_step_without_gradient_allreduce"] > 0
     assert comm["ms_per_step_without_lookahead"] > 0
-    assert "cpu_baseline" not in rec and rec["graph"]["replayed"] is False          # N > 1 runs DDP eagerly
+    assert "cpu_baseline" not in rec and rec["graph"]["replayed"] is False          # gloo: collectives on the host, not capturable -- eager DDP
     ranks = rec["ranks"]                                                            # what a scaling line is attributed with
     assert len(ranks["host_issue_ms_per_step"]["per_rank"]) == 2 and ranks["host_issue_ms_per_step"]["max"] >= ranks["host_issue_ms_per_step"]["mean"] > 0
     assert len(ranks["cores_visible_per_rank"]) == 2 and ranks["host_cpu_ms_per_step"]["max"] > 0
@@ -63,7 +63,7 @@ def test_bench_two_rank_rehearsal_emits_an_auditable_line(workload):
     # SyncBatchNorm through fused_norm.bn_act: one all-reduce of the statistics forward, one backward, per BatchNorm layer
     assert coll.get("all_reduce", 0) >= 2 * 9
     if workload == "fixmatch":
-        assert coll.get("all_gather", 0) >= 1                                       # the class-anchor exchange
+        assert coll.get("all_gather", 0) + coll.get("all_gather_into_tensor", 0) >= 1   # the class-anchor exchange
     assert np.isfinite(rec["final_loss"])
 
 
