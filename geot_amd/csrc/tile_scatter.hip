@@ -87,7 +87,17 @@ static bool ts_plan(int b, int c, int m, long long L, int nt, bool weighted, TsP
         if (tl < 256 && tl < ((L + 3) & ~3LL)) continue;   // tiles this short are all barrier: fewer channels per workgroup
         if (q > TS_MAX_Q) continue;
         tl = ((L + q - 1) / q + 3) & ~3LL;                   // equal tiles
+        // ... whose 16 shares are a few pairs short of whole chunks: a share of 64 j + (0 .. 3) pairs plus the spill of its last
+        // target is j + 1 chunks with one or two entries in the last
+        {
+            long long t2 = tl;
+            for (long long share = t2 * nt / TS_WAVES; t2 > 64 && share >= 64 && ((share & 63) >= 60 || (share & 63) < 2);
+                 share = t2 * nt / TS_WAVES)
+                t2 -= 4;
+            if (((L + t2 - 1) / t2) * 20 <= q * 21) tl = t2;    // ... unless that costs more than 5 % more tiles (short rows)
+        }
         q = (L + tl - 1) / tl;
+        if (q > TS_MAX_Q) continue;
         const long long ppp = tl * nt;
         const long long cap = ((ppp + 64LL * TS_WAVES + 63) & ~63LL) + 64 * TS_NPF;
         if (cap > 0xffff) continue;                          // a wave's first slot is a 16-bit field of its table entry
@@ -277,11 +287,13 @@ __global__ __launch_bounds__(TS_THREADS) void ts_scatter_kernel(int c, int m, in
 
     TS_STAMP_DECL
     ts_f4 pre[4];
+    const int qfull = 4 * min(qd, (tl >> 2) - 1), last_len = L - (q - 1) * tl;          // (all tiles but the last are tl long)
+    const int qlast = 4 * min(qd, max(last_len >> 2, 1) - 1);
     auto load_tile = [&](int p, ts_f4 &dst) {
         p = min(p, q - 1);
         const int p0 = p * tl, plen = min(tl, L - p0);
         if (VEC) {
-            dst = __builtin_nontemporal_load(reinterpret_cast<const ts_f4 *>(grow + p0 + 4 * min(qd, (plen >> 2) - 1)));
+            dst = __builtin_nontemporal_load(reinterpret_cast<const ts_f4 *>(grow + p0 + (p == q - 1 ? qlast : qfull)));
         } else {
             const float *src = grow + p0;
             dst.x = src[min(4 * qd + 0, plen - 1)];
@@ -319,9 +331,10 @@ __global__ __launch_bounds__(TS_THREADS) void ts_scatter_kernel(int c, int m, in
     for (int i = tid; i < q * TS_WAVES; i += TS_THREADS) s_wr[i] = wr[(size_t)bi * q * TS_WAVES + i];
     __syncthreads();
 
-    // the entries of this wave's first TS_NPF chunks of a tile, fetched while the previous tile is walked
-    uint32_t nk[TS_NPF];
-    float nw[TS_NPF];
+    // the entries of this wave's first TS_NPF chunks of a tile, fetched while the previous tile is walked: two register
+    // sets, by the tile's parity (no copies); one address per tile, the chunks at immediate offsets
+    uint32_t ek[2][TS_NPF];
+    float ew[2][TS_NPF];
     auto entry = [&](int p, int slot, uint32_t &key, float &w) {
         const size_t at = (size_t)p * cap + min(slot, cap - 1);
         if (WEIGHTED) {
@@ -333,31 +346,49 @@ __global__ __launch_bounds__(TS_THREADS) void ts_scatter_kernel(int c, int m, in
             w = 1.f;
         }
     };
-    auto fetch = [&](int p) {
-        p = min(p, q - 1);
-        const int first = s_wr[p * TS_WAVES + wave] & 0xffff;
+    int desc_next = 0;                                          // descriptor of the tile whose entries were fetched last
+    size_t ebase_next = 0;                                      // first entry slot of that tile
+    auto fetch = [&](int p, uint32_t(&nk)[TS_NPF], float(&nw)[TS_NPF]) {
+        if (p < q) {
+            desc_next = __builtin_amdgcn_readfirstlane(s_wr[p * TS_WAVES + wave]);
+            ebase_next = (size_t)p * cap;
+        } else desc_next &= 0xffff;                             // past the end: no chunks (the loads below repeat the last tile's)
+        const size_t at = ebase_next + (desc_next & 0xffff);    // (first + 64 TS_NPF <= cap: the plan's slack)
+        if (WEIGHTED) {
+            const uint2 *src = reinterpret_cast<const uint2 *>(pent) + at + lane;
 #pragma unroll
-        for (int j = 0; j < TS_NPF; ++j) entry(p, first + 64 * j + lane, nk[j], nw[j]);
+            for (int j = 0; j < TS_NPF; ++j) {
+                const uint2 e2 = src[64 * j];
+                nk[j] = e2.x;
+                nw[j] = __uint_as_float(e2.y);
+            }
+        } else {
+            const uint32_t *src = pent + at + lane;
+#pragma unroll
+            for (int j = 0; j < TS_NPF; ++j) {
+                nk[j] = src[64 * j];
+                nw[j] = 1.f;
+            }
+        }
     };
-    fetch(0);
+    fetch(0, ek[0], ew[0]);
     TS_STAMP(0)
 
     // sorted runs: segmented sum over the lanes of one chunk -- on return every target's last lane holds the sum of the
     // target's lanes and `tail` marks it (padding lanes carry k = INT_MAX)
-    auto scan = [&](int k, bool valid, vec v, bool &tail) -> vec {
-        const int kp = __builtin_amdgcn_update_dpp(-1, k, TS_DPP_WAVE_SHR1, 0xF, 0xF, false);
-        const bool same = valid && kp == k;                 // this lane continues the run of the lane below
-        const unsigned long long mask = __ballot(same);
-        vec s = v;
-        if (mask) {
-            int R = 0;                                      // longest run of set bits = shift-and-add rounds needed
-            for (unsigned long long mm = mask; mm; mm &= mm << 1) ++R;
+    // (the rounds beyond the first: s = the sums after one shift-and-add round, mask = ballot(same))
+    auto scan_more = [&](int k, bool same, unsigned long long mask, vec v, vec s) -> vec {
+        unsigned long long mm = mask & (mask << 1);
+        if (mm) {                                           // three or more lanes of one target
+            int R = 1;                                      // longest run of set bits = rounds needed in all
+            for (; mm; mm &= mm << 1) ++R;
             if (R <= 6) {
-                for (int rr = 0; rr < R; ++rr) {
+                for (int rr = 1; rr < R; ++rr) {
                     const vec t = ts_shr1(s);
                     s = same ? v + t : v;
                 }
             } else {                                        // log-step segmented scan (keys are sorted)
+                s = v;
                 for (int d = 1; d < 64; d <<= 1) {
                     const int kd = __shfl_up(k, d);
                     const vec t = ts_up(s, d);
@@ -365,22 +396,58 @@ __global__ __launch_bounds__(TS_THREADS) void ts_scatter_kernel(int c, int m, in
                 }
             }
         }
+        return s;
+    };
+    auto scan = [&](int k, bool valid, vec v, bool &tail) -> vec {
+        const int kp = __builtin_amdgcn_update_dpp(-1, k, TS_DPP_WAVE_SHR1, 0xF, 0xF, false);
+        const bool same = valid && kp == k;                 // this lane continues the run of the lane below
+        const unsigned long long mask = __ballot(same);
+        vec s = v;
+        if (mask) {
+            const vec t1 = ts_shr1(v);
+            s = scan_more(k, same, mask, v, same ? v + t1 : v);
+        }
         tail = valid && !(lane < 63 && ((mask >> (lane + 1)) & 1ull));
         return s;
     };
 
-    auto walk = [&](int p) {
-        const int desc = __builtin_amdgcn_readfirstlane(p < q ? s_wr[p * TS_WAVES + wave] : 0);
+    auto walk = [&](int p, const uint32_t(&ck)[TS_NPF], const float(&cw)[TS_NPF], uint32_t(&nk)[TS_NPF], float(&nw)[TS_NPF]) {
+        const int desc = desc_next;                          // (set when this tile's entries were fetched)
         const int first = desc & 0xffff, np = (desc >> 16) & 31, ntot = np + (int)((unsigned)desc >> 21);
-        uint32_t ck[TS_NPF];
-        float cw[TS_NPF];
-#pragma unroll
-        for (int j = 0; j < TS_NPF; ++j) { ck[j] = nk[j]; cw[j] = nw[j]; }
-        fetch(p + 1);
+        fetch(p + 1, nk, nw);
         const vec *rows = reinterpret_cast<const vec *>((p & 1) ? buf1 : buf0);
-        // the first TS_NPF chunks (all of them at the model's shapes) from the prefetched entries: the source rows of all
-        // chunks first, then the plain chunks -- distinct targets across all of them -- as one batch of reads, adds and
-        // writes, then the chunks of the sorted run in order
+        // The shapes of nearly every (wave, tile) of a large problem -- two or three full plain chunks and one chunk of sorted
+        // run -- as straight-line code: no per-chunk branches, one shift-and-add round for the run (targets with three or more
+        // lanes in the run fall through to the general rounds).
+        auto fast = [&](auto npc) {
+            constexpr int NP = decltype(npc)::value;
+            int kk[NP];
+            vec rr[NP], aa[NP];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                kk[j] = (int)(ck[j] >> TS_EBITS);
+                rr[j] = rows[ck[j] & ((1u << TS_EBITS) - 1)];
+            }
+            const bool ok = ck[NP] != TS_NONE;
+            const int k2 = ok ? (int)(ck[NP] >> TS_EBITS) : 0x7fffffff;
+            const vec r2 = rows[ok ? (int)(ck[NP] & ((1u << TS_EBITS) - 1)) : 0];
+#pragma unroll
+            for (int j = 0; j < NP; ++j) aa[j] = acc[kk[j]];
+            const vec x2 = WEIGHTED ? r2 * cw[NP] : r2;
+            const int kp = __builtin_amdgcn_update_dpp(-1, k2, TS_DPP_WAVE_SHR1, 0xF, 0xF, false);
+            const bool same = ok && kp == k2;
+            const unsigned long long mask = __ballot(same);
+            const vec t1 = ts_shr1(x2);
+            vec s2 = same ? x2 + t1 : x2;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) acc[kk[j]] = WEIGHTED ? aa[j] + rr[j] * cw[j] : aa[j] + rr[j];
+            s2 = scan_more(k2, same, mask, x2, s2);          // (targets with three or more lanes: further rounds)
+            if (ok && !(lane < 63 && ((mask >> (lane + 1)) & 1ull))) acc[k2] = acc[k2] + s2;
+        };
+        if (np == 2 && ntot == 3) { fast(std::integral_constant<int, 2>{}); return; }
+        if (np == 3 && ntot == 4) { fast(std::integral_constant<int, 3>{}); return; }
+        // any other shape: the first TS_NPF chunks from the prefetched entries -- the source rows of all chunks first, the
+        // plain chunks (distinct targets across all of them) as one batch of reads, adds and writes, then the run in order
         int k[TS_NPF];
         bool valid[TS_NPF];
         vec v[TS_NPF], a[TS_NPF];
@@ -391,14 +458,12 @@ __global__ __launch_bounds__(TS_THREADS) void ts_scatter_kernel(int c, int m, in
                 k[j] = valid[j] ? (int)(ck[j] >> TS_EBITS) : 0x7fffffff;
                 v[j] = rows[valid[j] ? (int)(ck[j] & ((1u << TS_EBITS) - 1)) : 0];
             }
-        TS_STAMP(3)
 #pragma unroll
         for (int j = 0; j < TS_NPF; ++j)
             if (j < np) a[j] = acc[k[j]];
 #pragma unroll
         for (int j = 0; j < TS_NPF; ++j)
             if (j < np) acc[k[j]] = WEIGHTED ? a[j] + v[j] * cw[j] : a[j] + v[j];
-        TS_STAMP(4)
 #pragma unroll
         for (int j = 0; j < TS_NPF; ++j)
             if (j >= np && j < ntot) {
@@ -406,7 +471,6 @@ __global__ __launch_bounds__(TS_THREADS) void ts_scatter_kernel(int c, int m, in
                 const vec sum = scan(k[j], valid[j], WEIGHTED ? v[j] * cw[j] : v[j], tail);
                 if (tail) acc[k[j]] = acc[k[j]] + sum;      // a target's last lane: its sole writer in this tile
             }
-        TS_STAMP(5)
         for (int j = TS_NPF; j < ntot; ++j) {                // more chunks than the prefetch holds (skewed tiles): one by one
             uint32_t key;
             float w;
@@ -422,7 +486,6 @@ __global__ __launch_bounds__(TS_THREADS) void ts_scatter_kernel(int c, int m, in
                 if (tail) acc[kk] = acc[kk] + vv;
             }
         }
-        TS_STAMP(6)
     };
 
     const int q4 = (q + 3) & ~3;
@@ -435,7 +498,7 @@ __global__ __launch_bounds__(TS_THREADS) void ts_scatter_kernel(int c, int m, in
             TS_STAMP(1)
             __syncthreads();     // tile p is in LDS; every wave has finished tile p - 1
             TS_STAMP(2)
-            walk(p);
+            walk(p, ek[j & 1], ew[j & 1], ek[(j + 1) & 1], ew[(j + 1) & 1]);
         }
     }
     __syncthreads();
