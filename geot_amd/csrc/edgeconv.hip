@@ -332,26 +332,9 @@ __global__ __launch_bounds__(256) void edge_bwd_coef_kernel(int b, int c, int gr
     }
 }
 
-// ---- backward 3: d/dQ[b,c,i] = sum_j dy_ij,  dy_ij = rstd (gamma dz_i [j == jsel] - s1 - yhat_ij s2) ----------
-__global__ __launch_bounds__(256) void edge_bwd_q_kernel(int c, int nq, int k, int groups, float slope,
-                                                         const float *__restrict__ ysel, const float *__restrict__ ysum,
-                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                         const float *__restrict__ stats, const float *__restrict__ coef,
-                                                         const float *__restrict__ grad_out, float *__restrict__ grad_q)
-{
-    const int bi = blockIdx.z, cc = blockIdx.y, g = cc / (c / groups);
-    const float mean = stats[2 * (bi * groups + g)], rstd = stats[2 * (bi * groups + g) + 1];
-    const float s1 = coef[2 * (bi * groups + g)], s2 = coef[2 * (bi * groups + g) + 1];
-    const float gm = gamma[cc], bt = beta[cc], kf = (float)k;
-    const size_t base = ((size_t)bi * c + cc) * nq;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
-        const float yh = (ysel[base + i] - mean) * rstd;
-        const float z = fmaf(gm, yh, bt);
-        const float dz = grad_out[base + i] * (z > 0.f ? 1.f : slope);
-        const float yhs = (ysum[base + i] - kf * mean) * rstd;       // sum_j yhat_ij
-        grad_q[base + i] = rstd * (gm * dz - kf * s1 - s2 * yhs);
-    }
-}
+// ---- backward 3: d/dQ[b,c,i] = sum_j dy_ij,  dy_ij = rstd (gamma dz_i [j == jsel] - s1 - yhat_ij s2)
+//   = rstd (a_i - k s1 - s2 rstd (ysum_i - k mean)): element-wise over rows that backward 4 stages anyway, so it is written
+//   there (one more read, one write in the staging loop instead of a pass that reloads ysel and grad_out).
 
 // ---- reverse index of idx: pairs (i, j) grouped by (batch, target n) ------------------------------------------
 __global__ __launch_bounds__(256) void edge_rix_count_kernel(long long total, long long per_batch, int nk,
@@ -413,7 +396,7 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
     const float *__restrict__ ysel, const uint8_t *__restrict__ jsel, const float *__restrict__ gamma,
     const float *__restrict__ beta, const float *__restrict__ stats, const float *__restrict__ coef,
     const float *__restrict__ grad_out, const int *__restrict__ off, const int *__restrict__ rev,
-    float *__restrict__ grad_p)
+    const float *__restrict__ ysum, float *__restrict__ grad_p, float *__restrict__ grad_q)
 {
     extern __shared__ float ec_rows[]; // [CH][nq] (a, u) | [CH][nq] jsel bytes
     float2 *AU = reinterpret_cast<float2 *>(ec_rows);
@@ -449,6 +432,7 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
     if (n1 > n0) request(slot);
 
     float mean[CH], rstd[CH], s1[CH], s2[CH];
+    const float kf = (float)k;
 #pragma unroll
     for (int l = 0; l < CH; ++l) {
         const int cc = min(c0 + l, c - 1), g = cc / (c / groups);
@@ -461,9 +445,10 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
     for (int l = 0; l < CH; ++l) {
         if (l < nch) {
             const float gm = gamma[c0 + l], bt = beta[c0 + l], us = -s2[l] * rstd[l];
+            const float kmean = kf * mean[l], ks1 = kf * s1[l];
             const size_t base = ((size_t)bi * c + c0 + l) * nq;
             for (int i0 = threadIdx.x; i0 < nq; i0 += EC_SU * EC_THREADS) {
-                float ys[EC_SU], go[EC_SU], qq[EC_SU];
+                float ys[EC_SU], go[EC_SU], qq[EC_SU], sm[EC_SU];
                 uint8_t jj[EC_SU];
 #pragma unroll
                 for (int u = 0; u < EC_SU; ++u) {
@@ -472,6 +457,7 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
                     go[u] = grad_out[base + i];
                     qq[u] = Q[base + i];
                     jj[u] = jsel[base + i];
+                    sm[u] = ysum[base + i];
                 }
 #pragma unroll
                 for (int u = 0; u < EC_SU; ++u) {
@@ -479,8 +465,11 @@ __global__ __launch_bounds__(EC_THREADS) void edge_bwd_p_kernel(
                     if (i < nq) {
                         const float yh = (ys[u] - mean[l]) * rstd[l];
                         const float z = fmaf(gm, yh, bt);
-                        AU[(size_t)l * nq + i] = make_float2(gm * go[u] * (z > 0.f ? 1.f : slope), us * qq[u]);
+                        const float a = gm * (go[u] * (z > 0.f ? 1.f : slope));
+                        AU[(size_t)l * nq + i] = make_float2(a, us * qq[u]);
                         J[(size_t)l * nq + i] = jj[u];
+                        // d/dQ[b,c,i] = sum_j dy_ij = rstd (a_i - k s1 - s2 sum_j yhat_ij): the rows are here already
+                        if (blockIdx.x == 0) grad_q[base + i] = rstd[l] * (a - ks1 - s2[l] * ((sm[u] - kmean) * rstd[l]));
                     }
                 }
             }
@@ -723,10 +712,6 @@ static int ec_grad(int b, int c, int nq, int nk, int k, int groups, float slope,
     const double count = (double)(c / groups) * nq * k;
     hipLaunchKernelGGL(edge_bwd_coef_kernel, dim3(b * groups + (c + 255) / 256), dim3(256), 0, s, b, c, groups, slices, count,
                        gamma, bpart, coef, grad_gamma, grad_beta);
-    int gx = (nq + 1023) / 1024;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(edge_bwd_q_kernel, dim3(gx, c, b), dim3(256), 0, s, c, nq, k, groups, slope, ysel, ysum, gamma, beta,
-                       stats, coef, grad_out, grad_q);
     const int ch = ec_bwd_ch(nq), pslices = ec_slices(b, c, ch, nk);
     const size_t lds = (size_t)ch * nq * 9;
     const dim3 grid(pslices, (c + ch - 1) / ch, b);
@@ -737,7 +722,7 @@ static int ec_grad(int b, int c, int nq, int nk, int k, int groups, float slope,
         e = ec_allow_lds(edge_bwd_p_kernel<KV, CHV>, lds);                                                         \
         if (e != hipSuccess) return e;                                                                             \
         hipLaunchKernelGGL((edge_bwd_p_kernel<KV, CHV>), grid, dim3(EC_THREADS), lds, s, c, nq, nk, k, groups, lg, slope, \
-                           P, Q, ysel, jsel, gamma, beta, stats, coef, grad_out, off, rev, grad_p);                \
+                           P, Q, ysel, jsel, gamma, beta, stats, coef, grad_out, off, rev, ysum, grad_p, grad_q);   \
     }
     if (k4) {
         if (ch == 4) GEOT_EC_BWD(true, 4) else if (ch == 2) GEOT_EC_BWD(true, 2) else GEOT_EC_BWD(true, 1)

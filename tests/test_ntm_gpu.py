@@ -312,7 +312,7 @@ def test_class_anchor_kernel_first_maximum_and_rows():
     assert torch.equal(a, b_)
 
 
-@pytest.mark.parametrize("Cn", [2, 5, 12, 20, 32])
+@pytest.mark.parametrize("Cn", [2, 5, 7, 8, 12, 13, 16, 20, 31, 32])   # 6 up: the MFMA form, every row-tile width, whole and partial pieces
 def test_any_class_count_matches_the_oracle(Cn):
     """transformer.py:1104-1110 builds `nclasses` heads for ANY nclasses and insT_loss.py takes num_classes: every
     per-point kernel at class counts other than the specialised 17 (run-time-C kernels, csrc/ntm_generic.hip)."""
@@ -375,6 +375,41 @@ def test_any_class_count_matches_the_oracle(Cn):
     wl, wg, _ = np_ntm.feature_space_loss(p, labels, want, fnbr, sigma=1.0)
     assert abs(fl.item() - wl) <= 1e-5 * max(abs(wl), 1e-3)
     np.testing.assert_allclose(ti.grad.cpu().numpy(), wg, rtol=1e-4, atol=1e-4 * np.abs(wg).max())
+
+
+@pytest.mark.parametrize("Cn", [8, 13, 20, 32])
+@pytest.mark.parametrize("impl", ["mfma", "rows"])
+def test_any_class_count_at_full_size_against_fp64(Cn, impl, monkeypatch):
+    """140 002 points: more point tiles than resident waves (every wave walks several tiles, the next tile's inputs in flight),
+    a last tile of 2 points, C = 32 with its weights split over two workgroup ranges -- forward and d raw of the run-time-C
+    sig_t_mean against the same arithmetic in fp64 (transformer.py:1111-1131: heads, clamp, L1 norm over o)."""
+    from geot_amd import ntm
+    monkeypatch.setenv("GEOT_NTM_GENERIC", impl)
+    torch.manual_seed(Cn)
+    B, N = 2, 70001
+    p = torch.softmax(torch.randn(B, Cn, N, device=DEV) * 2, 1)
+    cm = torch.softmax(torch.randn(Cn, Cn, device=DEV), 1)
+    mod = ntm.Ins_T_mean(nclasses=Cn).to(DEV)
+    with torch.no_grad():
+        for kk, l in enumerate(mod.T_predictor.fc):
+            l.weight[kk, kk] += 0.6
+            l.weight += 0.03
+    W = torch.stack([l.weight for l in mod.T_predictor.fc]).detach().contiguous()
+    g = torch.randn(B * N, Cn, Cn, device=DEV)
+    with torch.no_grad():
+        got = mod(p, cm)
+        draw = ntm.sig_t_mean_grad_raw(p, cm, W, g)
+    W64, p64 = W.double(), p.double()
+    raw = torch.einsum("bjn,koj->bnko", p64, W64[:, :, :Cn]).reshape(B * N, Cn, Cn) + torch.einsum("kj,koj->ko", cm.double(), W64[:, :, Cn:])
+    raw.requires_grad_(True)
+    cl = raw.clamp(1e-5, 1 - 1e-5)
+    want = cl / cl.abs().sum(-1, keepdim=True).clamp_min(1e-12)
+    assert float((got.double() - want.detach()).abs().max()) <= 2e-6
+    (want * g.double()).sum().backward()
+    # an element whose fp32 raw value rounds across the clamp's edge flips its gradient on or off: compare where fp64 is clear of it
+    clear = ((raw.detach() - 1e-5).abs() > 1e-6) & ((raw.detach() - (1 - 1e-5)).abs() > 1e-6)
+    err = ((draw.double() - raw.grad).abs() * clear).max()
+    assert float(err) <= 1e-5 * float(raw.grad.abs().max())
 
 
 def test_class_count_out_of_range_is_an_error():

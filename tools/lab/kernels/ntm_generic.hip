@@ -1,3 +1,4 @@
+// LAB COPY (tools/lab/ntm_knockouts.sh: GEN_KO_STORE / GEN_KO_MFMA / GEN_KO_POST) of
 // ntm_generic.hip -- the per-point transition-matrix kernels for ANY class count 2 <= C <= 32.
 //
 // The reference builds `nclasses` Linear(2C -> C) heads for whatever nclasses the config names
@@ -181,174 +182,122 @@ __global__ __launch_bounds__(256) void gen_sig_t_mean_rows_kernel(int total_pts,
 //     raw[kk][o][pt] = bias[kk][o] + sum_j W[kk][o][j] p[pt][j]
 // done as v_mfma_f32_32x32x2_f32 tiles with the WEIGHTS on the row side and 32 POINTS on the column side, so that in the
 // result a lane owns one point (column = lane & 31) and 16 of a tile's 32 rows: clamp, L1 norm and the backward's dot
-// product over o are 16 in-lane steps plus one exchange with lane ^ 32 -- no workgroup barrier in the loop.
+// product over o are 16 in-lane steps plus one exchange with lane ^ 32 -- no LDS tile, no barrier in the loop.
 // A row tile holds 32 / CPAD heads of CPAD rows (CPAD = 8, 16, 32 >= C), the bias starts the accumulator, the weight
-// fragments of every (row tile, 4 K steps) sit in LDS in fragment order (one ds_read_b128 per 4 MFMAs), each wave walks its
-// own point tiles.  In that layout neighbouring lanes hold neighbouring POINTS (4 C^2 bytes apart): written from there, every
-// 16-byte piece is a memory request of its own and the address path bounds the kernel (knock-outs at C = 32: stores 100 of
-// 290 us, not overlapping the MFMAs' 100 -- profiles/r05_ntm_generic.txt).  So a row tile's results cross a wave-private LDS
-// tile ([32 points][32 rows + 4]) and leave in the order of the output: 8 lanes per 128 contiguous bytes; the backward's
-// incoming gradient takes the same way in.  A workgroup serves one of `ksplit` ranges of row tiles (its weights: 1 / ksplit
-// of C^3 floats; 16 waves x 4.5 KB of tiles), the point tiles are dealt over the workgroups of a range.
-// Memory operations of a wave retire in order (one vmcnt counter for loads and stores), so a load issued behind a tile's stores
-// waits for them: the forward fetches the NEXT point tile's fragments before the first store of this one, the backward the
-// NEXT row tile's gradient pieces (a counted wait then leaves one row tile of stores in flight).
+// fragments of every (row tile, 4 K steps) sit in LDS in fragment order (one ds_read_b128 per 4 MFMAs; 132 KB at
+// C = 32, one workgroup of 16 waves per CU), each wave walks its own point tiles.  A lane writes its results as 16-byte
+// pieces of its point's row (4-byte pieces if C is not a multiple of 4): lanes l and l ^ 32 fill 32 adjacent bytes, the C
+// row tiles of a point complete its 4 C^2 bytes within the same wave.
 typedef float gen_f32x16 __attribute__((ext_vector_type(16)));
 typedef float gen_f32x4 __attribute__((ext_vector_type(4)));
 typedef float gen_f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte piece at 4-byte alignment (one dwordx4 access)
 constexpr int GEN_MT = 1024, GEN_MW = GEN_MT / 64;
-constexpr int GEN_RS = 36;        // floats per point in a wave's tile: 32 rows (NG heads of CPAD) + 4, so that rows start 4 banks apart
-constexpr int GEN_NI = 4;         // 16-byte pieces per lane of a tile's dense image: 32 points x <= 8 pieces over 64 lanes
 
-// TAILS: C is not a multiple of 4 -- pieces of the dense image straddle heads and the last one of a point is partial
+// TAILS: C is not a multiple of 4, the last piece of a row is partial (element stores)
+// Memory operations of a wave retire in order (one vmcnt counter for loads and stores), so a load issued behind a tile's stores
+// waits for them: the forward fetches the NEXT unit's point fragments before the first store of this one, the backward the
+// NEXT row tile's gradient pieces (a counted wait then leaves one row tile of stores in flight).
 template <int CPAD, bool BACKWARD, bool TAILS>
 __global__ __launch_bounds__(GEN_MT) void gen_sig_t_mean_mfma_kernel(int total_pts, int n, int c, int ksplit, const float *__restrict__ p,
                                                                      const float *__restrict__ W, const float *__restrict__ cm,
                                                                      const float *__restrict__ grad_out, float *__restrict__ out)
 {
     constexpr int NG = 32 / CPAD, QPG = CPAD / 8, KSMAX = CPAD / 2;   // heads per row tile, 8-row blocks per head, K steps
-    constexpr bool AHEAD = BACKWARD && !TAILS;                        // (the TAILS forms have no registers for the second set of pieces)
+    constexpr bool AHEAD = BACKWARD && !(TAILS && CPAD == 32);        // (that one instantiation has no registers for the second set)
     extern __shared__ float gen_lds[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cc = c * c, nkt = (c + NG - 1) / NG, ng = (c + 7) / 8;   // row tiles; groups of 4 K steps (8 inputs)
-    const int part = blockIdx.x % ksplit, wb = blockIdx.x / ksplit, nb = gridDim.x / ksplit;
-    const int kt0 = nkt * part / ksplit, kt1 = nkt * (part + 1) / ksplit, nktmax = (nkt + ksplit - 1) / ksplit;
-    float *Af = gen_lds;                         // [kt1 - kt0][ng][64][4]: lane (row, half), element e holds W[kk][o][2 (4 g + e) + half]
-    float *Bt = Af + (size_t)nktmax * ng * 256;  // [kt1 - kt0][32]: bias of the tile's rows
-    float *tile = Bt + nktmax * 32 + wave * (32 * GEN_RS);
-    // (every workgroup builds both from W: coalesced reads in W's own order, scattered LDS writes; the padding is zeroed first)
-    for (int e = tid; e < (kt1 - kt0) * ng * 64; e += GEN_MT) reinterpret_cast<gen_f32x4 *>(Af)[e] = gen_f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-    const int kk0 = kt0 * NG, kk1 = min(c, kt1 * NG);
-    for (int e = tid; e < (kk1 - kk0) * cc; e += GEN_MT) {
-        const int col = kk0 * c + e / c, j = e % c, kk = col / c, o = col - kk * c;
-        const int kt = kk / NG - kt0, row = (kk % NG) * CPAD + o, st = j >> 1;
-        Af[(((kt * ng + (st >> 2)) * 64) + (j & 1) * 32 + row) * 4 + (st & 3)] = W[(size_t)col * 2 * c + j];
+    float *Af = gen_lds;                     // [nkt][ng][64][4]: lane (row, half), element e holds W[kk][o][2 (4 g + e) + half]
+    float *Bt = Af + (size_t)nkt * ng * 256; // [nkt][32]: bias of the tile's rows
+    for (int e = tid; e < nkt * ng * 256; e += GEN_MT) {
+        const int l = (e >> 2) & 63, g = (e >> 8) % ng, kt = (e >> 8) / ng, row = l & 31;
+        const int kk = kt * NG + row / CPAD, o = row % CPAD, j = 2 * (4 * g + (e & 3)) + (l >> 5);
+        Af[e] = (kk < c && o < c && j < c) ? W[((size_t)kk * c + o) * 2 * c + j] : 0.f;
     }
-    for (int e = tid; e < (kt1 - kt0) * 32; e += GEN_MT) {              // (ascending j, as the other two forms: same bits)
-        const int row = e & 31, kk = (kt0 + (e >> 5)) * NG + row / CPAD, o = row % CPAD;
+    for (int e = tid; e < nkt * 32; e += GEN_MT) {                      // (ascending j, as the other two forms: same bits)
+        const int row = e & 31, kk = (e >> 5) * NG + row / CPAD, o = row % CPAD;
         float acc = 0.f;
         if (kk < c && o < c) {
             const float *wr = W + ((size_t)kk * c + o) * 2 * c + c, *cr = cm + kk * c;
-            for (int j0 = 0; j0 < c; j0 += 8) {                         // 16 loads in flight per round
-                float a[8], w[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    a[j] = cr[min(j0 + j, c - 1)];
-                    w[j] = wr[min(j0 + j, c - 1)];
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j0 + j < c) acc += a[j] * w[j];
-            }
+            for (int j = 0; j < c; ++j) acc += cr[j] * wr[j];
         }
         Bt[e] = acc;
     }
     __syncthreads();
-
-    // The dense image of a (point tile, row tile): per point NG c contiguous floats (heads kt NG .. of the point's C x C block),
-    // as ceil(NG c / 4) pieces.  Lane `lane` moves pieces lane + 64 i: point, first dense element, address in the LDS tile.
-    const int seg = NG * c, pieces = (seg + 3) >> 2;
-    unsigned ppt[GEN_NI], pd0[GEN_NI], plo[GEN_NI];
-#pragma unroll
-    for (int i = 0; i < GEN_NI; ++i) {
-        const int f = lane + 64 * i, pt = min(f / pieces, 31), d0 = (f - (f / pieces) * pieces) * 4;
-        const int g = TAILS ? 0 : d0 / c;                              // (whole pieces: inside one head)
-        ppt[i] = f < 32 * pieces ? pt : 32u;                            // 32: no piece
-        pd0[i] = d0;
-        plo[i] = pt * GEN_RS + g * CPAD + (d0 - g * c);
-    }
-    auto lds_of = [&](int pt, int d) {       // TAILS: element d of a point's dense image -> its place in the tile
-        const int g = (NG > 1 && d >= c ? 1 : 0) + (NG > 2 && d >= 2 * c ? 1 : 0) + (NG > 2 && d >= 3 * c ? 1 : 0);
-        return pt * GEN_RS + g * CPAD + (d - g * c);
-    };
-    const long long tiles = ((long long)total_pts + 31) / 32, tstride = (long long)nb * GEN_MW;
-    const unsigned last4 = (unsigned)total_pts * (unsigned)cc - 4u;     // (host: B N C^2 < 2^30, >= 4)
-    long long t = (long long)wb * GEN_MW + wave;
-    if (t >= tiles || kt1 <= kt0) return;
-    auto point = [&](long long tl, bool &ok, unsigned &pbase) {
-        const long long i = tl * 32 + r;
+    // work units: (tile of 32 points, one of ksplit ranges of row tiles)
+    const long long units = (((long long)total_pts + 31) / 32) * ksplit, stride = (long long)gridDim.x * GEN_MW;
+    long long u = (long long)blockIdx.x * GEN_MW + wave;
+    if (u >= units) return;
+    auto point = [&](long long unit, bool &ok, unsigned &row0, unsigned &pbase) {
+        const long long i = unit / ksplit * 32 + r;
         ok = i < total_pts;
         const long long ic = ok ? i : (long long)total_pts - 1;
         const int b = (int)(ic / n), ni = (int)(ic - (long long)b * n);
-        pbase = (unsigned)(b * c * n + ni);  // 32-bit element offsets: uniform base + lane offset
+        row0 = (unsigned)ic * (unsigned)cc;  // 32-bit element offsets (host: B N C^2 < 2^30): uniform base + lane offset
+        pbase = (unsigned)(b * c * n + ni);
     };
     auto fetch_p = [&](float (&dst)[KSMAX], unsigned pbase) {           // column side: lane (point, half) holds p[point][2 s + half]
 #pragma unroll
         for (int s = 0; s < KSMAX; ++s) dst[s] = p[pbase + (unsigned)(min(2 * s + h, c - 1) * n)];
     };
-    // the pieces of (point tile tl, row tile kt) of the incoming gradient: unconditional loads, clamped into the buffer
-    auto fetch_g = [&](gen_f32x4u (&dst)[GEN_NI], long long tl, int kt) {
-        const unsigned base = (unsigned)(tl * 32) * (unsigned)cc + (unsigned)(kt * NG * c);
+    auto fetch_g = [&](float (&dst)[16], unsigned row, int kt) {         // the incoming gradient in the result's own layout
 #pragma unroll
-        for (int i = 0; i < GEN_NI; ++i) {
-            const unsigned off = base + min(ppt[i], 31u) * (unsigned)cc + pd0[i];
-            dst[i] = *reinterpret_cast<const gen_f32x4u *>(grad_out + min(off, last4));
+        for (int q = 0; q < 4; ++q) {
+            const int kk = kt * NG + q / QPG, o0 = 8 * (q % QPG) + 4 * h;
+            const unsigned src = row + (unsigned)(min(kk, c - 1) * c);
+            if (!TAILS || c >= 4) {
+                const int at = max(min(o0, c - 4), 0);                  // a partial last piece is read (o0 - at) elements early
+                const gen_f32x4u v = *reinterpret_cast<const gen_f32x4u *>(grad_out + (src + (unsigned)at));
+                const int sh = TAILS ? o0 - at : 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    dst[4 * q + e] = !TAILS || sh == 0 ? v[e] : (sh == 1 ? v[(e + 1) & 3] : (sh == 2 ? v[(e + 2) & 3] : v[3]));
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[4 * q + e] = grad_out[src + (unsigned)min(o0 + e, c - 1)];
+            }
         }
     };
     bool ok;
-    unsigned pbase;
-    point(t, ok, pbase);
-    float bf[KSMAX], bfn[KSMAX];
-    gen_f32x4u g4[GEN_NI], g4n[GEN_NI];
+    unsigned row0, pbase;
+    point(u, ok, row0, pbase);
+    float bf[KSMAX], bfn[KSMAX], gv[16], gvn[16];
     fetch_p(bf, pbase);
-    if (AHEAD) fetch_g(g4, t, kt0);
+    if (AHEAD) fetch_g(gv, row0, (int)((long long)nkt * (u % ksplit) / ksplit));
     while (true) {
-        const long long tn = t + tstride;
-        const bool more = tn < tiles;
+        const int part = (int)(u % ksplit);
+        const int kt0 = (int)((long long)nkt * part / ksplit), kt1 = (int)((long long)nkt * (part + 1) / ksplit);
+        const long long un = u + stride;
+        const bool more = un < units;
         bool okn;
-        unsigned pbasen;
-        point(more ? tn : t, okn, pbasen);
+        unsigned row0n, pbasen;
+        point(more ? un : u, okn, row0n, pbasen);
+        const int kt0n = more ? (int)((long long)nkt * (un % ksplit) / ksplit) : kt0;
         if (!BACKWARD) fetch_p(bfn, pbasen);
-        const int npts = (int)min((long long)32, (long long)total_pts - t * 32);
-        const unsigned tbase = (unsigned)(t * 32) * (unsigned)cc;
         for (int kt = kt0; kt < kt1; ++kt) {
-            const int segk = min(NG, c - kt * NG) * c;                 // valid floats of a point's image in this row tile
-            const unsigned kbase = tbase + (unsigned)(kt * NG * c);
-            float gv[16];
-            if (BACKWARD) {
-                // this row tile's gradient pieces -> tile -> the result's layout; then the next row tile's pieces take off
-                if (!AHEAD) fetch_g(g4, t, kt);
-#pragma unroll
-                for (int i = 0; i < GEN_NI; ++i) {
-                    if (ppt[i] < 32u) {
-                        if (!TAILS) *reinterpret_cast<gen_f32x4 *>(tile + plo[i]) = g4[i];
-                        else {
-                            const unsigned off = kbase + ppt[i] * (unsigned)cc + pd0[i];
-                            const int sh = (int)(off - min(off, last4));        // the clamped load began sh elements early
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float x = sh == 0 ? g4[i][e] : (sh == 1 ? g4[i][(e + 1) & 3] : (sh == 2 ? g4[i][(e + 2) & 3] : g4[i][3]));
-                                if ((int)pd0[i] + e < seg) tile[lds_of((int)ppt[i], (int)pd0[i] + e)] = x;
-                            }
-                        }
-                    }
-                }
+            if (AHEAD) {
                 const bool last = kt + 1 == kt1;
-                if (AHEAD) fetch_g(g4n, last ? (more ? tn : t) : t, last ? kt0 : kt + 1);
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const gen_f32x4 v = *reinterpret_cast<const gen_f32x4 *>(tile + r * GEN_RS + (q / QPG) * CPAD + 8 * (q % QPG) + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) gv[4 * q + e] = v[e];
-                }
-            }
+                fetch_g(gvn, last ? row0n : row0, last ? kt0n : kt + 1);
+            } else if (BACKWARD) fetch_g(gv, row0, kt);
             gen_f32x16 acc;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {    // result rows 8 q + 4 half + (0..3)
-                const gen_f32x4 v = *reinterpret_cast<const gen_f32x4 *>(Bt + (kt - kt0) * 32 + 8 * q + 4 * h);
+                const gen_f32x4 v = *reinterpret_cast<const gen_f32x4 *>(Bt + kt * 32 + 8 * q + 4 * h);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[4 * q + e] = v[e];
             }
             // the weight fragments of 4 K steps per 16-byte read, the next group's read in flight under this group's MFMAs
             // (a K step past C inside the last group multiplies zeros)
-            const gen_f32x4 *af = reinterpret_cast<const gen_f32x4 *>(Af + (size_t)(kt - kt0) * ng * 256) + lane;
+            const gen_f32x4 *af = reinterpret_cast<const gen_f32x4 *>(Af + (size_t)kt * ng * 256) + lane;
             gen_f32x4 a4 = af[0];
 #pragma unroll
             for (int g = 0; g < KSMAX / 4; ++g) {
+#ifdef GEN_KO_MFMA
+                if (g < ng && n < 0) {
+#else
                 if (g < ng) {
+#endif
                     gen_f32x4 nx = a4;
                     if (g + 1 < KSMAX / 4 && g + 1 < ng) nx = af[(g + 1) * 64];
 #pragma unroll
@@ -364,7 +313,11 @@ __global__ __launch_bounds__(GEN_MT) void gen_sig_t_mean_mfma_kernel(int total_p
             for (int g = 0; g < NG; ++g) sum[g] = dot[g] = 0.f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
+#ifdef GEN_KO_POST
+                if (8 * (q % QPG) < c && n < 0) {
+#else
                 if (8 * (q % QPG) < c) {     // (wave-uniform: 8-row blocks past C hold padding)
+#endif
                     const int o0 = 8 * (q % QPG) + 4 * h;
                     float part4 = 0.f;
 #pragma unroll
@@ -399,49 +352,40 @@ __global__ __launch_bounds__(GEN_MT) void gen_sig_t_mean_mfma_kernel(int total_p
 #pragma unroll
                 for (int g = 0; g < NG; ++g) dot[g] += __shfl_xor(dot[g], 32);
             }
-            // results -> tile (the gradient reads above are done: LDS serves a wave in order)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int g = q / QPG;
+                const int g = q / QPG, kk = kt * NG + g, o0 = 8 * (q % QPG) + 4 * h;
                 if (8 * (q % QPG) < c) {
-                    gen_f32x4 v;
+                    gen_f32x4u v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (!BACKWARD) v[e] = acc[4 * q + e] * rden[g];
                         else v[e] = ((inside >> (4 * q + e)) & 1u) ? (gv[4 * q + e] - dot[g]) * rden[g] : 0.f;
                     }
-                    *reinterpret_cast<gen_f32x4 *>(tile + r * GEN_RS + g * CPAD + 8 * (q % QPG) + 4 * h) = v;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // tile -> the output, in the output's order
-#pragma unroll
-            for (int i = 0; i < GEN_NI; ++i) {
-                if ((int)ppt[i] < npts && (int)pd0[i] < segk) {
-                    float *dst = out + (kbase + ppt[i] * (unsigned)cc + pd0[i]);
-                    if (!TAILS) *reinterpret_cast<gen_f32x4u *>(dst) = *reinterpret_cast<const gen_f32x4 *>(tile + plo[i]);
-                    else {
-                        gen_f32x4u v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = tile[lds_of((int)ppt[i], min((int)pd0[i] + e, seg - 1))];
-                        if ((int)pd0[i] + 4 <= segk) *reinterpret_cast<gen_f32x4u *>(dst) = v;
-                        else {
+                    float *dst = out + (row0 + (unsigned)(kk * c + o0));
+#ifdef GEN_KO_STORE
+                    if (ok && kk < c && n < 0) {
+#else
+                    if (ok && kk < c) {
+#endif
+                        if (o0 + 4 <= c) *reinterpret_cast<gen_f32x4u *>(dst) = v;
+                        else if (TAILS) {
 #pragma unroll
                             for (int e = 0; e < 3; ++e)
-                                if ((int)pd0[i] + e < segk) dst[e] = v[e];
+                                if (o0 + e < c) dst[e] = v[e];
                         }
                     }
                 }
             }
-            __builtin_amdgcn_wave_barrier();
             if (AHEAD) {
 #pragma unroll
-                for (int i = 0; i < GEN_NI; ++i) g4[i] = g4n[i];
+                for (int e = 0; e < 16; ++e) gv[e] = gvn[e];
             }
         }
         if (!more) break;
-        t = tn;
+        u = un;
         ok = okn;
+        row0 = row0n;
         if (BACKWARD) fetch_p(bf, pbasen);
         else {
 #pragma unroll
@@ -545,30 +489,25 @@ static hipError_t launch_sig_mfma(bool backward, int b, int n, int c, const floa
 {
     constexpr int NG = 32 / CPAD;
     const int nkt = (c + NG - 1) / NG, ng = (c + 7) / 8;
+    const size_t lds = ((size_t)nkt * ng * 256 + (size_t)nkt * 32) * sizeof(float);         // 132 KB at C = 32
     const bool tails = (c & 3) != 0;
     const void *fn = backward ? (tails ? (const void *)gen_sig_t_mean_mfma_kernel<CPAD, true, true> : (const void *)gen_sig_t_mean_mfma_kernel<CPAD, true, false>)
                               : (tails ? (const void *)gen_sig_t_mean_mfma_kernel<CPAD, false, true> : (const void *)gen_sig_t_mean_mfma_kernel<CPAD, false, false>);
-    const long long tiles = ((long long)b * n + 31) / 32;
-    // ranges of row tiles (a workgroup stages the weights of one): the fewest whose weights fit beside the 16 waves' tiles and
-    // that leave the last round of a range's waves >= 85 % full (one workgroup per CU: 88+ registers x 1024 threads)
-    const long long cus = device_cus();
-    auto lds_of = [&](int ks) {
-        const int per = (nkt + ks - 1) / ks;
-        return ((size_t)per * ng * 256 + (size_t)per * 32 + (size_t)GEN_MW * 32 * GEN_RS) * sizeof(float);
-    };
-    int ksplit = 1;
-    for (; ksplit < nkt; ++ksplit) {
-        if (lds_of(ksplit) > 160 * 1024) continue;
-        const long long waves = cus / ksplit * GEN_MW, rounds = (tiles + waves - 1) / (waves > 0 ? waves : 1);
-        if (waves > 0 && (tiles <= waves || tiles * 100 >= rounds * waves * 85 || ksplit >= 4)) break;
-    }
-    const size_t lds = lds_of(ksplit);
-    if (lds > 160 * 1024 || cus < ksplit) return hipErrorInvalidValue;
     hipError_t e = allow_big_lds(fn, lds);
     if (e != hipSuccess) return e;
-    long long nb = cus / ksplit;             // workgroups per range
-    if (nb > (tiles + GEN_MW - 1) / GEN_MW) nb = (tiles + GEN_MW - 1) / GEN_MW;
-    const long long blocks = nb * ksplit;
+    const long long tiles = ((long long)b * n + 31) / 32;
+    int per_cu = 0;                          // workgroups of 16 waves that share a CU (registers and LDS)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, GEN_MT, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const long long cap = (long long)per_cu * device_cus(), waves = cap * GEN_MW;
+    // ranges of row tiles per point tile: the fewest that leave the last round of the resident waves >= 85 % full (every
+    // unit boundary is a wait for the wave's stores in flight)
+    int ksplit = 1;
+    for (; ksplit < nkt; ++ksplit) {
+        const long long units = tiles * ksplit, rounds = (units + waves - 1) / waves;
+        if (units <= waves || units * 100 >= rounds * waves * 85) break;
+    }
+    long long blocks = (tiles * ksplit + GEN_MW - 1) / GEN_MW;
+    if (blocks > cap) blocks = cap;
 #define GEOT_GEN_SIG(BW, TL)                                                                                                   \
     hipLaunchKernelGGL((gen_sig_t_mean_mfma_kernel<CPAD, BW, TL>), dim3((int)blocks), dim3(GEN_MT), lds, s, b * n, n, c, ksplit, p, W, \
                        cm, grad_out, out)
@@ -581,12 +520,9 @@ static hipError_t launch_sig_mfma(bool backward, int b, int n, int c, const floa
 hipError_t gen_sig_t_mean(bool backward, int b, int n, int c, const float *p, const float *W, const float *cm,
                           const float *grad_out, float *out, hipStream_t s)
 {
-    const char *impl = getenv("GEOT_NTM_GENERIC");      // A/B tests: "mfma" / "rows" = the lane-per-point kernel / "wave" = the wave-per-point kernel
+    const char *impl = getenv("GEOT_NTM_GENERIC");      // A/B tests: "rows" = the lane-per-point kernel, "wave" = the wave-per-point kernel
     const bool small = (long long)b * n * c * c < 0x7fffffffLL * 4LL;
-    // the MFMA form from C = 6 up (kernel times at 8 x 24000 points, C = 5: 18 / 32 us against the lane-per-point form's
-    // 17 / 30; C = 7: 20 / 41 against 33 / 64 -- profiles/r05_ntm_generic.txt)
-    const bool want_mfma = impl && impl[0] == 'm' ? true : (impl && (impl[0] == 'r' || impl[0] == 'w') ? false : c >= 6);
-    if (want_mfma && (long long)b * n * c * c < (1LL << 30)) {
+    if ((!impl || (impl[0] != 'r' && impl[0] != 'w')) && (long long)b * n * c * c < (1LL << 30)) {
         if (c <= 8) return launch_sig_mfma<8>(backward, b, n, c, p, W, cm, grad_out, out, s);
         if (c <= 16) return launch_sig_mfma<16>(backward, b, n, c, p, W, cm, grad_out, out, s);
         return launch_sig_mfma<32>(backward, b, n, c, p, W, cm, grad_out, out, s);
