@@ -393,6 +393,33 @@ HOST_ISSUE = {}     # seconds the host needed to queue the timed steps (the last
 HOST_ISSUE_MAIN = {}
 
 
+class ReplayGuard:
+    """N > 1 only.  A hipGraph replay that holds an RCCL all-reduce has run here on ONE rank only (this pool has no multi-GPU
+    box for the builder); if such a replay were to stall on a real node, every rank would sit in it until the driver's limit.
+    The guard turns that into a finished run: the eager DistributedDataParallel step is timed FIRST (a short leg), and if the
+    capture + replays that follow do not finish inside the deadline every rank leaves -- rank 0 after printing the bench line
+    of that eager leg, marked as such.  Cancelled as soon as the timed replay region is over."""
+
+    def __init__(self, seconds, line):
+        import threading
+        self.done = threading.Event()
+        self.line = line
+        self.thread = threading.Thread(target=self._watch, args=(seconds,), daemon=True)
+        self.thread.start()
+
+    def _watch(self, seconds):
+        if self.done.wait(seconds):
+            return
+        sys.stderr.write("bench.py: the hipGraph replay did not finish in %.0f s -- reporting the eager leg measured before it\n" % seconds)
+        sys.stderr.flush()
+        if self.line is not None:
+            print(self.line, flush=True)
+        os._exit(0)
+
+    def cancel(self):
+        self.done.set()
+
+
 def timed_steps(step, steps, dev, rehearsal):
     """barrier + synchronize, `steps` steps, synchronize + barrier; MAX over ranks of the elapsed seconds."""
     import torch
@@ -643,6 +670,22 @@ def main():
             if workload == "model":
                 return graphed(cur[0], cur[1], cur[2], next_pos=nxt[0] if lookahead else None)
             return graphed(cur[0], cur[1], next_batches=nxt if lookahead else None)["loss"]
+    guard = None
+    if use_graph and world > 1:
+        k_g = max(2, min(args.steps, 5))
+        for _ in range(2):
+            eager_step()
+        t_g, out_g = timed_steps(eager_step, k_g, dev, rehearsal)
+        fallback = {"metric": "point-clouds/sec (24k pts, 17 classes) fwd+bwd", "value": world * clouds_per_step * k_g / t_g,
+                    "unit": "clouds/s", "n_gpus": world, "steps": k_g, "warmup": 2, "ms_per_step": 1e3 * t_g / k_g,
+                    "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": desc + "; eager DistributedDataParallel step -- the hipGraph replay that is the "
+                                           "primary mode at N > 1 did not finish inside its deadline on this node (ReplayGuard)",
+                               "clouds_per_gpu": clouds_per_step, "points": N_POINTS, "parallelism": parallelism,
+                               "stand_in": False},
+                    "roofline": None, "cpu_baseline": None, "final_loss": float(out_g.float().mean())}
+        guard = ReplayGuard(float(os.environ.get("GEOT_BENCH_REPLAY_DEADLINE", "300")) + 2.0 * args.steps,
+                            json.dumps(_finite(fallback), allow_nan=False) if rank == 0 else None)
     if use_graph:
         try:
             for _ in range(graphed.warmup + 1):     # eager over the static buffers, then the capture + first replay
@@ -717,6 +760,8 @@ def main():
         elapsed, out = timed_steps(dealt_step, args.steps, dev, rehearsal)
     else:
         elapsed, out = timed_steps(step, args.steps, dev, rehearsal)
+    if guard is not None:
+        guard.cancel()
     HOST_ISSUE_MAIN["ms"] = 1e3 * HOST_ISSUE["s"] / max(args.steps, 1)
     HOST_ISSUE_MAIN["cpu_ms"] = 1e3 * HOST_ISSUE["cpu_s"] / max(args.steps, 1)
     assert torch.isfinite(out).all()

@@ -179,3 +179,32 @@ def test_lookahead_gemm_selection_differs_from_the_alone_file_only_where_it_was_
     assert 10 <= len(changed) <= 40
     # 8-cloud supervised shapes only: 4096 tokens (8 x 512 groups) or 131072 group points (8 x 512 x 32) in the parameters
     assert all(any(tok in k[1].split("_") for tok in ("4096", "131072")) or "_B_32_" in k[1] for k in changed), changed
+
+
+def test_replay_guard_reports_the_eager_leg_when_a_replay_stalls(tmp_path):
+    """N > 1: a replay that never returns must not cost the run -- after the deadline rank 0 prints the line of the eager leg it
+    timed first and every rank leaves with 0; a replay that finishes cancels the guard."""
+    prog = textwrap.dedent("""
+        import importlib.util, sys, time
+        spec = importlib.util.spec_from_file_location("geot_bench", %r)
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        mode = sys.argv[1]
+        g = bench.ReplayGuard(0.3, '{"metric": "eager leg"}' if mode != "other_rank" else None)
+        if mode == "finishes":
+            g.cancel()
+            time.sleep(0.8)
+            print("done")
+            sys.exit(0)
+        time.sleep(30)              # the stalled replay
+        print("late")
+    """ % os.path.join(ROOT, "bench.py"))
+    script = tmp_path / "guard.py"
+    script.write_text(prog)
+    env = dict(os.environ, GEOT_BUILD_ON_IMPORT="0")
+    r = subprocess.run([sys.executable, str(script), "stalls"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines() == ['{"metric": "eager leg"}'] and "did not finish" in r.stderr
+    r = subprocess.run([sys.executable, str(script), "other_rank"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == ""
+    r = subprocess.run([sys.executable, str(script), "finishes"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and r.stdout.strip() == "done"

@@ -439,3 +439,58 @@ def test_rowsum_f64_and_the_bias_gradient_it_feeds(shape):
     assert torch.equal(gy, g)
     lead = tuple(range(g.dim() - 2)) + (g.dim() - 1,)
     assert torch.allclose(gb.double(), g.double().sum(lead), rtol=2e-7, atol=1e-30)
+
+
+@pytest.mark.parametrize("b,n,m,c,kind", [
+    (2, 24000, 8192, 64, "nn"),        # the model's first FP stage (8.8 pairs per target)
+    (1, 6000, 1500, 256, "nn"),        # 12 pairs per target
+    (2, 1000, 100, 32, "random"),      # random ids: a band of lists wants every source row
+    (1, 1500, 96, 16, "random"),       # 47 pairs per target
+    (2, 3000, 700, 48, "hub"),         # empty lists, one target with a third of all pairs
+])
+@pytest.mark.parametrize("relu", [True, False])
+def test_bn_row_gather_against_fp64_in_both_target_orders(b, n, m, c, kind, relu):
+    """geot_gather_rows_csr_bn_cl called directly (the BatchNorm(+ReLU) backward folded into the interpolation gradient):
+    against fp64, and with / without the Morton order of the targets -- the order moves rows between workgroups, no sum:
+    the same bits."""
+    from geot_amd import fused_norm as fn
+    from geot_amd.ext import pointnet2_ext as p2
+    from geot_amd.ext._common import call, ptr
+    torch.manual_seed(n + m)
+    pos = _cloud(b, n, 3)
+    known = pos[:, torch.randperm(n, device=DEV)[:m]].contiguous()
+    if kind == "nn":
+        d2, idx = p2.three_nn(pos, known)
+        w = p2.fp_weights(d2)
+    else:
+        idx = torch.randint(0, m - 1 if kind == "hub" else m, (b, n, 3), device=DEV, dtype=torch.int32)
+        if kind == "hub":
+            idx[:, ::3, 1] = 5
+            idx[idx == 7] = 8                       # target 7 and m - 1 get no pairs
+        w = torch.rand(b, n, 3, device=DEV)
+        w = (w / w.sum(-1, keepdim=True)).contiguous()
+    y = torch.randn(b, n, c, device=DEV)
+    dz = torch.randn(b, n, c, device=DEV)
+    scale, shift, mean = torch.randn(c, device=DEV), torch.randn(c, device=DEV), 0.1 * torch.randn(c, device=DEV)
+    rstd, c1, c2 = torch.rand(c, device=DEV) + 0.5, 0.01 * torch.randn(c, device=DEV), 0.01 * torch.randn(c, device=DEV)
+    outs = {}
+    for ordered in (True, False):
+        order = fn.local_spatial_order(known) if ordered else None
+        rix = fn.ReverseIndex(idx, w, m, order)
+        out = torch.full((b, m, c), float("nan"), device=DEV)
+        call("geot_gather_rows_csr_bn_cl", DEV, b, c, n, m, 3, int(relu), ptr(y), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
+             ptr(rstd), ptr(c1), ptr(c2), ptr(rix.ws), ptr(order), ptr(out))
+        outs[ordered] = out
+    assert torch.equal(outs[True], outs[False])
+    # fp64: gy = k0 (g - c1 - xhat c2), g = dz [relu: y k0 + shift > 0], then the interpolation gradient
+    y64, dz64 = y.double().cpu(), dz.double().cpu()
+    k0, mu, rs = scale.double().cpu(), mean.double().cpu(), rstd.double().cpu()
+    mask = ((y.cpu() * scale.cpu() + shift.cpu()) > 0).double() if relu else 1.0     # (the mask as fp32 evaluates it)
+    gy = k0 * (dz64 * mask - c1.double().cpu() - (y64 - mu) * rs * c2.double().cpu())
+    want = torch.zeros(b, m, c, dtype=torch.float64)
+    src = (gy.unsqueeze(2) * w.double().cpu().unsqueeze(-1)).reshape(b, n * 3, c)
+    want.scatter_add_(1, idx.long().cpu().reshape(b, n * 3, 1).expand(-1, -1, c), src)
+    got = outs[True]
+    assert rel(got.transpose(1, 2), want.transpose(1, 2)) <= 2e-5 * (30 if kind == "hub" else 1)
+    if kind == "hub":
+        assert float(got[:, 7].abs().max()) == 0.0 and float(got[:, m - 1].abs().max()) == 0.0
