@@ -1514,8 +1514,182 @@ __global__ __launch_bounds__(1024) void gather_rows_csr_bn_cl_kernel(
     }
 }
 
+// ---- the BatchNorm form for FEW targets: the sources stream, the targets' sums stay in registers ------------------------
+// At the two 512-target stages (8192 <- 512 and 4096 <- 512: 48 and 24 pairs per target) the list walk reads every source
+// row ~2.5 times (profiles/r04_gr_small_stages.txt): a band of lists wants far more rows than an XCD's L2 keeps.  With so few
+// targets the roles turn: a workgroup takes (cloud, 128-byte slab of the rows) and ALL targets -- thread (target slot, column)
+// keeps the three running sums of up to GC_TPT targets in registers -- and the sources stream past in memory order, GC_K rows
+// at a time through a double-buffered LDS chunk (loads two chunks ahead, masked and centred on the way in): every row is
+// fetched ONCE, by 128-byte coalesced pieces.  What a thread adds from a chunk is decided once per index (rix_chunks_kernel):
+// the chunk's pairs grouped by target, ascending pair id inside a group, as (row within the chunk, weight) entries behind an
+// offset table -- both copied into the chunk's buffer.  Chunks ascend, pair ids ascend inside a chunk: a target's sum is formed
+// in the list walk's order with the list walk's fma chain -- the same bits; no atomics, one writer per output element.
+constexpr int GC_K = 256;                  // source rows per chunk
+constexpr int GC_S = 8;                    // float4 columns per slab (128 bytes of a row)
+constexpr int GC_THREADS = 1024;           // GC_RPT (row, column) elements per thread while staging
+constexpr int GC_RPT = GC_K * GC_S / GC_THREADS;
+constexpr int GC_TPT = 4;                  // targets per thread: slots tid / GC_S + 128 i
+constexpr int GC_MAXM = GC_TPT * GC_THREADS / GC_S;     // 512
+constexpr int GC_MAXNT = 4;                // pairs per source (entries of a chunk: GC_K x nt <= 1024)
+
+static inline bool gc_shape(long long L, int m, int nt) { return m <= GC_MAXM && nt <= GC_MAXNT && L * nt >= 16LL * m; }
+static inline bool gc_applies(long long L, int m, int nt)
+{
+    const char *e = getenv("GEOT_GR_FORM");        // "list": the list walk everywhere (A/B runs)
+    return !(e && e[0] == 'l') && gc_shape(L, m, nt);
+}
+static inline long long gc_chunks(long long L) { return (L + GC_K - 1) / GC_K; }
+
+// per (cloud, chunk): coff[t] = first entry | entries << 16 of target t (the chunk's entries grouped by target), cent = (row within
+// the chunk, weight) in ascending pair order inside a group
+__global__ __launch_bounds__(GC_K * GC_MAXNT) void rix_chunks_kernel(int L, int m, int nt, long long nchunk, const int *__restrict__ idx,
+                                                         const float *__restrict__ weight, int *__restrict__ coff,
+                                                         uint2 *__restrict__ cent)
+{
+    __shared__ int cnt[GC_MAXM + 1], tg[GC_K * GC_MAXNT];
+    const int tid = threadIdx.x;
+    const long long bi = blockIdx.x / nchunk, ch = blockIdx.x - bi * nchunk;
+    const int e0 = (int)ch * GC_K, rows = min(GC_K, L - e0), np = rows * nt;
+    const long long x0 = (bi * L + e0) * nt;                 // first pair of the chunk
+    for (int i = tid; i <= m; i += GC_K * GC_MAXNT) cnt[i] = 0;
+    __syncthreads();
+    const int j = tid < np ? idx[x0 + tid] : -1;
+    if (tid < np) {
+        tg[tid] = j;
+        atomicAdd(&cnt[j + 1], 1);
+    }
+    __syncthreads();
+    if (tid < 64) {                                           // inclusive scan of cnt[1 .. m] by one wave
+        int carry = 0;
+        for (int piece = 0; piece < m; piece += 64) {
+            const int i = piece + tid;
+            int v = i < m ? cnt[i + 1] : 0;
+#pragma unroll
+            for (int sh = 1; sh < 64; sh <<= 1) {
+                const int o = __shfl_up(v, sh);
+                if (tid >= sh) v += o;
+            }
+            if (i < m) cnt[i + 1] = v + carry;
+            carry += __shfl(v, 63);
+        }
+    }
+    __syncthreads();
+    int *co = coff + (size_t)blockIdx.x * (m + 1);
+    for (int i = tid; i < m; i += GC_K * GC_MAXNT) co[i] = cnt[i] | ((cnt[i + 1] - cnt[i]) << 16);    // first entry | entries (both <= 1024)
+    if (tid == 0) co[m] = cnt[m];
+    if (tid < np) {
+        int r = 0;                                            // pairs of the same target in front of this one
+        for (int y = 0; y < tid; ++y) r += tg[y] == j ? 1 : 0;
+        cent[(size_t)blockIdx.x * (GC_K * GC_MAXNT) + cnt[j] + r] = make_uint2((unsigned)(tid / nt), __float_as_uint(weight ? weight[x0 + tid] : 1.f));
+    }
+}
+
+__global__ __launch_bounds__(GC_THREADS) void gather_rows_chunks_bn_cl_kernel(
+    int c4, int L, int m, int nt, long long nchunk, int relu, const cl_f4 *__restrict__ y, const cl_f4 *__restrict__ dz,
+    const cl_f4 *__restrict__ scale, const cl_f4 *__restrict__ shift, const cl_f4 *__restrict__ mean, const cl_f4 *__restrict__ rstd,
+    const cl_f4 *__restrict__ c1, const cl_f4 *__restrict__ c2, const int *__restrict__ coff, const uint2 *__restrict__ cent,
+    cl_f4 *__restrict__ out)
+{
+    // two buffers of: rows [GC_K][GC_S] masked gradient | [GC_K][GC_S] centred input | offsets [m + 1 .. padded to GC_MAXM + 4] | entries
+    constexpr int ROWS = GC_K * GC_S, OFFS = GC_MAXM + 4, ENTS = GC_K * GC_MAXNT;
+    static_assert(ENTS == GC_THREADS && GC_RPT * GC_THREADS == ROWS, "one entry per thread, GC_RPT row elements per thread");
+    constexpr int BUF_BYTES = 2 * ROWS * 16 + OFFS * 4 + ENTS * 8;
+    extern __shared__ char gc_lds[];
+    const int tid = threadIdx.x, col = tid % GC_S, slot = tid / GC_S;
+    const int slabs = c4 / GC_S, slab = blockIdx.x % slabs, bi = blockIdx.x / slabs;
+    const int q = slab * GC_S + col;
+    const cl_f4 k0s = scale[q], sh = shift[q], mu = mean[q];
+    const cl_f4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto rowsG = [&](int b) { return reinterpret_cast<cl_f4 *>(gc_lds + (size_t)b * BUF_BYTES); };
+    auto rowsY = [&](int b) { return rowsG(b) + ROWS; };
+    auto offs = [&](int b) { return reinterpret_cast<int *>(gc_lds + (size_t)b * BUF_BYTES + 2 * ROWS * 16); };
+    auto ents = [&](int b) { return reinterpret_cast<uint2 *>(gc_lds + (size_t)b * BUF_BYTES + 2 * ROWS * 16 + OFFS * 4); };
+    const cl_f4 *yb = y + (size_t)bi * L * c4 + q, *gb = dz + (size_t)bi * L * c4 + q;
+    const int *cob = coff + (size_t)bi * nchunk * (m + 1);
+    const uint2 *ceb = cent + (size_t)bi * nchunk * ENTS;
+    // loads unconditional, indices clamped (a clamped value is never used)
+    auto load_rows = [&](long long ch, cl_f4 (&vy)[GC_RPT], cl_f4 (&vg)[GC_RPT]) {
+#pragma unroll
+        for (int u = 0; u < GC_RPT; ++u) {
+            const long long e = min(min(ch, nchunk - 1) * GC_K + slot + u * (GC_THREADS / GC_S), (long long)L - 1);
+            vy[u] = yb[e * c4];
+            vg[u] = gb[e * c4];
+        }
+    };
+    auto load_index = [&](long long ch, int &o, uint2 &en) {
+        ch = min(ch, nchunk - 1);
+        o = cob[ch * (m + 1) + min(tid, m)];
+        en = ceb[ch * ENTS + tid];
+    };
+    cl_f4 G[GC_TPT], Y[GC_TPT];
+    float W[GC_TPT];
+#pragma unroll
+    for (int i = 0; i < GC_TPT; ++i) {
+        G[i] = Y[i] = zero;
+        W[i] = 0.f;
+    }
+    cl_f4 py[2][GC_RPT], pg[2][GC_RPT];
+    int po;
+    uint2 pe;
+    load_rows(0, py[0], pg[0]);
+    load_rows(1, py[1], pg[1]);
+    load_index(0, po, pe);
+    for (long long ch = 0; ch < nchunk; ch += 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const long long cc = ch + b;
+            if (cc < nchunk) {                               // (uniform)
+#pragma unroll
+                for (int u = 0; u < GC_RPT; ++u) {
+                    const cl_f4 vy = py[b][u], vg = pg[b][u];
+                    cl_f4 g;
+                    g.x = (!relu || fmaf(vy.x, k0s.x, sh.x) > 0.f) ? vg.x : 0.f;
+                    g.y = (!relu || fmaf(vy.y, k0s.y, sh.y) > 0.f) ? vg.y : 0.f;
+                    g.z = (!relu || fmaf(vy.z, k0s.z, sh.z) > 0.f) ? vg.z : 0.f;
+                    g.w = (!relu || fmaf(vy.w, k0s.w, sh.w) > 0.f) ? vg.w : 0.f;
+                    rowsG(b)[tid + u * GC_THREADS] = g;      // (row slot + u 128, column): tid = slot * GC_S + col
+                    rowsY(b)[tid + u * GC_THREADS] = vy - mu;
+                }
+                if (tid <= m) offs(b)[tid] = po;
+                ents(b)[tid] = pe;                           // (ENTS = GC_THREADS)
+                load_rows(cc + 2, py[b], pg[b]);
+                load_index(cc + 1, po, pe);
+                __syncthreads();                             // chunk cc is in buffer b; every thread has finished chunk cc - 1
+                const cl_f4 *sG = rowsG(b), *sY = rowsY(b);
+                const int *so = offs(b);
+                const uint2 *se = ents(b);
+#pragma unroll
+                for (int i = 0; i < GC_TPT; ++i) {
+                    const int t = slot + i * (GC_THREADS / GC_S);
+                    if (t < m) {
+                        const int az = so[t], a = az & 0xffff, z = a + (az >> 16);
+                        for (int p = a; p < z; ++p) {
+                            const uint2 en = se[p];
+                            const float w = __uint_as_float(en.y);
+                            G[i] = __builtin_elementwise_fma((cl_f4)(w), sG[en.x * GC_S + col], G[i]);
+                            Y[i] = __builtin_elementwise_fma((cl_f4)(w), sY[en.x * GC_S + col], Y[i]);
+                            W[i] += w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    const cl_f4 A = -(k0s * rstd[q] * c2[q]), k0c1 = k0s * c1[q];
+#pragma unroll
+    for (int i = 0; i < GC_TPT; ++i) {
+        const int t = slot + i * (GC_THREADS / GC_S);
+        if (t < m) {
+            // (a target without pairs: W = 0 and the list walk writes +0)
+            const cl_f4 r = W[i] == 0.f && G[i].x == 0.f ? __builtin_elementwise_fma(k0s, G[i], __builtin_elementwise_fma(A, Y[i], zero))
+                                                         : __builtin_elementwise_fma(k0s, G[i], __builtin_elementwise_fma(A, Y[i], -(k0c1 * W[i])));
+            __builtin_nontemporal_store(r, out + ((size_t)bi * m + t) * c4 + q);
+        }
+    }
+}
+
 struct RixLayout {
-    long long t, pairs, off, bsum, rank, rev, revw, rtgt, tmp, rank_of, ints;
+    long long t, pairs, off, bsum, rank, rev, revw, rtgt, tmp, rank_of, coff, cent, ints;
 };
 static inline RixLayout rix_layout(int b, long long L, int m, int nt)
 {
@@ -1530,7 +1704,11 @@ static inline RixLayout rix_layout(int b, long long L, int m, int nt)
     r.rtgt = r.revw + r.pairs;
     r.tmp = r.rtgt + r.pairs;
     r.rank_of = r.tmp + r.pairs;
-    r.ints = r.rank_of + r.t + 8;
+    // the few-target form's tables (gc_shape): per (cloud, chunk) an offset per target + 1, GC_K x GC_MAXNT entries of 2 words
+    const long long chunks = gc_shape(L, m, nt) ? (long long)b * gc_chunks(L) : 0;
+    r.coff = (r.rank_of + r.t + 1) & ~1LL;          // (entries are 8-byte words)
+    r.cent = (r.coff + chunks * (m + 1) + 1) & ~1LL;
+    r.ints = r.cent + chunks * GC_K * GC_MAXNT * 2 + 8;
     return r;
 }
 
@@ -1808,6 +1986,9 @@ GEOT_EXPORT int geot_rix_build(int b, int L, int m, int nt, const int *idx, cons
     else
         hipLaunchKernelGGL((rix_place_cl_kernel<false>), dim3(pb), dim3(256), 0, s, r.pairs, pbatch, m, nt, L, idx, weight, rank_of,
                            off, ws + r.rank, ws + r.tmp, ws + r.rev, revw, (unsigned *)(ws + r.rtgt));
+    if (gc_shape(L, m, nt))                         // (whatever GEOT_GR_FORM says now: the index may outlive the setting)
+        hipLaunchKernelGGL(rix_chunks_kernel, dim3((unsigned)(b * gc_chunks(L))), dim3(GC_K * GC_MAXNT), 0, s, L, m, nt, gc_chunks(L), idx, weight,
+                           ws + r.coff, (uint2 *)(ws + r.cent));
     return hipGetLastError();
 }
 
@@ -1869,6 +2050,17 @@ GEOT_EXPORT int geot_gather_rows_csr_bn_cl(int b, int c, int L, int m, int nt, i
     if (c % 4 || c / 4 > 1024) return hipErrorInvalidValue;
     const RixLayout r = rix_layout(b, L, m, nt);
     if (r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL) return hipErrorInvalidValue;
+    if ((c / 4) % GC_S == 0 && gc_applies(L, m, nt) && (long long)b * (c / 4 / GC_S) <= 0x7fffffffLL) {
+        // few targets: the sources stream once, the sums stay in registers (the target order plays no part: rows are written by id)
+        const size_t lds = 2 * (size_t)(2 * GC_K * GC_S * 16 + (GC_MAXM + 4) * 4 + GC_K * GC_MAXNT * 8);
+        hipError_t e = allow_big_lds((const void *)gather_rows_chunks_bn_cl_kernel, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gather_rows_chunks_bn_cl_kernel, dim3((unsigned)(b * (c / 4 / GC_S))), dim3(GC_THREADS), lds, (hipStream_t)stream,
+                           c / 4, L, m, nt, gc_chunks(L), relu, (const cl_f4 *)y_cl, (const cl_f4 *)dz_cl, (const cl_f4 *)scale,
+                           (const cl_f4 *)shift, (const cl_f4 *)mean, (const cl_f4 *)rstd, (const cl_f4 *)c1, (const cl_f4 *)c2,
+                           ws + r.coff, (const uint2 *)(ws + r.cent), (cl_f4 *)out_cl);
+        return hipGetLastError();
+    }
     const int c4 = c / 4, slabs = gr_slabs(c4), waves = (c4 / slabs + 63) / 64;
     const int cus = device_cus();
     static int per_cu_of[GEOT_DEV_SLOTS][1024 / 64 + 1];

@@ -444,15 +444,18 @@ def test_rowsum_f64_and_the_bias_gradient_it_feeds(shape):
 @pytest.mark.parametrize("b,n,m,c,kind", [
     (2, 24000, 8192, 64, "nn"),        # the model's first FP stage (8.8 pairs per target)
     (1, 6000, 1500, 256, "nn"),        # 12 pairs per target
-    (2, 1000, 100, 32, "random"),      # random ids: a band of lists wants every source row
-    (1, 1500, 96, 16, "random"),       # 47 pairs per target
-    (2, 3000, 700, 48, "hub"),         # empty lists, one target with a third of all pairs
+    (2, 8192, 512, 64, "nn"),          # the second FP stage: 48 pairs per target -> the few-target form (sources stream once)
+    (1, 4099, 300, 96, "nn"),          # the same form: a last chunk of 3 rows, fewer targets than slots
+    (2, 1000, 100, 32, "random"),      # random ids, 30 pairs per target
+    (1, 1500, 96, 32, "hub"),          # few targets, empty lists, one target with a third of all pairs
+    (2, 3000, 700, 48, "hub"),         # the list walk with empty lists and a hub
 ])
 @pytest.mark.parametrize("relu", [True, False])
-def test_bn_row_gather_against_fp64_in_both_target_orders(b, n, m, c, kind, relu):
+def test_bn_row_gather_against_fp64_in_both_target_orders(b, n, m, c, kind, relu, monkeypatch):
     """geot_gather_rows_csr_bn_cl called directly (the BatchNorm(+ReLU) backward folded into the interpolation gradient):
-    against fp64, and with / without the Morton order of the targets -- the order moves rows between workgroups, no sum:
-    the same bits."""
+    against fp64; with / without the Morton order of the targets (the order moves rows between workgroups, no sum: the same
+    bits); and the few-target form (<= 512 targets, long lists: sums in registers, sources streamed once) against the list walk
+    it replaces there (GEOT_GR_FORM=list) -- the same pairs in the same order through the same fma chain: the same bits."""
     from geot_amd import fused_norm as fn
     from geot_amd.ext import pointnet2_ext as p2
     from geot_amd.ext._common import call, ptr
@@ -477,10 +480,14 @@ def test_bn_row_gather_against_fp64_in_both_target_orders(b, n, m, c, kind, relu
     for ordered in (True, False):
         order = fn.local_spatial_order(known) if ordered else None
         rix = fn.ReverseIndex(idx, w, m, order)
-        out = torch.full((b, m, c), float("nan"), device=DEV)
-        call("geot_gather_rows_csr_bn_cl", DEV, b, c, n, m, 3, int(relu), ptr(y), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
-             ptr(rstd), ptr(c1), ptr(c2), ptr(rix.ws), ptr(order), ptr(out))
-        outs[ordered] = out
+        for form in ("default", "list"):
+            monkeypatch.setenv("GEOT_GR_FORM", form)
+            out = torch.full((b, m, c), float("nan"), device=DEV)
+            call("geot_gather_rows_csr_bn_cl", DEV, b, c, n, m, 3, int(relu), ptr(y), ptr(dz), ptr(scale), ptr(shift), ptr(mean),
+                 ptr(rstd), ptr(c1), ptr(c2), ptr(rix.ws), ptr(order), ptr(out))
+            outs[(ordered, form)] = out
+        assert torch.equal(outs[(ordered, "default")], outs[(ordered, "list")])
+        outs[ordered] = outs[(ordered, "default")]
     assert torch.equal(outs[True], outs[False])
     # fp64: gy = k0 (g - c1 - xhat c2), g = dz [relu: y k0 + shift > 0], then the interpolation gradient
     y64, dz64 = y.double().cpu(), dz.double().cpu()
