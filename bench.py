@@ -245,6 +245,21 @@ def pmc_traffic(kernel, tag):
     return None, None
 
 
+def pmc_launches(kernel, tag):
+    """launches of `kernel` in the PMC pass pmc_traffic() quotes (None: the profile predates the field)"""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*%s*_pmc_traffic.json" % tag)),
+                   key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))])
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        for name, rec in json.load(f).get("kernels", {}).items():
+            if kernel in name:
+                return rec.get("launches")
+    return None
+
+
 def sq_share(kernel, tag):
     """Executed-work figure of `kernel` from the committed SQ counter passes of this command (profiles/*<tag>*_sq_counters.json,
     tools/profile_bench.sh): the share of the cycles its CUs were busy in which a vector instruction was issuing
@@ -886,9 +901,20 @@ def main():
             tg = TOOTH_SEG_CFG["downsample_targets"]
             stages = [(N_POINTS, tg[0]), (tg[0], TOOTH_SEG_CFG["num_group"]), (tg[1], TOOTH_SEG_CFG["num_group"])]   # (n, m) of prop0 / 1 / 2
             gr_bytes = sum(4.0 * B * c_fp * (2 * n_ + m_) for n_, m_ in stages)
-            t3, s3 = pmc_traffic("gather_rows_csr_bn_cl_kernel", tag) if B == default_b else (None, None)
+            # (24000 <- 8192 is the list walk, the two 512-target stages the few-target form: per-launch PMC bytes of both kernels,
+            # weighted by their launch counts in the profiled run)
+            t3 = s3 = None
+            if B == default_b:
+                parts = [pmc_traffic(k, tag) + (pmc_launches(k, tag),) for k in ("gather_rows_csr_bn_cl_kernel", "gather_rows_chunks_bn_cl_kernel")]
+                parts = [p for p in parts if p[0] is not None]
+                if parts and all(p[2] for p in parts):
+                    t3 = sum(p[0] * p[2] for p in parts) / sum(p[2] for p in parts)
+                    s3 = parts[0][1]
+                elif parts:
+                    t3, s3 = parts[0][0], parts[0][1]
             result["roofline_hbm"] = {
-                "kernel": "gather_rows_csr_bn_cl_kernel (3 launches per step: FP stages 24000<-8192, 8192<-512, 4096<-512 at C = %d)" % c_fp,
+                "kernel": "gather_rows_csr_bn_cl_kernel + gather_rows_chunks_bn_cl_kernel (geot_gather_rows_csr_bn_cl, 3 launches per step: "
+                          "FP stages 24000<-8192, 8192<-512, 4096<-512 at C = %d)" % c_fp,
                 "bound": "hbm", "achieved": gr_bytes / (gr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gr_bytes / (gr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": t3, "traffic_source": s3,
                 "algorithmic_bytes_per_launch": gr_bytes / 3, "avg_launch_ms": gr_ms / 3,

@@ -37,7 +37,8 @@ def main():
                 continue
             f = sum(F[k]["FETCH_SIZE"]) / len(F[k]["FETCH_SIZE"])
             w = sum(W[k]["WRITE_SIZE"]) / len(W[k]["WRITE_SIZE"]) if k in W else 0.0
-            kernels[short(k)] = {"fetch_kb": f, "write_kb": w, "traffic_bytes": int(round((2 * f + w) * 1024))}
+            kernels[short(k)] = {"fetch_kb": f, "write_kb": w, "traffic_bytes": int(round((2 * f + w) * 1024)),
+                                 "launches": len(F[k]["FETCH_SIZE"])}
         import subprocess
         try:
             commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
