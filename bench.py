@@ -478,6 +478,18 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist_utils.init("gloo" if rehearsal else "nccl")
+    # GEOT_BENCH_SOLO_DP=1 (one rank): the N > 1 code paths on ONE rank over RCCL -- DDP + SyncBatchNorm wrapped, the replay with
+    # its captured all-reduce, the eager-first leg and its guard, the comm audit -- so that a one-GPU box executes every line
+    # the multi-GPU run will (tests/test_dist_gpu.py); `multi` selects code paths, `world` stays the arithmetic
+    solo = world == 1 and os.environ.get("GEOT_BENCH_SOLO_DP") == "1"
+    if solo and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    multi = world > 1 or solo
+    min_world = 1 if solo else 2
 
     from geot_amd import _lib, build as hip_build
     from geot_amd.synth import make_batch, region_labels
@@ -511,7 +523,7 @@ def main():
     parallelism = "independent clouds per rank, no collective"
     # N > 1: the step replayed from hipGraphs (no host on the critical path) needs its collectives captured -- RCCL only, and
     # never in the one-GPU rehearsal over gloo.  GEOT_BENCH_DP_GRAPH=0: the eager DistributedDataParallel step as primary.
-    dp_graph = (world > 1 and not rehearsal and workload in ("model", "fixmatch") and not args.no_graph
+    dp_graph = (multi and not rehearsal and workload in ("model", "fixmatch") and not args.no_graph
                 and os.environ.get("GEOT_BENCH_DP_GRAPH", "1") != "0")
     trainer_g = None
 
@@ -522,7 +534,7 @@ def main():
         torch.manual_seed(1609)
         model = PointTransformer_seg_T(**TOOTH_SEG_CFG, dense=args.dense).to(dev)
         dense_mode = model.dense
-        net = ts.ddp(model, dev, unused=ts.UNUSED_SUPERVISED)
+        net = ts.ddp(model, dev, unused=ts.UNUSED_SUPERVISED, min_world=min_world)
         ddp_modules = [net] if net is not model else []
         trainer = ts.SupervisedStep(net)
         target = torch.from_numpy(region_labels(xyz_np)).to(dev)
@@ -531,10 +543,10 @@ def main():
         fps_rounds = max(TOOTH_SEG_CFG["downsample_targets"]) - 1
         desc = ("configs[2]: B=%d x %dk-pt clouds, full transformer_finetune backbone PointTransformer_seg_T "
                 "(trans_dim 384, depth 12, 512 groups x 32, targets 8192/4096/2048) fwd + Poly1FocalLoss + bwd + AdamW, "
-                "train mode, random init" % (B, N_POINTS // 1000)) if world == 1 else \
+                "train mode, random init" % (B, N_POINTS // 1000)) if not multi else \
                ("configs[3]: data-parallel %d x (B=%d x %dk-pt clouds), same model; SyncBatchNorm + DDP gradient "
                 "all-reduce over %s" % (world, B, N_POINTS // 1000, "gloo (rehearsal)" if rehearsal else "RCCL"))
-        if world > 1:
+        if multi:
             parallelism = "dp%d: DistributedDataParallel (25 MB buckets, overlapped with backward) + SyncBatchNorm" % world
 
         # two batches, alternating, as a loader with one batch of look-ahead delivers them: the step is told the NEXT batch's
@@ -555,18 +567,18 @@ def main():
             # all-reduce between backward and optimizer (train_step.sync_only / GradSync) -- the form a hipGraph can hold
             model_g = PointTransformer_seg_T(**TOOTH_SEG_CFG, dense=args.dense).to(dev)
             model_g.load_state_dict(model.state_dict())
-            net_g = ts.sync_only(model_g)
+            net_g = ts.sync_only(model_g, min_world=min_world)
             trainer_g = ts.SupervisedStep(net_g, grad_sync=ts.GradSync([net_g], torch.distributed.group.WORLD))
     elif workload == "fixmatch":
         from geot_amd import train_step as ts
         torch.manual_seed(1609)
-        trainer = ts.build_fixmatch(dev, use_ddp=True,
-                                    group=torch.distributed.group.WORLD if world > 1 else None)
-        if world > 1:
+        trainer = ts.build_fixmatch(dev, use_ddp=True, min_world=min_world,
+                                    group=torch.distributed.group.WORLD if multi else None)
+        if multi:
             ddp_modules = [trainer.model, trainer.T_predictor]
         if dp_graph:
             torch.manual_seed(1609)         # (the same initial weights as `trainer`)
-            trainer_g = ts.build_fixmatch(dev, graph_sync=True, group=torch.distributed.group.WORLD)
+            trainer_g = ts.build_fixmatch(dev, graph_sync=True, min_world=min_world, group=torch.distributed.group.WORLD)
         from geot_amd.pointops.functions import pointops as pops
         patch_owner, patch_name = pops, "furthestsampling_uniform"      # the student's 8192-sample FPS: its largest kernel
         from geot_amd.openpoints.models.backbone.transformer import TOOTH_SEG_CFG
@@ -587,7 +599,7 @@ def main():
         desc = ("configs[4]: FixMatch+NTM semi-supervised step per rank: teacher fwd on %d weak clouds, student fwd+bwd on "
                 "%d labelled + %d strong + %d weak clouds x %dk pts, class transition + sig_t_mean + logit correction + "
                 "threeD_space_loss(k=32) + Poly1Focal losses, AdamW x2" % (bu, bl, bu, bu, N_POINTS // 1000))
-        if world > 1:
+        if multi:
             parallelism = "dp%d: DDP(student) + DDP(T_predictor) + SyncBatchNorm + all-gather of the class anchors" % world
 
         # a second pair of batches: the iterations alternate, and each is told the next one's batches (FixMatchNTMStep look-ahead)
@@ -655,10 +667,10 @@ def main():
     # way; the replay 2 % behind at 4 clouds, level at 8 -- and the dominant kernel's HIP events, which the roofline block
     # needs from the timed region, can only be recorded on eager launches).
     # --graph / --no-graph force the primary mode (--no-graph also skips the replay leg).
-    can_replay = workload in ("model", "fixmatch") and (world == 1 or dp_graph) and not args.no_graph
+    can_replay = workload in ("model", "fixmatch") and (not multi or dp_graph) and not args.no_graph
     # N > 1: the replay is the primary mode whenever it captures (on every rank: `agree`) -- an eager rank needs ~1.5 host cores
     # continuously, eight of them share one host
-    use_graph = can_replay and (args.graph or workload == "fixmatch" or B <= 3 or world > 1)
+    use_graph = can_replay and (args.graph or workload == "fixmatch" or B <= 3 or multi)
     eager_step = step
     graphed = replay_step = None
     replay_refused = None
@@ -671,10 +683,10 @@ def main():
         from geot_amd import graph_step as gs
         try:
             graphed = (gs.GraphedSupervisedStep if workload == "model" else gs.GraphedFixMatchStep)(
-                trainer_g if world > 1 else trainer, agree=agree if world > 1 else None)
+                trainer_g if multi else trainer, agree=agree if multi else None)
         except RuntimeError as e:                   # e.g. packet capture left on by the environment without GEOT_GRAPH_LAUNCH=fast
             replay_refused, use_graph, can_replay = "%s: %s" % (type(e).__name__, str(e)[:600]), False, False
-        if world > 1 and not agree(graphed is not None):      # one verdict for all ranks, before any of them replays
+        if multi and not agree(graphed is not None):          # one verdict for all ranks, before any of them replays
             replay_refused = replay_refused or "another rank could not construct its replay"
             graphed, use_graph, can_replay = None, False, False
     if can_replay:
@@ -686,7 +698,7 @@ def main():
                 return graphed(cur[0], cur[1], cur[2], next_pos=nxt[0] if lookahead else None)
             return graphed(cur[0], cur[1], next_batches=nxt if lookahead else None)["loss"]
     guard = None
-    if use_graph and world > 1:
+    if use_graph and multi:
         k_g = max(2, min(args.steps, 5))
         for _ in range(2):
             eager_step()
@@ -808,7 +820,7 @@ def main():
                      "host_issue_ms_per_step": 1e3 * HOST_ISSUE["s"] / k_e,
                      "host_cpu_ms_per_step": 1e3 * HOST_ISSUE["cpu_s"] / k_e, "steps": k_e,
                      "note": ("the same iterations, same model state continuing, launched kernel by kernel from the host"
-                              if use_graph and world == 1 else
+                              if use_graph and not multi else
                               "the eager DistributedDataParallel step (25-MB buckets overlapped with the backward) on the same "
                               "batches, its own copy of the model" if use_graph else
                               "the same iterations, same model state continuing, replayed from single-stream hipGraphs "
@@ -955,7 +967,7 @@ def main():
                               "top_entry_points_ms": dict(sorted(att.items(), key=lambda kv: -kv[1])[:8]),
                               "note": "HIP-event durations around every C-ABI launch in 2 extra untimed iterations; the FPS "
                                       "launches and the teacher run on side streams, so this is GPU work, not wall time"}
-    if world > 1:
+    if multi:
         # Audit trail for a multi-GPU record: (a) an all-reduce of ones over the backend the step used -- the number of
         # ranks that really took part; (b) what the gradient all-reduce costs on the critical path: the same steps with
         # DDP's reduction switched off (no_sync: gradients stay local; SyncBatchNorm and the anchor exchange still talk)
@@ -965,19 +977,20 @@ def main():
         dist.all_reduce(ones)
         k2 = max(2, min(args.steps, 5))
 
-        def local_step():
+        def local_step():          # (the eager DDP step: a replay holds its all-reduce inside the graph)
             with contextlib.ExitStack() as stack:
                 for m in ddp_modules:
                     stack.enter_context(m.no_sync())
-                return step()
+                return eager_step()
         local_step()
         t_local, _ = timed_steps(local_step, k2, dev, rehearsal)
+        eager_ms = other_leg["ms_per_step"] if (use_graph and other_leg) else ms_per_step
         grad_bytes = sum(p.numel() * 4 for m in ddp_modules for p in m.parameters() if p.requires_grad)
         result["comm"] = {"backend": dist.get_backend(), "ranks_in_collective": int(ones.item()),
                           "gradient_allreduce_mb_per_step": grad_bytes / 1e6,
                           "ms_per_step_without_gradient_allreduce": 1e3 * t_local / k2,
-                          "exposed_allreduce_ms": ms_per_step - 1e3 * t_local / k2,
-                          "note": "exposed = timed step minus the same step under DDP.no_sync() (%d steps); negative = noise" % k2}
+                          "exposed_allreduce_ms": eager_ms - 1e3 * t_local / k2,
+                          "note": "exposed = the eager DDP step minus the same step under DDP.no_sync() (%d steps); negative = noise" % k2}
         # What a scaling line needs to be attributed: the host side of every rank (N ranks share one host: issue time is
         # the first suspect when N x the one-GPU rate is not reached), the collectives a step really issues, and the step
         # with the look-ahead off (its FPS / index kernels run beside RCCL's all-reduce kernels when it is on)
@@ -996,7 +1009,8 @@ def main():
         for n_ in real:
             setattr(dist, n_, counted(n_))
         try:
-            step()                 # one untimed step with the python-level collectives counted (SyncBatchNorm in bn_act, anchors)
+            eager_step()           # one untimed EAGER step with the python-level collectives counted (SyncBatchNorm in bn_act,
+            # anchors); a replayed step issues the same ones from inside its graphs, plus GradSync's one flat all-reduce
         finally:
             for n_, f_ in real.items():
                 setattr(dist, n_, f_)
@@ -1024,7 +1038,7 @@ def main():
                                     "look-ahead graph on a side stream, bit-identical to the eager step, "
                                     "tests/test_graph_step_gpu.py); the eager leg of the same run is `eager`") if use_graph else
                                    ("primary mode = eager: N > 1 runs DistributedDataParallel, whose buckets and collectives are "
-                                    "host logic" if world > 1 else
+                                    "host logic" if multi else
                                     "primary mode = eager" + ("; the hipGraph replay of the same iterations is `replay` (primary for "
                                                               "the FixMatch iteration and at <= 3 clouds, where the eager "
                                                               "step is host-bound)" if can_replay else
@@ -1046,7 +1060,7 @@ def main():
         result["config"]["lookahead"] = ("the step is handed the next batch's coordinates (two batches alternate) and queues "
                                          "their sampling / grouping / index work beside its own backward"
                                          if lookahead else "off: all of a batch's work inside its own step")
-    if workload in ("model", "fixmatch") and world == 1 and lookahead and not args.no_dense_reference:
+    if workload in ("model", "fixmatch") and not multi and lookahead and not args.no_dense_reference:
         # the same steps without the look-ahead (every batch's sampling at the head of its own step), observed in this run
         runner = graphed if use_graph else trainer      # (the replay's "plain" variant is captured by the first call)
 
@@ -1060,7 +1074,7 @@ def main():
         result["lookahead"] = {"ms_per_step_without": 1e3 * t_plain / k3, "clouds_per_s_without": clouds_per_step * k3 / t_plain,
                                "steps": k3, "note": "same model, same alternating batches, next_pos=None: every step samples "
                                                     "and groups its own batch before its encoder can start"}
-    if workload == "model" and world == 1 and dense_mode != "reference" and not args.no_dense_reference:
+    if workload == "model" and not multi and dense_mode != "reference" and not args.no_dense_reference:
         # the same step with every layer in the REFERENCE's op order (first 1x1 conv after the gather, op-by-op attention /
         # LayerNorm) on the same kernels: what the algebraic re-ordering is worth, observed in this run
         del trainer, net
@@ -1080,7 +1094,7 @@ def main():
                                               "steps": 3, "note": "--dense reference: the reference's op order, same HIP "
                                                                   "kernels and GEMM selection; 1 warm-up + 3 timed steps"}
         del ref_trainer, ref_model
-    if workload == "sa" and world == 1 and not args.graph and not args.no_saturated and B < 64:
+    if workload == "sa" and not multi and not args.graph and not args.no_saturated and B < 64:
         # one cloud occupies ONE of the 256 CUs in FPS (96 % of this step): the same module at 256 clouds per launch
         # is what the chip does when every CU has a cloud (the reference's per-cloud semantics are unchanged)
         bs = 256
@@ -1096,7 +1110,7 @@ def main():
                                "steps": 3, "note": "same SetAbstraction forward with one cloud per CU (256 clouds in one "
                                                    "call): throughput when FPS fills the chip"}
         del xs, fs
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         if workload == "sa":
             from geot_amd.pointnet2.pointnet2_modules import PointnetSAModuleVotes
             torch.manual_seed(1609)
@@ -1107,14 +1121,14 @@ def main():
             result["cpu_baseline"] = cpu_baseline_model()
         elif workload == "fixmatch":
             result["cpu_baseline"] = cpu_baseline_fixmatch(bl, bu)
-    if (rank == 0 and world == 1 and workload == "model" and not args.no_also and args.clouds is None
+    if (rank == 0 and not multi and workload == "model" and not args.no_also and args.clouds is None
             and args.points == N_POINTS and not args.graph and not args.no_graph and args.dense is None):
         # the driver's default invocation: configs[1] and configs[4] into the same record, after the primary leg's timing
         torch.cuda.empty_cache()
         result["also"] = also_legs(args)
     if rank == 0:
         print(json.dumps(_finite(result), allow_nan=False), flush=True)
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         dist.barrier()                      # rank 0 may still be printing: leave together
         dist.destroy_process_group()

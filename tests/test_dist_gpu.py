@@ -382,3 +382,32 @@ def test_bench_one_gpu_line_has_both_modes_or_says_why_not(packet_capture_env):
     else:
         assert g["replayed"] is True and g["launch_mode"] == "inspected" and "replay_refused" not in g
         assert all(set(v) == {"kernel"} for v in g["nodes"].values())
+
+
+@pytest.mark.parametrize("workload", ["model", "fixmatch"])
+def test_bench_multi_gpu_code_paths_on_one_rank_over_rccl(workload):
+    """GEOT_BENCH_SOLO_DP=1: every line the N > 1 bench will execute, on ONE rank over RCCL -- DDP + SyncBatchNorm wrapped, the
+    short eager-DDP leg timed first with the replay guard armed, the step captured with its flat gradient all-reduce and
+    replayed (kernel-only graphs), the eager leg after it, the comm audit (no_sync leg, per-rank host figures, collectives
+    counted) -- so that the multi-GPU run meets no code for the first time.  (What one rank cannot show: a transfer.)"""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DEBUG_CLR_GRAPH_PACKET_CAPTURE",
+                        "GEOT_GRAPH_LAUNCH")}
+    env["GEOT_BENCH_SOLO_DP"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--clouds", "2" if workload == "model" else "1",
+           "--steps", "3", "--warmup", "1", "--points", "8192", "--no-cpu-baseline", "--no-dense-reference", "--no-also"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                        # the guard stayed silent: ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and np.isfinite(rec["ms_per_step"])
+    assert rec["config"]["parallelism"].startswith("dp1: D")
+    g = rec["graph"]
+    assert g["replayed"] is True and "replay_refused" not in g, g
+    assert all(set(v) == {"kernel"} for v in g["nodes"].values())
+    assert "eager" in rec and rec["eager"]["ms_per_step"] > 0          # the DDP step, timed after the replay
+    assert rec["comm"]["backend"] == "nccl" and rec["comm"]["ranks_in_collective"] == 1
+    assert rec["comm"]["gradient_allreduce_mb_per_step"] > 50
+    assert "ranks" in rec and len(rec["ranks"]["host_issue_ms_per_step"]["per_rank"]) == 1
+    assert "ReplayGuard" not in rec["config"]["workload"]
