@@ -1,10 +1,12 @@
 """Mirror of the openpoints-flavoured SetAbstraction / FeaturePropagation modules
 (openpoints/models/backbone/pointnetv2.py:17-100 PointNetSAModuleMSG, :103-146 PointNetFPModule):
 FPS (K1', no origin skip) -> gather -> per-scale LocalAggregation -> concat, and
-three_nn -> inverse-distance weights -> three_interpolate -> concat skip -> Conv1d stack.
-Same constructor arguments, forward signatures and return values."""
+three_nn -> inverse-distance weights -> three_interpolate -> concat skip -> Conv1d stack;
+and of the encoder / decoder that stack them (:149-345 PointNet2Encoder, :348-381 PointNet2Decoder).
+Same constructor arguments, forward signatures, return values and state_dict keys."""
 import copy
-from typing import List
+import logging
+from typing import List, Optional
 
 import torch
 import torch.nn as nn
@@ -80,3 +82,127 @@ class PointNetFPModule(nn.Module):
         else:
             new_features = interpolated_feats
         return self.convs(new_features)
+
+
+def _as_dict(args):
+    """group_args arrives as a dict or an attribute bag (the reference writes .radius / .nsample into an EasyDict)"""
+    return copy.deepcopy(dict(args)) if args is not None else {}
+
+
+class PointNet2Encoder(nn.Module):
+    """Encoder of PointNet++ / ASSANet (pointnetv2.py:149-345): an optional stem (point-wise conv, optional local
+    aggregation at full resolution), then one PointNetSAModuleMSG per stride.  radius / num_samples: a scalar (scaled per
+    stage by radius_scaling / nsample_scaling, per block by block_radius_scaling) or per-stage lists; channel sizes from
+    `mlps` or from width / layers / width_scaling.  forward -> (list of xyz, list of features), input first."""
+
+    def __init__(self, in_channels: int, radius, num_samples, aggr_args: dict, group_args: dict, conv_args: dict,
+                 norm_args: dict, act_args: dict, blocks: Optional[List] = None, mlps=None, width: Optional[int] = None,
+                 strides: List[int] = [4, 4, 4, 4], layers: int = 3, width_scaling: int = 2, radius_scaling: int = 2,
+                 block_radius_scaling: int = 1, nsample_scaling: int = 1, sampler: str = 'fps', use_res=False,
+                 stem_conv=False, stem_aggr=False, double_last_channel=True, query_as_support=False, **kwargs):
+        super().__init__()
+        if kwargs:
+            logging.warning("kwargs: %s are not used in PointNet2Encoder", kwargs)
+        self.strides = list(strides)
+        self.blocks = list(blocks) if mlps is None else [len(m) for m in mlps]
+        self.radius = self._per_block(radius, radius_scaling, block_radius_scaling)
+        self.num_samples = self._per_block(num_samples, nsample_scaling, 1)
+        self.stem_conv, self.stem_aggr = stem_conv, stem_aggr
+        if stem_conv:
+            width = width if width is not None else mlps[0][0][0]
+            self.conv1 = create_convblock1d(in_channels, width, norm_args=None, act_args=None)
+            if stem_aggr:
+                ga = _as_dict(group_args)
+                ga['radius'], ga['nsample'] = self.radius[0][0], self.num_samples[0][0]
+                self.stem = LocalAggregation([width] * (layers + 1), aggr_args, conv_args, norm_args, act_args, ga, use_res)
+            in_channels = width
+        if mlps is None:
+            assert width is not None and layers is not None
+            mlps = []
+            for i, stride in enumerate(self.strides):
+                grown = width * width_scaling if stride > 1 else width
+                if double_last_channel:             # the first block of a stage ends on the stage's new width
+                    mlps.append([[width] * (layers - 1) + [grown]] + [[grown] * layers] * (self.blocks[i] - 1))
+                else:
+                    mlps.append([[width] * layers] * self.blocks[i])
+                width = grown
+        self.mlps = mlps
+        self.SA_modules = nn.ModuleList()
+        self.channel_list = [in_channels]
+        for k, stride in enumerate(self.strides):
+            per_block = [[in_channels] + list(m) for m in mlps[k]]
+            self.SA_modules.append(PointNetSAModuleMSG(
+                stride=stride, radii=self.radius[k], nsamples=self.num_samples[k], channel_list=per_block,
+                aggr_args=aggr_args, group_args=_as_dict(group_args), conv_args=conv_args, norm_args=norm_args,
+                act_args=act_args, sampler=sampler, use_res=use_res, query_as_support=query_as_support))
+            in_channels = sum(m[-1] for m in per_block)      # the blocks' outputs are concatenated
+            self.channel_list.append(in_channels)
+        self.out_channels = in_channels
+
+    def _per_block(self, param, stage_scaling, block_scaling):
+        """radius / nsample as [stage][block] (pointnetv2.py:290-307)"""
+        if isinstance(param, (list, tuple)):
+            full = []
+            for i, value in enumerate(param):
+                value = list(value) if isinstance(value, (list, tuple)) else [value]
+                full.append(value + [value[-1]] * (self.blocks[i] - len(value)))
+            return full
+        full = []
+        for i, stride in enumerate(self.strides):
+            if stride == 1:
+                full.append([param] * self.blocks[i])
+            else:
+                full.append([param] + [param * block_scaling] * (self.blocks[i] - 1))
+                param = param * stage_scaling
+        return full
+
+    def _stem(self, xyz, features):
+        if hasattr(xyz, 'keys'):
+            xyz, features = xyz['pos'], xyz['x']
+        if features is None:
+            features = xyz.clone().transpose(1, 2).contiguous()
+        xyz = xyz.contiguous()
+        if self.stem_conv:
+            features = self.conv1(features)
+        if self.stem_aggr:
+            features = self.stem(xyz, xyz, features)
+        return xyz, features
+
+    def forward_cls_feat(self, xyz, features=None):
+        xyz, features = self._stem(xyz, features)
+        for sa in self.SA_modules:
+            xyz, features = sa(xyz, features)
+        return features.squeeze(-1)
+
+    def forward_seg_feat(self, xyz, features=None):
+        xyz, features = self._stem(xyz, features)
+        l_xyz, l_features = [xyz], [features]
+        for sa in self.SA_modules:
+            xyz, features = sa(l_xyz[-1], l_features[-1])
+            l_xyz.append(xyz)
+            l_features.append(features)
+        return l_xyz, l_features
+
+    def forward(self, xyz, features=None):
+        return self.forward_seg_feat(xyz, features)
+
+
+class PointNet2Decoder(nn.Module):
+    """Decoder of PointNet++ (pointnetv2.py:348-381): one PointNetFPModule per encoder stage, coarsest first; stage k takes
+    the skip of level k and the output of stage k + 1 (the encoder's last features for the coarsest)."""
+
+    def __init__(self, encoder_channel_list: List[int], mlps=None, fp_mlps=None, decoder_layers=1, **kwargs):
+        super().__init__()
+        skips = list(encoder_channel_list)
+        if fp_mlps is None:
+            fp_mlps = [[mlps[0][0][0]] * (decoder_layers + 1)] + [[c] * (decoder_layers + 1) for c in skips[1:-1]]
+        self.FP_modules = nn.ModuleList()
+        for k, widths in enumerate(fp_mlps):
+            below = fp_mlps[k + 1][-1] if k + 1 < len(fp_mlps) else skips[-1]
+            self.FP_modules.append(PointNetFPModule([below + skips[k]] + list(widths)))
+        self.out_channels = fp_mlps[0][-1]
+
+    def forward(self, l_xyz, l_features):
+        for i in range(len(self.FP_modules) - 1, -1, -1):
+            l_features[i] = self.FP_modules[i](l_xyz[i], l_xyz[i + 1], l_features[i], l_features[i + 1])
+        return l_features[0]

@@ -1,8 +1,7 @@
-"""Mirror of the ConvPool local aggregation the reference's openpoints PointNet++ encoder is built from
-(openpoints/models/layers/local_aggregation.py:12-29 CHANNEL_MAP, :140-242 ConvPool, :246-288
+"""Mirror of the local aggregations the reference's openpoints PointNet++ / ASSANet encoder is built from
+(openpoints/models/layers/local_aggregation.py:12-29 CHANNEL_MAP, :32-138 ASSA, :140-242 ConvPool, :246-288
 LocalAggregation; conv blocks openpoints/models/layers/conv.py:24-103 in their default
-'conv-norm-act' order).  Only the 'convpool' aggregator is on the GeoT path (the ASSA variant belongs
-to another model family and is not reproduced).
+'conv-norm-act' order): the callers of the grouping operators (QueryAndGroup / KNNGroup / GroupAll).
 
 In eval mode without autograd, a ('dp_fj', max-reduction, conv->BN->ReLU, ball-query) ConvPool runs
 the fused HIP SetAbstraction kernel (geot_amd/csrc/sa_mlp.hip): the (B, 3+C, npoint, nsample) grouped
@@ -19,11 +18,18 @@ from .group import create_grouper, get_aggregation_feautres, ball_query, QueryAn
 CHANNEL_MAP = {
     'fj': lambda x: x,
     'df': lambda x: x,
+    'assa': lambda x: x * 3,
+    'assa_dp': lambda x: x * 3 + 3,
     'dp_fj': lambda x: 3 + x,
     'pj': lambda x: x,
     'dp': lambda x: 3,
+    'pi_dp': lambda x: x + 3,
+    'pj_dp': lambda x: x + 3,
     'dp_fj_df': lambda x: x * 2 + 3,
+    'dp_fi_df': lambda x: x * 2 + 3,
     'pi_dp_fj_df': lambda x: x * 2 + 6,
+    'pj_dp_fj_df': lambda x: x * 2 + 6,
+    'pj_dp_df': lambda x: x + 6,
     'dp_df': lambda x: x + 3,
 }
 
@@ -157,17 +163,72 @@ class ConvPool(nn.Module):
         return out_features
 
 
+class ASSA(nn.Module):
+    """Anisotropic separable set abstraction (local_aggregation.py:32-138): point-wise convolutions, grouping, the three
+    relative coordinates times every grouped channel reduced over the neighbourhood, point-wise convolutions, residual.
+    `convs` holds both conv stacks under the reference's indices (same state_dict keys).  The reduction never needs the
+    (B, 3 C, npoint, nsample) product the reference materialises when it is a sum or a mean: it is one contraction over the
+    neighbourhood of the grouper's two outputs (channel a C + c = coordinate a times feature c, the reference's view)."""
+
+    def __init__(self, channels: List[int], conv_args=None, norm_args=None, act_args=None, group_args=None,
+                 feature_type='dp_fj', reduction='mean', use_res=True, use_inverted_dims=False):
+        super().__init__()
+        conv_args = dict(conv_args or {})
+        channels = list(channels)
+        self.feature_type, self.use_res, self.reduction = feature_type, use_res, reduction
+        self.num_preconv = n_pre = -(-(len(channels) - 1) // 2)
+        if feature_type == 'assa' and not use_inverted_dims:
+            channels[n_pre] = -(-channels[n_pre] // 3)
+        convs = [create_convblock1d(channels[i], channels[i + 1], norm_args=norm_args, act_args=act_args, **conv_args)
+                 for i in range(n_pre)]
+        skip_channels = channels[n_pre]
+        channels[n_pre] = CHANNEL_MAP[feature_type](channels[n_pre])
+        last = len(channels) - 2
+        convs += [create_convblock1d(channels[i], channels[i + 1], norm_args=norm_args,
+                                     act_args=None if use_res and i == last else act_args, **conv_args)
+                  for i in range(n_pre, len(channels) - 1)]
+        self.act = create_act(act_args)
+        self.convs = nn.Sequential(*convs)
+        if use_res:
+            self.skip_layer = nn.Identity() if skip_channels == channels[-1] else nn.Conv1d(skip_channels, channels[-1], 1, bias=False)
+        self.grouper = create_grouper(group_args)
+        if reduction not in ('max', 'avg', 'mean', 'sum'):
+            raise NotImplementedError('reduction %s not implemented' % reduction)
+
+    def forward(self, query_xyz, support_xyz, features, query_idx=None):
+        features = self.convs[:self.num_preconv](features)
+        dp, fj = self.grouper(query_xyz, support_xyz, features)          # (B, 3, P, S), (B, C, P, S)
+        if self.use_res and query_idx is not None:
+            features = torch.gather(features, -1, query_idx.unsqueeze(1).expand(-1, features.shape[1], -1))
+        b, c, npoint, nsample = fj.shape
+        if self.reduction == 'max':
+            prod = (fj.unsqueeze(1) * dp.unsqueeze(2)).reshape(b, 3 * c, npoint, nsample)
+            out = prod.max(dim=-1)[0]
+        else:
+            out = torch.einsum('baps,bcps->bacp', dp, fj).reshape(b, 3 * c, npoint)
+            if self.reduction != 'sum':
+                out = out / nsample
+        out = self.convs[self.num_preconv:](out)
+        if self.use_res:
+            out = self.act(out + self.skip_layer(features))
+        return out
+
+
 class LocalAggregation(nn.Module):
     def __init__(self, channels: List[int], aggr_args: dict, conv_args=None, norm_args=None, act_args=None,
                  group_args=None, use_res=False):
         super().__init__()
         aggr_args = dict(aggr_args or {})
-        aggr_type = aggr_args.get('NAME', 'convpool')
-        if aggr_type.lower() != 'convpool':
-            raise NotImplementedError('LocalAggregation %s is not on the GeoT path' % aggr_type.lower())
-        self.SA_CONFIG_operator = ConvPool(channels, conv_args, norm_args, act_args, group_args,
-                                           aggr_args.get('feature_type', 'dp_fj'), aggr_args.get('reduction', 'max'),
-                                           use_res, aggr_args.get('use_pooled_as_identity', False))
+        aggr_type = aggr_args.get('NAME', 'convpool').lower()
+        feature_type, reduction = aggr_args.get('feature_type', 'dp_fj'), aggr_args.get('reduction', 'max')
+        if aggr_type == 'convpool':
+            self.SA_CONFIG_operator = ConvPool(channels, conv_args, norm_args, act_args, group_args, feature_type, reduction,
+                                               use_res, aggr_args.get('use_pooled_as_identity', False))
+        elif aggr_type == 'assa':
+            self.SA_CONFIG_operator = ASSA(channels, conv_args, norm_args, act_args, group_args, feature_type, reduction,
+                                           use_res, aggr_args.get('use_inverted_dims', False))
+        else:
+            raise NotImplementedError('LocalAggregation %s not implemented' % aggr_type)
 
     def forward(self, query_xyz, support_xyz, support_features, query_idx=None):
         return self.SA_CONFIG_operator(query_xyz, support_xyz, support_features, query_idx)

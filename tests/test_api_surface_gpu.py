@@ -224,3 +224,93 @@ def test_patch_embeddings_on_the_hip_operators():
     assert np.array_equal(ps[1].cpu().numpy(), idx1)          # stage 1 centres = the oracle's FPS prefix
     fs[-1].square().mean().backward()
     assert torch.isfinite(xg.grad).all() and float(xg.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum", "max"])
+@pytest.mark.parametrize("group", ["ballquery", "knn"])
+def test_assa_equals_its_definition(reduction, group):
+    """ASSA (openpoints/models/layers/local_aggregation.py:32-138): pre-convs, grouping, every grouped channel times each of
+    the three relative coordinates reduced over the neighbourhood (channel a C + c), post-convs, residual.  The module forms
+    sum / mean as one contraction; here the definition is spelled out -- the (B, 3 C, P, S) product, then the reduction."""
+    from geot_amd.openpoints.models.layers.local_aggregation import ASSA, LocalAggregation
+    torch.manual_seed(3)
+    b, n, p, c_in = 2, 600, 150, 12
+    xyz = torch.rand(b, n, 3, device=DEV)
+    idx = torch.stack([torch.randperm(n, device=DEV)[:p] for _ in range(b)])
+    q = torch.gather(xyz, 1, idx.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    feats = torch.randn(b, c_in, n, device=DEV, requires_grad=True)
+    la = LocalAggregation([c_in, 24, 24, 36], {"NAME": "assa", "feature_type": "assa", "reduction": reduction},
+                          {}, {"norm": "bn1d"}, {"act": "relu"}, {"NAME": group, "radius": 0.25, "nsample": 16}, use_res=True).to(DEV)
+    m = la.SA_CONFIG_operator
+    assert isinstance(m, ASSA) and m.num_preconv == 2 and len(m.convs) == 3
+    # channels: 12 -> 24 -> ceil(24 / 3) = 8 before the reduction, 3 x 8 = 24 -> 36 after it; the residual is the 8-channel tensor
+    assert m.convs[1][0].out_channels == 8 and m.convs[2][0].in_channels == 24 and isinstance(m.skip_layer, torch.nn.Conv1d)
+    out = la(q, xyz, feats, query_idx=idx)
+    assert out.shape == (b, 36, p)
+    g = torch.randn_like(out)
+    out.backward(g)
+    got_grad = feats.grad.clone()
+    feats.grad = None
+    grads = [pp.grad.clone() for pp in la.parameters()]
+    la.zero_grad()
+    # the definition
+    f1 = m.convs[:2](feats)
+    dp, fj = m.grouper(q, xyz, f1)
+    prod = (fj.unsqueeze(1).expand(-1, 3, -1, -1, -1) * dp.unsqueeze(2)).reshape(b, -1, p, fj.shape[-1])
+    red = {"mean": prod.mean(-1), "sum": prod.sum(-1), "max": prod.max(-1)[0]}[reduction]
+    res = torch.gather(f1, -1, idx.unsqueeze(1).expand(-1, f1.shape[1], -1))
+    want = m.act(m.convs[2:](red) + m.skip_layer(res))
+    # (two train-mode passes move the BatchNorm running statistics twice; the batch statistics the outputs use are the same)
+    assert float((out - want).detach().abs().max()) <= 2e-5 * float(want.detach().abs().max())
+    want.backward(g)
+    assert float((got_grad - feats.grad).abs().max()) <= 5e-5 * float(feats.grad.abs().max())
+    for a, pp in zip(grads, la.parameters()):
+        assert float((a - pp.grad).abs().max()) <= 1e-4 * max(float(pp.grad.abs().max()), 1e-6)
+
+
+def test_pointnet2_encoder_decoder_on_the_hip_operators():
+    """PointNet2Encoder / PointNet2Decoder (openpoints/models/backbone/pointnetv2.py:149-381): the stage / block parameter
+    tables, the state_dict layout a reference checkpoint has, a segmentation forward + backward, the classification path,
+    and an ASSANet-style encoder (stem aggregation, residual blocks, query_as_support)."""
+    from geot_amd.openpoints.models.backbone.pointnetv2 import PointNet2Encoder, PointNet2Decoder
+    torch.manual_seed(0)
+    cfg = dict(aggr_args={"NAME": "convpool", "feature_type": "dp_fj", "reduction": "max"}, group_args={"NAME": "ballquery"},
+               conv_args={}, norm_args={"norm": "bn"}, act_args={"act": "relu"})
+    enc = PointNet2Encoder(3, 0.1, 16, blocks=[1, 2, 1], width=32, strides=[4, 4, 4], layers=3, radius_scaling=2,
+                           block_radius_scaling=1.5, nsample_scaling=2, **cfg).to(DEV)
+    assert enc.radius == [[0.1], [0.2, 0.2 * 1.5], [0.4]] and enc.num_samples == [[16], [32, 32], [64]]
+    assert enc.mlps == [[[32, 32, 64]], [[64, 64, 128], [128, 128, 128]], [[128, 128, 256]]]
+    assert enc.channel_list == [3, 64, 256, 256] and enc.out_channels == 256
+    keys = set(enc.state_dict())
+    assert "SA_modules.1.local_aggregations.1.SA_CONFIG_operator.convs.2.0.weight" in keys
+    assert "SA_modules.0.local_aggregations.0.SA_CONFIG_operator.convs.0.1.running_mean" in keys
+    dec = PointNet2Decoder(enc.channel_list, mlps=enc.mlps, decoder_layers=2).to(DEV)
+    # fp_mlps: [mlps[0][0][0]] * 3 for the finest level, then the skip widths of the inner levels; inputs = below + skip
+    assert [fp.convs[0][0].in_channels for fp in dec.FP_modules] == [64 + 3, 256 + 64, 256 + 256] and dec.out_channels == 32
+    assert "FP_modules.2.convs.1.0.weight" in set(dec.state_dict())
+    xyz = torch.rand(2, 2048, 3, device=DEV)
+    l_xyz, l_feat = enc(xyz)
+    assert [t.shape[1] for t in l_xyz] == [2048, 512, 128, 32] and [t.shape[1] for t in l_feat] == [3, 64, 256, 256]
+    out = dec(l_xyz, list(l_feat))
+    assert out.shape == (2, 32, 2048)
+    out.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in list(enc.parameters()) + list(dec.parameters()))
+    assert enc.forward_cls_feat({"pos": xyz[:, :64].contiguous(), "x": None}).shape == (2, 256)      # 64 -> 16 -> 4 -> 1 points
+    # eval: ConvPool takes the fused SetAbstraction kernel; the same features as the composed ops
+    enc.eval()
+    with torch.no_grad():
+        fused = enc(xyz)[1][-1]
+        for sa in enc.SA_modules:
+            for la in sa.local_aggregations:
+                la.SA_CONFIG_operator.fused_eval = False
+        composed = enc(xyz)[1][-1]
+    assert float((fused - composed).abs().max()) <= 2e-4 * float(composed.abs().max())
+    assa = PointNet2Encoder(3, 0.15, 16, aggr_args={"NAME": "assa", "feature_type": "assa", "reduction": "mean"},
+                            group_args={"NAME": "ballquery"}, conv_args={}, norm_args={"norm": "bn"}, act_args={"act": "relu"},
+                            blocks=[3, 3], width=48, strides=[4, 4], layers=3, use_res=True, stem_conv=True, stem_aggr=True,
+                            double_last_channel=False, query_as_support=True).to(DEV)
+    # (the stem's residual is the 16-channel tensor in front of the reduction: a 16 -> 48 skip convolution, as in the reference)
+    assert assa.channel_list == [48, 144, 288] and assa.state_dict()["stem.SA_CONFIG_operator.skip_layer.weight"].shape == (48, 16, 1)
+    lx, lf = assa(xyz)
+    assert [t.shape[1] for t in lf] == [48, 144, 288] and [t.shape[2] for t in lf] == [2048, 512, 128]
+    lf[-1].mean().backward()
