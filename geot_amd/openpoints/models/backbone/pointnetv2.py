@@ -2,7 +2,8 @@
 (openpoints/models/backbone/pointnetv2.py:17-100 PointNetSAModuleMSG, :103-146 PointNetFPModule):
 FPS (K1', no origin skip) -> gather -> per-scale LocalAggregation -> concat, and
 three_nn -> inverse-distance weights -> three_interpolate -> concat skip -> Conv1d stack;
-and of the encoder / decoder that stack them (:149-345 PointNet2Encoder, :348-381 PointNet2Decoder).
+and of the encoder / decoders that stack them (:149-345 PointNet2Encoder, :348-381 PointNet2Decoder, :384-512
+PointNet2PartDecoder).
 Same constructor arguments, forward signatures, return values and state_dict keys."""
 import copy
 import logging
@@ -205,4 +206,52 @@ class PointNet2Decoder(nn.Module):
     def forward(self, l_xyz, l_features):
         for i in range(len(self.FP_modules) - 1, -1, -1):
             l_features[i] = self.FP_modules[i](l_xyz[i], l_xyz[i + 1], l_features[i], l_features[i + 1])
+        return l_features[0]
+
+
+class PointNet2PartDecoder(nn.Module):
+    """Part-segmentation decoder (pointnetv2.py:384-512): the FP stack of PointNet2Decoder, computed from the ENCODER's
+    arguments (it rebuilds the encoder's channel table), with the object class as 16 one-hot channels beside the finest
+    level's skip features.  forward(l_xyz, l_features, cls_label (B, 1) int64) -> (B, out_channels, N)."""
+    NUM_OBJECT_CLASSES = 16
+
+    def __init__(self, in_channels: int, radius, num_samples, group_args: dict, conv_args: dict, norm_args: dict,
+                 act_args: dict, mlps=None, blocks: Optional[List] = None, width: Optional[int] = None, strides=[4, 4, 4, 4],
+                 layers=3, fp_mlps=None, decoder_layers=1, decocder_aggr_args=None, width_scaling=2, radius_scaling=2,
+                 nsample_scaling=1, use_res=False, stem_conv=False, double_last_channel=False, **kwargs):
+        super().__init__()
+        if kwargs:
+            logging.warning("kwargs: %s are not used in PointNet2PartDecoder", kwargs)
+        self.strides = list(strides)
+        self.blocks = list(blocks) if mlps is None else [len(m) for m in mlps]
+        if stem_conv:
+            in_channels = width
+        if mlps is None:
+            assert width is not None and layers is not None
+            mlps = []
+            for i, stride in enumerate(self.strides):
+                grown = width * (width_scaling if not double_last_channel else 2) if stride > 1 else width
+                if double_last_channel:
+                    mlps.append([[width] * (layers - 1) + [grown]] + [[grown] * layers] * (self.blocks[i] - 1))
+                else:                               # (this table holds output widths only: the stage's new width throughout)
+                    mlps.append([[grown] * layers] * self.blocks[i])
+                width = grown
+        self.mlps = mlps
+        skips = [in_channels] + [sum(m[-1] for m in stage) for stage in mlps]
+        if fp_mlps is None:
+            fp_mlps = [[mlps[0][0][0]] * (decoder_layers + 1)] + [[c] * (decoder_layers + 1) for c in skips[1:-1]]
+        skips[0] += self.NUM_OBJECT_CLASSES
+        self.FP_modules = nn.ModuleList()
+        for k, widths in enumerate(fp_mlps):
+            below = fp_mlps[k + 1][-1] if k + 1 < len(fp_mlps) else skips[-1]
+            self.FP_modules.append(PointNetFPModule([below + skips[k]] + list(widths)))
+        self.out_channels = fp_mlps[0][-1]
+
+    def forward(self, l_xyz, l_features, cls_label):
+        for i in range(len(self.FP_modules) - 1, 0, -1):
+            l_features[i] = self.FP_modules[i](l_xyz[i], l_xyz[i + 1], l_features[i], l_features[i + 1])
+        b, n = l_xyz[0].shape[:2]
+        one_hot = torch.zeros((b, self.NUM_OBJECT_CLASSES), device=l_xyz[0].device).scatter_(1, cls_label, 1)
+        skip = torch.cat([one_hot.unsqueeze(-1).expand(-1, -1, n), l_features[0]], 1)
+        l_features[0] = self.FP_modules[0](l_xyz[0], l_xyz[1], skip, l_features[1])
         return l_features[0]

@@ -314,3 +314,17 @@ def test_pointnet2_encoder_decoder_on_the_hip_operators():
     lx, lf = assa(xyz)
     assert [t.shape[1] for t in lf] == [48, 144, 288] and [t.shape[2] for t in lf] == [2048, 512, 128]
     lf[-1].mean().backward()
+    # the part-segmentation decoder rebuilds the encoder's table from the encoder's arguments; 16 one-hot class channels
+    # join the finest level's skip features
+    from geot_amd.openpoints.models.backbone.pointnetv2 import PointNet2PartDecoder
+    part = PointNet2PartDecoder(3, 0.15, 16, {"NAME": "ballquery"}, {}, {"norm": "bn"}, {"act": "relu"}, blocks=[3, 3], width=48,
+                                strides=[4, 4], layers=3, stem_conv=True, double_last_channel=False).to(DEV)
+    assert part.mlps == [[[96] * 3] * 3, [[192] * 3] * 3]         # (this class's table: the stage's NEW width throughout)
+    enc3 = PointNet2Encoder(3, 0.15, 16, blocks=[1, 1], width=48, strides=[4, 4], layers=3, double_last_channel=False,
+                            stem_conv=True, **cfg).to(DEV)
+    part3 = PointNet2PartDecoder(3, 0.15, 16, {"NAME": "ballquery"}, {}, {"norm": "bn"}, {"act": "relu"}, mlps=enc3.mlps,
+                                 strides=[4, 4], layers=3, stem_conv=True, width=48).to(DEV)
+    assert [fp.convs[0][0].in_channels for fp in part3.FP_modules] == [48 + 48 + 16, 96 + 48]
+    lx, lf = enc3(xyz)
+    seg = part3(lx, list(lf), torch.tensor([[3], [11]], device=DEV))
+    assert seg.shape == (2, 48, 2048) and torch.isfinite(seg).all()
