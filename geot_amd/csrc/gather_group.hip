@@ -1688,6 +1688,84 @@ __global__ __launch_bounds__(GC_THREADS) void gather_rows_chunks_bn_cl_kernel(
     }
 }
 
+// the plain row gather (geot_gather_rows_csr_cl) over the same chunks: one tensor streams, one running sum per (target, column)
+__global__ __launch_bounds__(GC_THREADS) void gather_rows_chunks_cl_kernel(int c4, int L, int m, long long nchunk, const cl_f4 *__restrict__ g,
+                                                                          const int *__restrict__ coff, const uint2 *__restrict__ cent,
+                                                                          cl_f4 *__restrict__ out)
+{
+    constexpr int ROWS = GC_K * GC_S, OFFS = GC_MAXM + 4, ENTS = GC_K * GC_MAXNT;
+    constexpr int BUF_BYTES = ROWS * 16 + OFFS * 4 + ENTS * 8;
+    extern __shared__ char gc_lds[];
+    const int tid = threadIdx.x, col = tid % GC_S, slot = tid / GC_S;
+    const int slabs = c4 / GC_S, slab = blockIdx.x % slabs, bi = blockIdx.x / slabs;
+    const int q = slab * GC_S + col;
+    const cl_f4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto rows = [&](int b) { return reinterpret_cast<cl_f4 *>(gc_lds + (size_t)b * BUF_BYTES); };
+    auto offs = [&](int b) { return reinterpret_cast<int *>(gc_lds + (size_t)b * BUF_BYTES + ROWS * 16); };
+    auto ents = [&](int b) { return reinterpret_cast<uint2 *>(gc_lds + (size_t)b * BUF_BYTES + ROWS * 16 + OFFS * 4); };
+    const cl_f4 *gb = g + (size_t)bi * L * c4 + q;
+    const int *cob = coff + (size_t)bi * nchunk * (m + 1);
+    const uint2 *ceb = cent + (size_t)bi * nchunk * ENTS;
+    auto load_rows = [&](long long ch, cl_f4 (&v)[GC_RPT]) {         // unconditional, indices clamped
+#pragma unroll
+        for (int u = 0; u < GC_RPT; ++u)
+            v[u] = gb[min(min(ch, nchunk - 1) * GC_K + slot + u * (GC_THREADS / GC_S), (long long)L - 1) * c4];
+    };
+    auto load_index = [&](long long ch, int &o, uint2 &en) {
+        ch = min(ch, nchunk - 1);
+        o = cob[ch * (m + 1) + min(tid, m)];
+        en = ceb[ch * ENTS + tid];
+    };
+    cl_f4 acc[GC_TPT];
+#pragma unroll
+    for (int i = 0; i < GC_TPT; ++i) acc[i] = zero;
+    cl_f4 pv[2][GC_RPT];
+    int po;
+    uint2 pe;
+    load_rows(0, pv[0]);
+    load_rows(1, pv[1]);
+    load_index(0, po, pe);
+    for (long long ch = 0; ch < nchunk; ch += 2) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const long long cc = ch + b;
+            if (cc < nchunk) {                               // (uniform)
+#pragma unroll
+                for (int u = 0; u < GC_RPT; ++u) rows(b)[tid + u * GC_THREADS] = pv[b][u];
+                if (tid <= m) offs(b)[tid] = po;
+                ents(b)[tid] = pe;
+                load_rows(cc + 2, pv[b]);
+                load_index(cc + 1, po, pe);
+                __syncthreads();
+                const cl_f4 *sv = rows(b);
+                const int *so = offs(b);
+                const uint2 *se = ents(b);
+#pragma unroll
+                for (int i = 0; i < GC_TPT; ++i) {
+                    const int t = slot + i * (GC_THREADS / GC_S);
+                    if (t < m) {
+                        const int az = so[t], a = az & 0xffff, z = a + (az >> 16);
+                        for (int p = a; p < z; ++p) {
+                            const uint2 en = se[p];
+                            const float w = __uint_as_float(en.y);
+                            const cl_f4 v = sv[en.x * GC_S + col];
+                            acc[i].x = fmaf(w, v.x, acc[i].x);       // (the list walk's chain, component by component)
+                            acc[i].y = fmaf(w, v.y, acc[i].y);
+                            acc[i].z = fmaf(w, v.z, acc[i].z);
+                            acc[i].w = fmaf(w, v.w, acc[i].w);
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < GC_TPT; ++i) {
+        const int t = slot + i * (GC_THREADS / GC_S);
+        if (t < m) __builtin_nontemporal_store(acc[i], out + ((size_t)bi * m + t) * c4 + q);
+    }
+}
+
 struct RixLayout {
     long long t, pairs, off, bsum, rank, rev, revw, rtgt, tmp, rank_of, coff, cent, ints;
 };
@@ -2024,6 +2102,14 @@ GEOT_EXPORT int geot_gather_rows_csr_cl(int b, int c, int L, int m, int nt, cons
     if (c % 4 || c / 4 > 1024) return hipErrorInvalidValue;
     const RixLayout r = rix_layout(b, L, m, nt);
     if (r.pairs > 0x7ffffff0LL || r.t > 0x7ffffff0LL) return hipErrorInvalidValue;
+    if ((c / 4) % GC_S == 0 && gc_applies(L, m, nt) && (long long)b * (c / 4 / GC_S) <= 0x7fffffffLL) {       // few targets: see the BatchNorm form
+        const size_t lds = 2 * (size_t)(GC_K * GC_S * 16 + (GC_MAXM + 4) * 4 + GC_K * GC_MAXNT * 8);
+        hipError_t e = allow_big_lds((const void *)gather_rows_chunks_cl_kernel, lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gather_rows_chunks_cl_kernel, dim3((unsigned)(b * (c / 4 / GC_S))), dim3(GC_THREADS), lds, (hipStream_t)stream, c / 4,
+                           L, m, gc_chunks(L), (const cl_f4 *)g_cl, ws + r.coff, (const uint2 *)(ws + r.cent), (cl_f4 *)out_cl);
+        return hipGetLastError();
+    }
     const int c4 = c / 4, slabs = gr_slabs(c4), waves = (c4 / slabs + 63) / 64;
     const int cus = device_cus();
     static int per_cu_of[GEOT_DEV_SLOTS][1024 / 64 + 1];       // [device][waves] -> resident workgroups per CU

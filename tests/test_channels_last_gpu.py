@@ -488,6 +488,12 @@ def test_bn_row_gather_against_fp64_in_both_target_orders(b, n, m, c, kind, relu
             outs[(ordered, form)] = out
         assert torch.equal(outs[(ordered, "default")], outs[(ordered, "list")])
         outs[ordered] = outs[(ordered, "default")]
+        # the plain row gather over the same index, both forms
+        plain = {}
+        for form in ("default", "list"):
+            monkeypatch.setenv("GEOT_GR_FORM", form)
+            plain[form] = rix.gather(dz)
+        assert torch.equal(plain["default"], plain["list"])
     assert torch.equal(outs[True], outs[False])
     # fp64: gy = k0 (g - c1 - xhat c2), g = dz [relu: y k0 + shift > 0], then the interpolation gradient
     y64, dz64 = y.double().cpu(), dz.double().cpu()
