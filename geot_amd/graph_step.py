@@ -60,6 +60,17 @@ def tree_clone(obj):
     return obj
 
 
+def tree_detach(obj):
+    """The same buffers without their autograd history (tensors only; containers rebuilt, everything else as it is)."""
+    if torch.is_tensor(obj):
+        return obj.detach()
+    if isinstance(obj, dict):
+        return {k: tree_detach(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(tree_detach(v) for v in obj)
+    return obj
+
+
 def tree_copy_(dst, src, path="pre"):
     """Copy every tensor of `src` into the matching buffer of `dst`; the structure (and every python scalar) must agree."""
     if torch.is_tensor(dst):
@@ -153,6 +164,13 @@ class _Graphed:
                 self._eager_runs[name] = self._eager_runs.get(name, 0) + 1
                 return fn()
             torch.cuda.synchronize(self.device)
+            # Dead python cycles can hold an earlier iteration's autograd graph -- eager steps taken before this wrapper, the
+            # warm-up runs -- and with it every parameter's AccumulateGrad node, bound to the stream of THAT iteration; a
+            # backward under capture would hop to that stream and back: a fork inside the capture, which this runtime answers
+            # with a crash in hipStreamEndCapture (seen at 2 clouds after three eager steps; torch.cuda.graph collected
+            # unconditionally until 2.x made it optional).  Collect before every capture: three times in a wrapper's life.
+            import gc
+            gc.collect()
             graph = torch.cuda.CUDAGraph(keep_graph=True)         # (the hipGraph_t stays: node_types below)
             pool = self.graphs[pool_of][0].pool() if pool_of is not None else None
             refusal = None
@@ -221,7 +239,15 @@ class _Graphed:
                 self._pre_next = self._run("P", lookahead)
             self._pending = True
             self._announced = tuple((t, t._version) for t in next_src)
+        fresh = isinstance(train, tuple) and "M2" not in self.graphs
         out = self._run("M2", lambda: train[1](mid), pool_of="M1") if isinstance(train, tuple) else self._run("M", train)
+        if fresh and "M2" in self.graphs:
+            # M1's stored product (the cut: tensors with the capture-time iteration's autograd graph behind them) has done its
+            # job -- M2 is captured and a replay never runs the python backward again.  Kept as it was, it would hold that
+            # graph, every parameter's AccumulateGrad node with it (created on the capture stream), for the life of the
+            # wrapper, and an eager step afterwards (bench.py's other leg) would find them on the wrong stream.
+            g1, o1 = self.graphs["M1"]
+            self.graphs["M1"] = (g1, tree_detach(o1))
         self.calls += 1
         return out
 

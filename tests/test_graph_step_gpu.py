@@ -77,6 +77,49 @@ def test_supervised_step_from_a_graph_equals_eager(look, split):
     _same(runs["eager"][1], runs["graph"][1])
 
 
+@pytest.mark.parametrize("split", [False, True])
+def test_eager_steps_before_the_wrapper_do_not_reach_into_the_capture(split):
+    """A step that has ALREADY run eagerly (look-ahead on) and is wrapped afterwards: dead python cycles still hold those
+    iterations' autograd graphs -- every parameter's AccumulateGrad node with them, bound to the eager stream -- and a backward
+    under capture that meets them forks the capture (this runtime: a crash in hipStreamEndCapture, seen at 2 clouds in the
+    one-graph mode).  graph_step collects before every capture; the run continues with the bits of an all-eager run."""
+    import gc
+    from geot_amd.openpoints.models.backbone.transformer import PointTransformer_seg_T
+    from geot_amd import train_step as ts, graph_step as gs
+    batches = _sup_batches(2, 6000)
+    torch.manual_seed(0)
+    init = PointTransformer_seg_T(**SMALL).state_dict()
+    order = [0, 1, 0, 1, 0, 1, 0, 1]
+    runs = {}
+    was = gc.isenabled()
+    gc.disable()                   # (no collection by chance between the eager steps and the capture)
+    try:
+        for mode in ("eager", "mixed"):
+            m = PointTransformer_seg_T(**SMALL).to(DEV)
+            m.load_state_dict(init)
+            step = ts.SupervisedStep(m)
+            graphed = None
+            torch.manual_seed(7)
+            losses = []
+            for i, k in enumerate(order):
+                if mode == "mixed" and i == 3:
+                    graphed = gs.GraphedSupervisedStep(step, warmup=2, split=split)
+                cur, nxt = batches[k], batches[order[(i + 1) % len(order)]]
+                call = graphed if graphed is not None else step
+                # (the wrapper's first call finds the geometry the last eager step queued for this batch unused: it makes its own)
+                losses.append(call(cur[0], cur[1], cur[2], next_pos=nxt[0]).clone())
+            torch.cuda.synchronize()
+            if graphed is not None:
+                assert graphed.captured and all(set(v) == {"kernel"} for v in graphed.node_types.values())
+            runs[mode] = (losses, _state(step))
+    finally:
+        if was:
+            gc.enable()
+    for i, (a, b) in enumerate(zip(runs["eager"][0], runs["mixed"][0])):
+        assert torch.equal(a, b), (i, float(a), float(b))
+    _same(runs["eager"][1], runs["mixed"][1])
+
+
 def _fix_batch(seed, n=4096):
     from geot_amd.synth import make_batch, region_labels
     xl, xu = make_batch(2, n, start_index=seed)[0], make_batch(2, n, start_index=seed + 50)[0]
