@@ -52,6 +52,8 @@ def capture(graph, device=None, pool=None):
         return ev
     _KEPT = []
     torch.cuda.Stream.record_event = record_event
+    import gc
+    gc.collect()     # dead cycles may hold an earlier backward's AccumulateGrad nodes (another stream): graph_step._run has the story
     try:
         with torch.cuda.graph(graph, pool=pool):
             yield
