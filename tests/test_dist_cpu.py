@@ -189,3 +189,60 @@ def test_eight_rank_uneven_shards_and_anchor_exchange():
         np.testing.assert_allclose(r_corr, corr.numpy(), rtol=1e-14)
         np.testing.assert_allclose(r_nxt, nxt.numpy(), rtol=1e-14)
         assert owned == [2, 2, 2, 2, 2, 1, 0, 0] and t_max == 7.0 and total == 11.0
+
+
+def _gradsync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    from geot_amd import dist_utils, train_step as ts
+    dist_utils.init("gloo")
+    torch.manual_seed(100 + rank)                       # rank-different initial weights: both forms must start from rank 0's
+
+    def net():
+        return torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 16), torch.nn.ReLU(),
+                                   torch.nn.Linear(16, 3))
+    a, b = net(), net()
+    b.load_state_dict(a.state_dict())
+    ddp = torch.nn.parallel.DistributedDataParallel(a)              # broadcasts rank 0's parameters at construction
+    sync = ts.GradSync([b], dist.group.WORLD)                       # ... as this does
+    for p1, p2 in zip(a.parameters(), b.parameters()):
+        assert torch.equal(p1, p2)
+    oa, ob = torch.optim.SGD(a.parameters(), lr=0.1), torch.optim.SGD(b.parameters(), lr=0.1)
+    g = torch.Generator().manual_seed(7 + rank)                     # rank-different data
+    worst = 0.0
+    for _ in range(3):
+        x, y = torch.randn(5 + rank, 6, generator=g), torch.randn(5 + rank, 3, generator=g)
+        for model, opt, wrapped in ((a, oa, ddp), (b, ob, None)):
+            opt.zero_grad(set_to_none=True)
+            out = (wrapped or model)(x)
+            torch.nn.functional.mse_loss(out, y).backward()
+            if wrapped is None:
+                sync()
+            opt.step()
+        for p1, p2 in zip(a.parameters(), b.parameters()):
+            worst = max(worst, float((p1 - p2).abs().max()))
+    gathered = [torch.zeros(3) for _ in range(world)]
+    dist.all_gather(gathered, torch.cat([p.detach().reshape(-1) for p in b.parameters()])[:3].contiguous())
+    q.put((rank, worst, sync.collectives, [g_.tolist() for g_ in gathered]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_flat_gradient_exchange_equals_ddp():
+    """train_step.GradSync -- the ONE flat all-reduce a hipGraph-replayed step exchanges its gradients with (graph_step cannot
+    hold DistributedDataParallel) -- against DistributedDataParallel itself, two ranks over gloo: the same parameters after
+    three optimizer steps on rank-different data (mean of the ranks' gradients, divided before the sum as the reducer does),
+    the same on both ranks, one collective per step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gradsync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, collectives, gathered in res:
+        assert worst == 0.0, (rank, worst)              # two addends: the sum has one order
+        assert collectives == 3
+        assert gathered[0] == gathered[1]               # the ranks hold the same parameters
